@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py -- k-mers/s through hetmers (k=31) on N MI355X GPUs, with roofline + CPU baseline.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched under
+torch.distributed.run with one rank per GPU (RCCL).  Rank 0 prints ONE JSON line.
+
+A "step" = one complete hetmers computation (pass 1 -> complement exchange + symmetry proof ->
+pass 2 -> histogram reduction) over the whole device-resident table.  Workload at N=1 is
+BASELINE.json configs[2]: "Synthetic diploid 1 Gbp, 50x cov, k=31" generated on device
+(smudgeplot_amd/synth_device.py); --genome scales it (stated in config.workload).
+N>1: STRONG scaling -- the same table, prefix-sharded across the ranks; one all_to_all of the
+complement requests and one all_reduce of the 2-D histogram per step.
+
+value = table entries (k-mers) x steps / wall time, wall = max over ranks between barriers.
+"""
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from smudgeplot_amd import engine, ktab, sharded, synth, synth_device  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+ALG_BYTES_PER_KMER_PASS = 11   # k=31: TBYTE (8+2) read per pass + 1 degree byte written/read
+                               # => 22 B/k-mer over both passes
+
+
+def cpu_baseline(sample_n0: int, k: int, L: int):
+    """Time the REFERENCE hetmers binary (oracle/_ref, compiled from the reference's own sources)
+    on a bounded sample of the same kind of table, on this box's host cores."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "hetmers_ref")
+    if not os.path.exists(ref):
+        return None
+    cores = min(64, os.cpu_count() or 1)
+    keys, cnt = synth.diploid_table_u64(sample_n0, k=k, seed=7, het_frac=0.3, cov=50.0, L=L)
+    with tempfile.TemporaryDirectory(prefix="smg_cpu") as d:
+        synth.write_u64_table(os.path.join(d, "t"), keys, cnt, k, ibyte=3, nparts=4)
+        best = None
+        for _ in range(2):                       # second run = warm page cache
+            out = os.path.join(d, "cpu.smu")
+            if os.path.exists(out):
+                os.remove(out)
+            t0 = time.time()
+            subprocess.run([ref, f"-e{L}", f"-T{cores}", "-ocpu", "t.ktab"], cwd=d, check=True,
+                           capture_output=True)
+            best = time.time() - t0
+    return {"value": len(cnt) / best, "unit": "k-mers/s", "cores": cores, "kind": "reference",
+            "sample": f"reference hetmers -T{cores} on a {len(cnt)}-entry synthetic diploid k={k} "
+                      f"table (warm second run, {best:.1f} s wall)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome", type=float, default=1e9, help="haploid genome size in bases")
+    ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--L", type=int, default=10)
+    ap.add_argument("--symcheck", default="exact", choices=["exact", "hash"])
+    ap.add_argument("--cpu-sample", type=int, default=8_000_000)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- workload: identical table on every rank, then keep this rank's prefix shard ----------
+    G = int(args.genome)
+    keys, cnt = synth_device.diploid_table(G, k=args.k, het=0.01, cov=50.0, L=args.L, seed=1, device=dev)
+    n_total = cnt.numel()
+    if world > 1:
+        cuts = [0]
+        kcpu = None
+        for r in range(1, world):
+            c = (n_total * r) // world
+            # move the cut to a window-block boundary (first k//2 bases differ)
+            sh = 64 - 2 * (args.k // 2)
+            pref = keys >> sh
+            while c < n_total and int(pref[c]) == int(pref[c - 1]):
+                c += 1
+            cuts.append(c)
+        cuts.append(n_total)
+        lo, hi = cuts[rank], cuts[rank + 1]
+        keys = keys[lo:hi].clone()
+        cnt = cnt[lo:hi].clone()
+        del kcpu
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+
+    eng_stats = []
+
+    def step():
+        plot, st = sharded.hetmers_sharded(args.k, keys, cnt, symcheck=args.symcheck)
+        eng_stats.append(st)
+        return plot
+
+    for _ in range(args.warmup):
+        step()
+    eng_stats.clear()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        plot = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- roofline of the dominant kernel, from HIP events recorded by the engine on its stream
+    ms = {key: float(np.mean([s[key] for s in eng_stats])) for key in ("ms_pass1", "ms_rclookup", "ms_pass2")}
+    dom = max(ms, key=ms.get)
+    n_local = cnt.numel()
+    if dom == "ms_rclookup":
+        # look-up kernels: algorithmic traffic = one 8-byte k-mer + 2-byte count per request
+        alg = float(np.mean([s["nrequests"] for s in eng_stats])) * 10.0 if args.symcheck == "hash" \
+            else n_local * 10.0
+    else:
+        alg = n_local * float(ALG_BYTES_PER_KMER_PASS)
+    achieved = alg / (ms[dom] * 1e-3) / 1e9 if ms[dom] > 0 else 0.0
+
+    if rank == 0:
+        cpu = None if args.no_cpu else cpu_baseline(args.cpu_sample, args.k, args.L)
+        value = n_total * args.steps / dt
+        out = {
+            "metric": "k-mers/sec through hetmers (k=31)",
+            "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"synthetic diploid {G:.3g} bp, 50x, 1% het, k={args.k}, L={args.L}: "
+                                   f"{n_total} table entries (conditioned, rc-closed)",
+                       "symcheck": args.symcheck, "sharding": f"prefix x{world}"},
+            "roofline": {"bound": "hbm", "kernel": {"ms_pass1": "k_pass1", "ms_pass2": "k_pass2",
+                                                     "ms_rclookup": "k_apply+k_verify"}[dom],
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": ms, "whole_job_frac_of_22B_roofline":
+                             (n_total * 22.0 / (dt / args.steps)) / 1e9 / (HBM_PEAK_GBS * world)},
+            "cpu_baseline": cpu,
+            "pairs_in_plot": int(plot.sum().item()),
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

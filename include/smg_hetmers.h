@@ -1,0 +1,164 @@
+/*******************************************************************************************
+ *
+ *  smg_hetmers.h -- C ABI of the MI355X-native heterozygous k-mer pair engine.
+ *
+ *  The reference (KamilSJaron/smudgeplot) has no in-process plugin API for this path: its
+ *  boundary is the `hetmers` PROCESS (src/smudgeplot/cli.py:57-72 run_binary) plus two file
+ *  formats (FastK .ktab in, .smu out).  The drop-in executable lives in
+ *  smudgeplot_amd/csrc/hetmers_main.c; it is plain C and reaches the GPU only through the
+ *  entry points declared here, which are what a cgo/ctypes/JNI binding of this path would bind.
+ *  Each entry point names the reference code it stands in for.
+ *
+ *  Conventions (all entry points):
+ *    - plain pointers and sizes only; no C++/torch types; `void *stream` is a hipStream_t
+ *      (NULL = the device's default stream);
+ *    - return 0 on success, a negative SMG_E* code on failure with a message in errbuf
+ *      (never calls exit(), never prints unless opts->verbose asks for timing lines on stderr);
+ *    - NO CPU fallback: without a usable gfx950 device every compute call fails with
+ *      SMG_ENODEV.  (The CPU restatement lives under oracle/ and is test infrastructure.)
+ *    - one engine per device per thread of control; an engine is not re-entrant.
+ *
+ ********************************************************************************************/
+
+#ifndef SMG_HETMERS_H
+#define SMG_HETMERS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMG_SMAX        1000                     /* PloidyPlot.c:48  max covA+covB            */
+#define SMG_FMAX         500                     /* PloidyPlot.c:49  max min(covA,covB)       */
+#define SMG_PLOT_ROWS   (SMG_SMAX + 1)
+#define SMG_PLOT_COLS   (SMG_FMAX + 1)
+#define SMG_PLOT_CELLS  (SMG_PLOT_ROWS * SMG_PLOT_COLS)   /* int64 plot[sum][min], row major   */
+#define SMG_MAX_KMER     128                     /* keys are 1..4 64-bit words                */
+
+#define SMG_OK        0
+#define SMG_ENODEV   -1      /* no usable HIP device / HIP runtime error                     */
+#define SMG_EINVAL   -2      /* bad argument (k out of range, n too large, null pointer ...)  */
+#define SMG_ENOMEM   -3      /* device or host allocation failed                             */
+#define SMG_EFORMAT  -4      /* table violates format F (unsorted, duplicate k-mers ...)      */
+#define SMG_ENOTSYM  -5      /* sharded run on a table that is not reverse-complement closed */
+
+/* How the engine proves that the table is closed under reverse complement with equal counts
+   (the property `Symmex` establishes; the reference only spot-checks entry #1,
+   PloidyPlot.c:1199-1229).  If the proof fails the engine silently switches to the general
+   all-positions path, which assumes nothing, so the answer is the reference's either way. */
+#define SMG_SYM_EXACT  0     /* look up the complement of EVERY entry (exact, default)        */
+#define SMG_SYM_HASH   1     /* 128-bit additive multiset fingerprint of T vs rc(T) + exact   */
+                             /* look-ups for the entries that own a pair (fast)               */
+#define SMG_SYM_NONE   2     /* never use the symmetry identity: general path only            */
+
+/* A FastK table in host memory, exactly as it sits on disk minus the file headers.
+   Replaces: Kmer_Stream / Open_Kmer_Stream, src/lib/libfastk.c:717-745, 786-908.            */
+typedef struct smg_table_view
+{ int32_t               kmer;          /* k                                                    */
+  int32_t               ibyte;         /* prefix bytes folded into the index: 1, 2 or 3        */
+  int32_t               nparts;        /* number of part files                                 */
+  int32_t               minval;        /* stub header field, informational                     */
+  int64_t               nels;          /* total entries                                        */
+  const uint8_t *const *part_data;     /* [nparts] raw records, (kbyte+2-ibyte) bytes each     */
+  const int64_t        *part_nels;     /* [nparts] entries per part                            */
+  const int64_t        *prefix_index;  /* [2^(8*ibyte)] cumulative END offsets                 */
+} smg_table_view;
+
+typedef struct smg_opts
+{ int32_t device;        /* HIP device ordinal                                               */
+  int32_t symcheck;      /* SMG_SYM_*                                                        */
+  int32_t verbose;       /* >0: per-phase timing lines on stderr                             */
+  int32_t reserved;
+} smg_opts;
+
+typedef struct smg_stats
+{ int64_t nels;          /* entries scanned                                                  */
+  int64_t npairs;        /* one-away pairs that entered the histogram (weighted)             */
+  int64_t nrequests;     /* complement look-ups issued                                       */
+  int32_t path;          /* 1 = symmetric half-scan, 2 = general all-positions path          */
+  int32_t key_words;     /* 64-bit words per k-mer                                           */
+  double  ms_h2d;        /* host -> device copies                                            */
+  double  ms_decode;     /* format F records -> device table                                 */
+  double  ms_pass1;      /* window scan + degree                                             */
+  double  ms_rclookup;   /* complement look-ups / degree exchange                            */
+  double  ms_pass2;      /* unique-pair histogram                                            */
+  double  ms_total;      /* decode .. histogram on device (no H2D)                           */
+} smg_stats;
+
+/* ---- one-shot entry: host FastK table -> plot ------------------------------------------
+   Replaces the compute section of main(), PloidyPlot.c:1433-1575 (both passes over the
+   conditioned table and the reduction of the per-thread plots).
+   plot: caller-allocated int64[SMG_PLOT_CELLS], overwritten.  stats may be NULL.            */
+int smg_hetmers_run(const smg_table_view *table, const smg_opts *opts, int64_t *plot,
+                    smg_stats *stats, char *errbuf, size_t errlen);
+
+/* number of usable HIP devices (0 when there is none or the runtime is missing)             */
+int smg_device_count(void);
+
+/* ---- engine object: device-resident table, phase-level calls ---------------------------
+   Used by the one-shot entry, by bench.py and by the one-process-per-GPU sharded driver
+   (smudgeplot_amd/sharded.py), which interleaves the phases with RCCL collectives issued
+   through torch.distributed.  Device pointers handed in must belong to `device`.            */
+typedef struct smg_engine smg_engine;
+
+smg_engine *smg_engine_create(int device, void *stream, char *errbuf, size_t errlen);
+void        smg_engine_destroy(smg_engine *e);
+
+/* Decode `nels` format-F records already in device memory (parts concatenated, file headers
+   stripped) plus the stub's prefix index into the engine's own table.
+   Replaces Current_Entry / Next_Kmer_Entry expansion, libfastk.c:1159-1176, 1230-1269, and
+   the cache fill of small_recursion, PloidyPlot.c:954-961.                                   */
+int smg_engine_decode(smg_engine *e, int kmer, int ibyte, int64_t nels,
+                      const uint8_t *d_records, const int64_t *d_prefix_index,
+                      char *errbuf, size_t errlen);
+
+/* Bind an already decoded device table (not copied; must outlive the engine's use of it):
+   d_keys  = nels * words 64-bit words, k-mer left aligned (base 0 in bits 63..62 of word 0),
+             words = ceil(k/32), entries strictly increasing;
+   d_counts= nels uint16.                                                                     */
+int smg_engine_bind(smg_engine *e, int kmer, int64_t nels, const uint64_t *d_keys,
+                    const uint16_t *d_counts, char *errbuf, size_t errlen);
+
+/* Whole single-GPU computation on the bound/decoded table; d_plot = int64[SMG_PLOT_CELLS]
+   in device memory, overwritten.  Asynchronous on the engine's stream except for the small
+   control read-backs between phases.                                                         */
+int smg_engine_run(smg_engine *e, int symcheck, int64_t *d_plot, smg_stats *stats,
+                   char *errbuf, size_t errlen);
+
+/* ---- sharded (one process per GPU) phase calls ------------------------------------------
+   The table is split by k-mer PREFIX: rank r owns the entries in [splitter[r-1], splitter[r]).
+   Every position the half-scan visits is shard local; the only cross-shard traffic is one
+   record per entry that owns a suffix-side pair, sent to the rank that owns its complement.
+
+   pass1   : window scan, fills degrees, builds the request list, accumulates the fingerprints.
+   nreq    : number of pending requests.
+   route   : writes the requests grouped by destination rank into d_send (capacity in records)
+             and the per-rank counts into counts[nranks] (host).  A record is
+             (words+1) uint64: the complement k-mer, then count | value<<16.
+             splitters = (nranks-1)*words host uint64, the first k-mer of ranks 1..nranks-1.
+   apply   : adds received (or own) requests to the local degrees; *missing counts requests
+             whose k-mer is absent or carries another count (=> table not symmetric).
+   symhash : out[0..1] = fingerprint of T, out[2..3] = fingerprint of rc(T) (sum over ranks
+             with wrap-around and compare).
+   pass2   : histogram of unique pairs into d_plot (device int64[SMG_PLOT_CELLS], overwritten).*/
+int     smg_engine_pass1(smg_engine *e, int symcheck, char *errbuf, size_t errlen);
+int64_t smg_engine_nreq(smg_engine *e);
+int     smg_engine_record_words(smg_engine *e);
+int     smg_engine_route(smg_engine *e, const uint64_t *splitters, int nranks, uint64_t *d_send,
+                         int64_t capacity, int64_t *counts, char *errbuf, size_t errlen);
+int     smg_engine_apply(smg_engine *e, const uint64_t *d_recv, int64_t nrecv, int64_t *missing,
+                         char *errbuf, size_t errlen);
+int     smg_engine_apply_own(smg_engine *e, int64_t *missing, char *errbuf, size_t errlen);
+int     smg_engine_symhash(smg_engine *e, uint64_t out[4], char *errbuf, size_t errlen);
+int     smg_engine_pass2(smg_engine *e, int64_t *d_plot, char *errbuf, size_t errlen);
+int     smg_engine_stats(smg_engine *e, smg_stats *stats);
+
+/* library / build identification, e.g. "smudgeplot_amd 0.1 gfx950" */
+const char *smg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,190 @@
+// smg_device.hpp -- device-side primitives of the hetmers engine (gfx950 / CDNA4, wave64).
+//
+// K-mer layout in HBM: W = ceil(k/32) 64-bit words per entry, interleaved (entry i occupies
+// words [i*W, i*W+W)), left aligned: base b sits in bits (63-2(b%32), 62-2(b%32)) of word b/32,
+// a=0 c=1 g=2 t=3, pad bits zero.  Unsigned word-wise comparison therefore equals the bytewise
+// order of the FastK table (libfastk.c:614-636 packing, PloidyPlot.c:125-131 mycmp).
+
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SMG_DEV __device__ __forceinline__
+
+typedef unsigned long long u64;
+
+template <int W> struct Key { u64 w[W]; };
+
+template <int W> SMG_DEV Key<W> load_key(const u64 *__restrict__ keys, int64_t i)
+{ Key<W> x;
+  if constexpr (W == 1) { x.w[0] = keys[i]; }
+  else if constexpr (W == 2)
+    { const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(keys + 2 * i);
+      x.w[0] = v.x; x.w[1] = v.y;
+    }
+  else if constexpr (W == 4)
+    { const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(keys + 4 * i);
+      const ulonglong2 b = *reinterpret_cast<const ulonglong2 *>(keys + 4 * i + 2);
+      x.w[0] = a.x; x.w[1] = a.y; x.w[2] = b.x; x.w[3] = b.y;
+    }
+  else
+    {
+#pragma unroll
+      for (int w = 0; w < W; w++) x.w[w] = keys[(int64_t) W * i + w];
+    }
+  return x;
+}
+
+template <int W> SMG_DEV bool key_eq(const Key<W> &a, const Key<W> &b)
+{ bool e = true;
+#pragma unroll
+  for (int w = 0; w < W; w++) e &= (a.w[w] == b.w[w]);
+  return e;
+}
+
+template <int W> SMG_DEV bool key_lt(const Key<W> &a, const Key<W> &b)
+{
+#pragma unroll
+  for (int w = 0; w < W; w++)
+    { if (a.w[w] != b.w[w]) return a.w[w] < b.w[w]; }
+  return false;
+}
+
+// Geometry of one run, uniform over the grid (lives in SGPRs).
+struct Geo
+{ int  k;          // k-mer length
+  int  p0;         // first position the window scan covers: ceil((k-1)/2) on the symmetric path
+  int  pw;         // word that holds base p0
+  u64  pmask;      // bits of word pw that belong to bases < p0 (0 when p0 % 32 == 0)
+  int  mid;        // the self-mirrored position (k-1)/2 for odd k, -1 for even k
+  int  wrap;       // k > 85: a uint8 degree can wrap (PloidyPlot.c:163), emulate exactly
+};
+
+// do x and y share their first p0 bases?  (same "window block")
+template <int W> SMG_DEV bool same_block(const Key<W> &x, const Key<W> &y, const Geo &g)
+{ bool e = true;
+#pragma unroll
+  for (int w = 0; w < W; w++)
+    { if (w < g.pw) e &= (x.w[w] == y.w[w]); }
+  u64 d = 0;
+#pragma unroll
+  for (int w = 0; w < W; w++)
+    { if (w == g.pw) d = (x.w[w] ^ y.w[w]) & g.pmask; }
+  return e && d == 0;
+}
+
+// position of the single differing base, or -1 when x and y differ at 0 or >= 2 bases
+template <int W> SMG_DEV int pair_pos(const Key<W> &x, const Key<W> &y)
+{ int n = 0, pos = -1;
+#pragma unroll
+  for (int w = 0; w < W; w++)
+    { const u64 d = x.w[w] ^ y.w[w];
+      const u64 t = (d | (d >> 1)) & 0x5555555555555555ull;
+      n += __popcll(t);
+      if (t) pos = w * 32 + (__clzll((long long) t) >> 1);
+    }
+  return n == 1 ? pos : -1;
+}
+
+// x with base p replaced by (base ^ d), d in 1..3
+template <int W> SMG_DEV Key<W> flip_base(const Key<W> &x, int p, int d)
+{ Key<W> y = x;
+  const int w = p >> 5;
+  const u64 m = (u64) d << (62 - 2 * (p & 31));
+#pragma unroll
+  for (int v = 0; v < W; v++)
+    { if (v == w) y.w[v] ^= m; }
+  return y;
+}
+
+SMG_DEV u64 rev2_word(u64 x)        // reverse the order of the 32 2-bit groups of a word
+{ x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+  x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+  x = ((x >> 8) & 0x00FF00FF00FF00FFull) | ((x & 0x00FF00FF00FF00FFull) << 8);
+  x = ((x >> 16) & 0x0000FFFF0000FFFFull) | ((x & 0x0000FFFF0000FFFFull) << 16);
+  return (x >> 32) | (x << 32);
+}
+
+// reverse complement of a left aligned k-mer (restates compress_comp, PloidyPlot.c:1143-1165)
+template <int W> SMG_DEV Key<W> revcomp(const Key<W> &x, int k)
+{ Key<W> r, o;
+#pragma unroll
+  for (int w = 0; w < W; w++) r.w[w] = rev2_word(~x.w[W - 1 - w]);
+  // r holds the complement reversed over 32*W bases: the wanted k bases are the LAST k of it,
+  // i.e. shift the whole W-word value left by 2*(32W-k) bits (always < 64)
+  const int s = 2 * (32 * W - k);
+#pragma unroll
+  for (int w = 0; w < W; w++)
+    { u64 v = r.w[w] << s;
+      if (w + 1 < W && s) v |= r.w[w + 1] >> (64 - s);
+      o.w[w] = v;
+    }
+  return o;
+}
+
+// first index in [lo,hi) whose key is >= t
+template <int W> SMG_DEV int64_t lower_bound_key(const u64 *__restrict__ keys, int64_t lo,
+                                                 int64_t hi, const Key<W> &t)
+{ while (lo < hi)
+    { const int64_t m = (lo + hi) >> 1;
+      if (key_lt<W>(load_key<W>(keys, m), t)) lo = m + 1; else hi = m;
+    }
+  return lo;
+}
+
+// bucket directory over the first word: bstart[b] = first entry whose bucket is >= b
+struct Dir
+{ const uint32_t *bstart;
+  u64      base;      // first word of the first entry
+  int      shift;
+  uint32_t nb;        // number of buckets; bstart has nb+1 entries
+};
+
+template <int W> SMG_DEV int64_t find_key(const u64 *__restrict__ keys, const Dir &d,
+                                          const Key<W> &t)
+{ if (t.w[0] < d.base) return -1;
+  const u64 b = (t.w[0] - d.base) >> d.shift;
+  if (b >= d.nb) return -1;
+  int64_t lo = d.bstart[b], hi = d.bstart[b + 1];
+  lo = lower_bound_key<W>(keys, lo, hi, t);
+  if (lo < hi && key_eq<W>(load_key<W>(keys, lo), t)) return lo;
+  return -1;
+}
+
+SMG_DEV u64 mix64(u64 z)
+{ z ^= z >> 30; z *= 0xbf58476d1ce4e5b9ull;
+  z ^= z >> 27; z *= 0x94d049bb133111ebull;
+  z ^= z >> 31;
+  return z;
+}
+
+template <int W> SMG_DEV u64 hash_entry(const Key<W> &x, unsigned c, u64 seed)
+{ u64 a = seed;
+#pragma unroll
+  for (int w = 0; w < W; w++) a = mix64(a ^ x.w[w]);
+  return mix64(a ^ (u64) c ^ 0x9e3779b97f4a7c15ull);
+}
+
+SMG_DEV u64 wave_sum_u64(u64 v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// add v (< 256) to the byte deg[j]; the table is padded to a multiple of 4 bytes
+SMG_DEV void deg_add(uint8_t *deg, int64_t j, unsigned v, int wrap)
+{ unsigned *wp = reinterpret_cast<unsigned *>(deg + (j & ~(int64_t) 3));
+  const unsigned sh = (unsigned) (j & 3) * 8;
+  if (!wrap)
+    atomicAdd(wp, v << sh);                 // deg <= 3k <= 255: no carry into the neighbour
+  else
+    { unsigned old = *wp, assumed;
+      do
+        { assumed = old;
+          const unsigned b = ((assumed >> sh) + v) & 0xFFu;
+          old = atomicCAS(wp, assumed, (assumed & ~(0xFFu << sh)) | (b << sh));
+        }
+      while (old != assumed);
+    }
+}

@@ -1,0 +1,180 @@
+/* smg_ktab.c -- host loader for FastK tables (format F).  See smg_ktab.h. */
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/stat.h>
+
+#include "smg_ktab.h"
+
+static int read_full(int fd, void *buf, size_t n)
+{ uint8_t *p = (uint8_t *) buf;
+  while (n > 0)
+    { ssize_t r = read(fd, p, n > (1u << 30) ? (1u << 30) : n);
+      if (r <= 0) return -1;
+      p += r; n -= (size_t) r;
+    }
+  return 0;
+}
+
+int smg_ktab_load(const char *name, smg_ktab *t, char *what)
+{ const char *slash = strrchr(name, '/');
+  char  *dir, *root, *path;
+  size_t len;
+  int    fd, p, rc = SMG_KTAB_OK;
+  int32_t hdr[4];
+
+  memset(t, 0, sizeof(*t));
+  if (slash) { dir = strndup(name, (size_t) (slash - name)); root = strdup(slash + 1); }
+  else       { dir = strdup(".");                              root = strdup(name); }
+  len = strlen(root);                       /* Root(name,".ktab"), gene_core.c Root()          */
+  if (len > 5 && strcasecmp(root + len - 5, ".ktab") == 0) root[len - 5] = 0;
+  path = (char *) malloc(strlen(dir) + strlen(root) + 64);
+  if (!dir || !root || !path) { rc = SMG_KTAB_NOMEM; goto out; }
+
+  sprintf(path, "%s/%s.ktab", dir, root);
+  if (what) snprintf(what, 4096, "%s", path);
+  fd = open(path, O_RDONLY);
+  if (fd < 0) { rc = SMG_KTAB_NOSTUB; goto out; }
+  if (read_full(fd, hdr, sizeof(hdr))) { close(fd); rc = SMG_KTAB_SHORT; goto out; }
+  t->kmer = hdr[0]; t->nparts = hdr[1]; t->minval = hdr[2]; t->ibyte = hdr[3];
+  if (t->kmer < 1 || t->nparts < 0 || t->ibyte < 1 || t->ibyte > 3)
+    { close(fd); rc = SMG_KTAB_SHORT; goto out; }
+  t->kbyte = (t->kmer + 3) >> 2;
+  t->tbyte = t->kbyte + 2;
+  t->pbyte = t->tbyte - t->ibyte;
+  t->hbyte = t->kbyte - t->ibyte;
+  t->ixlen = 1ll << (8 * t->ibyte);
+  t->index = (int64_t *) malloc(sizeof(int64_t) * (size_t) t->ixlen);
+  t->part = (uint8_t **) calloc((size_t) (t->nparts > 0 ? t->nparts : 1), sizeof(uint8_t *));
+  t->part_nels = (int64_t *) calloc((size_t) (t->nparts > 0 ? t->nparts : 1), sizeof(int64_t));
+  t->part_end = (int64_t *) calloc((size_t) (t->nparts > 0 ? t->nparts : 1), sizeof(int64_t));
+  if (!t->index || !t->part || !t->part_nels || !t->part_end)
+    { close(fd); rc = SMG_KTAB_NOMEM; goto out; }
+  if (read_full(fd, t->index, sizeof(int64_t) * (size_t) t->ixlen))
+    { close(fd); rc = SMG_KTAB_SHORT; goto out; }
+  close(fd);
+
+  for (p = 1; p <= t->nparts; p++)
+    { int32_t km; int64_t n;
+      sprintf(path, "%s/.%s.ktab.%d", dir, root, p);
+      if (what) snprintf(what, 4096, "%s", path);
+      fd = open(path, O_RDONLY);
+      if (fd < 0) { rc = SMG_KTAB_NOPART; goto out; }
+      if (read_full(fd, &km, 4) || read_full(fd, &n, 8)) { close(fd); rc = SMG_KTAB_SHORT; goto out; }
+      if (km != t->kmer) { close(fd); rc = SMG_KTAB_KMISMATCH; goto out; }
+      if (n < 0) { close(fd); rc = SMG_KTAB_SHORT; goto out; }
+      t->part[p - 1] = (uint8_t *) malloc((size_t) (n > 0 ? n : 1) * (size_t) t->pbyte);
+      if (!t->part[p - 1]) { close(fd); rc = SMG_KTAB_NOMEM; goto out; }
+      if (n > 0 && read_full(fd, t->part[p - 1], (size_t) n * (size_t) t->pbyte))
+        { close(fd); rc = SMG_KTAB_SHORT; goto out; }
+      close(fd);
+      t->part_nels[p - 1] = n;
+      t->nels += n;
+      t->part_end[p - 1] = t->nels;
+    }
+out:
+  free(dir); free(root); free(path);
+  if (rc != SMG_KTAB_OK) smg_ktab_free(t);
+  return rc;
+}
+
+void smg_ktab_free(smg_ktab *t)
+{ int p;
+  if (t->part)
+    for (p = 0; p < t->nparts; p++) free(t->part[p]);
+  free(t->part); free(t->part_nels); free(t->part_end); free(t->index);
+  memset(t, 0, sizeof(*t));
+}
+
+static const uint8_t *record_at(const smg_ktab *t, int64_t i)
+{ int p = 0;
+  int64_t base = 0;
+  while (p < t->nparts - 1 && i >= t->part_end[p]) p++;
+  if (p > 0) base = t->part_end[p - 1];
+  return t->part[p] + (size_t) (i - base) * (size_t) t->pbyte;
+}
+
+static int64_t prefix_of(const smg_ktab *t, int64_t i)      /* smallest p with index[p] > i */
+{ int64_t lo = 0, hi = t->ixlen - 1;
+  while (lo < hi)
+    { int64_t m = (lo + hi) >> 1;
+      if (t->index[m] <= i) lo = m + 1; else hi = m;
+    }
+  return lo;
+}
+
+void smg_ktab_entry(const smg_ktab *t, int64_t i, uint8_t *kmer_out, int *count_out)
+{ const uint8_t *r = record_at(t, i);
+  int64_t pre = prefix_of(t, i);
+  int j;
+  for (j = 0; j < t->ibyte; j++)
+    kmer_out[j] = (uint8_t) ((pre >> (8 * (t->ibyte - 1 - j))) & 0xFF);
+  memcpy(kmer_out + t->ibyte, r, (size_t) t->hbyte);
+  if (count_out) *count_out = r[t->hbyte] | (r[t->hbyte + 1] << 8);
+}
+
+int64_t smg_ktab_find(const smg_ktab *t, const uint8_t *kmer)
+{ int64_t m = 0, lo, hi;
+  int j;
+  for (j = 0; j < t->ibyte; j++) m = (m << 8) | kmer[j];
+  lo = m == 0 ? 0 : t->index[m - 1];
+  hi = t->index[m];
+  if (hi > t->nels) hi = t->nels;
+  while (lo < hi)
+    { int64_t mid = (lo + hi) >> 1;
+      if (memcmp(record_at(t, mid), kmer + t->ibyte, (size_t) t->hbyte) < 0) lo = mid + 1; else hi = mid;
+    }
+  if (lo < t->index[m] && lo < t->nels
+      && memcmp(record_at(t, lo), kmer + t->ibyte, (size_t) t->hbyte) == 0)
+    return lo;
+  return -1;
+}
+
+static void revcomp_packed(const uint8_t *x, uint8_t *out, int k, int kbyte)
+{ int i;
+  memset(out, 0, (size_t) kbyte);
+  for (i = 0; i < k; i++)
+    { int b = (x[i >> 2] >> (6 - 2 * (i & 3))) & 3;
+      int j = k - 1 - i;
+      out[j >> 2] |= (uint8_t) ((3 - b) << (6 - 2 * (j & 3)));
+    }
+}
+
+void smg_ktab_examine(const smg_ktab *t, int ethresh, int *trim, int *symm)
+{ int64_t frst, last, i, nz;
+  int64_t *hist = (int64_t *) calloc(0x8000, sizeof(int64_t));
+
+  /* "Histogram of middle 100M counts and see if trimmed to ETHRESH", PloidyPlot.c:1169-1197.
+     The reference indexes with the count read as int16; counts above 32767 are outside what
+     it (and FastK) supports, they are ignored here instead of writing out of bounds.        */
+  if (t->nels + 3 < 100000000) { frst = 0; last = t->nels; }
+  else { frst = t->nels / 2 - 50000000; last = t->nels / 2 + 50000000; }
+  for (i = frst; i < last; i++)
+    { const uint8_t *r = record_at(t, i);
+      int c = r[t->hbyte] | (r[t->hbyte + 1] << 8);
+      if (hist && c < 0x8000) hist[c] += 1;
+    }
+  nz = 0x8000;
+  if (hist)
+    for (nz = 1; nz < 0x8000 && hist[nz] == 0; nz++) ;
+  *trim = (nz >= ethresh);
+  free(hist);
+
+  /* "Walk to a non-palindromic k-mer and see if its complement is in T", PloidyPlot.c:1199-1229.
+     Net effect of that loop (including its quirk for a self-complementary entry #1, see
+     oracle/hetmers_oracle.c): symm = the complement of entry #1 is in the table.            */
+  *symm = 0;
+  if (t->nels > 1)
+    { uint8_t *x = (uint8_t *) malloc((size_t) t->kbyte * 2);
+      if (x)
+        { smg_ktab_entry(t, 1, x, NULL);
+          revcomp_packed(x, x + t->kbyte, t->kmer, t->kbyte);
+          *symm = smg_ktab_find(t, x + t->kbyte) >= 0;
+          free(x);
+        }
+    }
+}

@@ -1,0 +1,45 @@
+/* smg_ktab.h -- host-side (plain C) loader for FastK k-mer tables, "format F".
+ *
+ * Stands in for the Kmer_Stream part of the reference's libfastk
+ * (/root/reference/src/lib/libfastk.c:717-1409): instead of a seekable stream with 1024-record
+ * read(2) blocks, the whole table is read once into host memory (parts kept as they are on
+ * disk, headers stripped) so it can be handed to the GPU engine as a `smg_table_view`.
+ */
+#ifndef SMG_KTAB_H
+#define SMG_KTAB_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+typedef struct smg_ktab
+{ int       kmer, nparts, minval, ibyte;
+  int       kbyte, tbyte, hbyte, pbyte;     /* as in libfastk.c:823-827                        */
+  int64_t   nels;
+  int64_t   ixlen;
+  int64_t  *index;                          /* [ixlen] cumulative end offsets                  */
+  uint8_t **part;                           /* [nparts] raw records                            */
+  int64_t  *part_nels;                      /* [nparts]                                        */
+  int64_t  *part_end;                       /* [nparts] cumulative (neps, libfastk.c:857)      */
+} smg_ktab;
+
+#define SMG_KTAB_OK        0
+#define SMG_KTAB_NOSTUB    1     /* stub cannot be opened     (Open_Kmer_Stream returns NULL)   */
+#define SMG_KTAB_NOPART    2     /* "Table part %s is missing ?"            libfastk.c:850-853 */
+#define SMG_KTAB_KMISMATCH 3     /* "... does not have k-mer length matching stub ?"  858-862  */
+#define SMG_KTAB_NOMEM     4
+#define SMG_KTAB_SHORT     5     /* file shorter than its header promises                       */
+
+/* name: "<path>[.ktab]".  On failure `what` (>= 4096 bytes) receives the offending file name. */
+int  smg_ktab_load(const char *name, smg_ktab *t, char *what);
+void smg_ktab_free(smg_ktab *t);
+
+/* expand entry i into kbyte packed bytes (Current_Entry, libfastk.c:1230-1269) + its count     */
+void smg_ktab_entry(const smg_ktab *t, int64_t i, uint8_t *kmer_out, int *count_out);
+
+/* index of the entry equal to the packed k-mer, or -1 (GoTo_Kmer_Entry, libfastk.c:1320-1409)  */
+int64_t smg_ktab_find(const smg_ktab *t, const uint8_t *kmer);
+
+/* the reference's conditioning probe, PloidyPlot.c:1167-1230                                   */
+void smg_ktab_examine(const smg_ktab *t, int ethresh, int *trim, int *symm);
+
+#endif

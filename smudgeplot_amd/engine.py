@@ -1,0 +1,232 @@
+"""ctypes binding of the C ABI in include/smg_hetmers.h (libsmg_hetmers.so, built in-tree).
+
+This is the reference-side binding a maintainer would add if smudgeplot called the engine
+in-process instead of exec'ing the `hetmers` binary.  PyTorch is used only
+as plumbing by callers (device tensors, streams, torch.distributed); nothing here imports it.
+
+There is no CPU fallback: if the shared library is missing, or no HIP device is usable, the
+calls raise `EngineError`.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+SMAX, FMAX = 1000, 500
+PLOT_ROWS, PLOT_COLS = SMAX + 1, FMAX + 1
+PLOT_CELLS = PLOT_ROWS * PLOT_COLS
+
+SYM_EXACT, SYM_HASH, SYM_NONE = 0, 1, 2
+_SYM = {"exact": SYM_EXACT, "hash": SYM_HASH, "none": SYM_NONE}
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsmg_hetmers.so")
+BIN_PATH = os.path.join(_HERE, "bin", "hetmers")
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"smg_hetmers error {code}: {msg}")
+        self.code = code
+
+
+class TableView(C.Structure):
+    _fields_ = [("kmer", C.c_int32), ("ibyte", C.c_int32), ("nparts", C.c_int32),
+                ("minval", C.c_int32), ("nels", C.c_int64),
+                ("part_data", C.POINTER(C.c_void_p)), ("part_nels", C.POINTER(C.c_int64)),
+                ("prefix_index", C.POINTER(C.c_int64))]
+
+
+class Opts(C.Structure):
+    _fields_ = [("device", C.c_int32), ("symcheck", C.c_int32), ("verbose", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("nels", C.c_int64), ("npairs", C.c_int64), ("nrequests", C.c_int64),
+                ("path", C.c_int32), ("key_words", C.c_int32),
+                ("ms_h2d", C.c_double), ("ms_decode", C.c_double), ("ms_pass1", C.c_double),
+                ("ms_rclookup", C.c_double), ("ms_pass2", C.c_double), ("ms_total", C.c_double)]
+
+    def asdict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+EXPORTS = [
+    "smg_hetmers_run", "smg_device_count", "smg_engine_create", "smg_engine_destroy",
+    "smg_engine_decode", "smg_engine_bind", "smg_engine_run", "smg_engine_pass1",
+    "smg_engine_nreq", "smg_engine_record_words", "smg_engine_route", "smg_engine_apply",
+    "smg_engine_apply_own", "smg_engine_symhash", "smg_engine_pass2", "smg_engine_stats",
+    "smg_version",
+]
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree library; raises EngineError (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(-1, f"{LIB_PATH} is not built (run `python -c 'import __graft_entry__ as g; "
+                              f"g.build()'` or `make -C smudgeplot_amd/csrc`)")
+    lib = C.CDLL(LIB_PATH)
+    vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
+    err = (C.c_char_p, C.c_size_t)
+    lib.smg_version.restype = C.c_char_p
+    lib.smg_device_count.restype = i32
+    lib.smg_hetmers_run.argtypes = [C.POINTER(TableView), C.POINTER(Opts), vp, C.POINTER(Stats), *err]
+    lib.smg_engine_create.restype = vp
+    lib.smg_engine_create.argtypes = [i32, vp, *err]
+    lib.smg_engine_destroy.argtypes = [vp]
+    lib.smg_engine_decode.argtypes = [vp, i32, i32, i64, vp, vp, *err]
+    lib.smg_engine_bind.argtypes = [vp, i32, i64, vp, vp, *err]
+    lib.smg_engine_run.argtypes = [vp, i32, vp, C.POINTER(Stats), *err]
+    lib.smg_engine_pass1.argtypes = [vp, i32, *err]
+    lib.smg_engine_nreq.restype = i64
+    lib.smg_engine_nreq.argtypes = [vp]
+    lib.smg_engine_record_words.argtypes = [vp]
+    lib.smg_engine_route.argtypes = [vp, vp, i32, vp, i64, C.POINTER(i64), *err]
+    lib.smg_engine_apply.argtypes = [vp, vp, i64, C.POINTER(i64), *err]
+    lib.smg_engine_apply_own.argtypes = [vp, C.POINTER(i64), *err]
+    lib.smg_engine_symhash.argtypes = [vp, C.POINTER(C.c_uint64), *err]
+    lib.smg_engine_pass2.argtypes = [vp, vp, *err]
+    lib.smg_engine_stats.argtypes = [vp, C.POINTER(Stats)]
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, buf) -> None:
+    if rc != 0:
+        raise EngineError(rc, buf.value.decode(errors="replace"))
+
+
+def device_count() -> int:
+    return int(load_library().smg_device_count())
+
+
+def hetmers_run(table, device: int = 0, symcheck: str = "exact", verbose: int = 0):
+    """Host FastK table (`ktab.KTable`) -> (plot int64[1001,501], stats dict).
+
+    In-process equivalent of running the `hetmers` executable on a conditioned table
+    (reference: main(), src/lib/PloidyPlot.c:1433-1575).
+    """
+    lib = load_library()
+    kb = (table.k + 3) >> 2
+    pb = kb + 2 - table.ibyte
+    n = table.nels
+    rec = np.empty((n, pb), dtype=np.uint8)
+    rec[:, : kb - table.ibyte] = table.packed[:, table.ibyte:]
+    rec[:, kb - table.ibyte:] = np.ascontiguousarray(table.counts.astype("<u2")).view(np.uint8).reshape(n, 2)
+    parts, offs = [], 0
+    for pn in table.part_nels:
+        parts.append(np.ascontiguousarray(rec[offs: offs + int(pn)]))
+        offs += int(pn)
+    ptrs = (C.c_void_p * max(1, len(parts)))(*[p.ctypes.data for p in parts])
+    pn = np.ascontiguousarray(table.part_nels, dtype=np.int64)
+    idx = np.ascontiguousarray(table.index, dtype=np.int64)
+    tv = TableView(table.k, table.ibyte, len(parts), table.minval, n,
+                   C.cast(ptrs, C.POINTER(C.c_void_p)),
+                   pn.ctypes.data_as(C.POINTER(C.c_int64)),
+                   idx.ctypes.data_as(C.POINTER(C.c_int64)))
+    opts = Opts(device, _SYM[symcheck], verbose, 0)
+    plot = np.zeros(PLOT_CELLS, dtype=np.int64)
+    st = Stats()
+    buf = C.create_string_buffer(512)
+    rc = lib.smg_hetmers_run(C.byref(tv), C.byref(opts), plot.ctypes.data, C.byref(st), buf, 512)
+    _check(rc, buf)
+    return plot.reshape(PLOT_ROWS, PLOT_COLS), st.asdict()
+
+
+def smu_text(plot: np.ndarray) -> str:
+    """The `.smu` writer (reference: PloidyPlot.c:1603-1617): rows `covB\\tcovA\\tfreq`, sum
+    ascending then covB ascending, zero cells skipped, covB == 500 never printed."""
+    out = []
+    s_idx, m_idx = np.nonzero(plot[:, :FMAX])
+    for s, m in zip(s_idx.tolist(), m_idx.tolist()):
+        out.append(f"{m}\t{s - m}\t{int(plot[s, m])}\n")
+    return "".join(out)
+
+
+@dataclass
+class _Buf:
+    ptr: int
+
+
+class Engine:
+    """Device-resident engine object (phase-level API).  Device pointers are plain ints, e.g.
+    `tensor.data_ptr()` of torch tensors on the same device."""
+
+    def __init__(self, device: int = 0, stream: int = 0):
+        self.lib = load_library()
+        self._buf = C.create_string_buffer(512)
+        self.h = self.lib.smg_engine_create(device, stream or None, self._buf, 512)
+        if not self.h:
+            raise EngineError(-1, self._buf.value.decode(errors="replace"))
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.smg_engine_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def bind(self, k: int, nels: int, keys_ptr: int, counts_ptr: int):
+        _check(self.lib.smg_engine_bind(self.h, k, nels, keys_ptr, counts_ptr, self._buf, 512), self._buf)
+
+    def decode(self, k: int, ibyte: int, nels: int, records_ptr: int, index_ptr: int):
+        _check(self.lib.smg_engine_decode(self.h, k, ibyte, nels, records_ptr, index_ptr, self._buf, 512),
+               self._buf)
+
+    def run(self, plot_ptr: int, symcheck: str = "exact") -> dict:
+        st = Stats()
+        _check(self.lib.smg_engine_run(self.h, _SYM[symcheck], plot_ptr, C.byref(st), self._buf, 512),
+               self._buf)
+        return st.asdict()
+
+    # ---- sharded phases -------------------------------------------------------------------
+    def pass1(self, symcheck: str = "hash"):
+        _check(self.lib.smg_engine_pass1(self.h, _SYM[symcheck], self._buf, 512), self._buf)
+
+    def nreq(self) -> int:
+        return int(self.lib.smg_engine_nreq(self.h))
+
+    def record_words(self) -> int:
+        return int(self.lib.smg_engine_record_words(self.h))
+
+    def route(self, splitters: np.ndarray, nranks: int, send_ptr: int, capacity: int):
+        counts = (C.c_int64 * nranks)()
+        sp = np.ascontiguousarray(splitters, dtype=np.uint64)
+        _check(self.lib.smg_engine_route(self.h, sp.ctypes.data if sp.size else None, nranks, send_ptr,
+                                         capacity, counts, self._buf, 512), self._buf)
+        return [int(c) for c in counts]
+
+    def apply(self, recv_ptr: int, nrecv: int) -> int:
+        missing = C.c_int64(0)
+        _check(self.lib.smg_engine_apply(self.h, recv_ptr, nrecv, C.byref(missing), self._buf, 512),
+               self._buf)
+        return int(missing.value)
+
+    def apply_own(self) -> int:
+        missing = C.c_int64(0)
+        _check(self.lib.smg_engine_apply_own(self.h, C.byref(missing), self._buf, 512), self._buf)
+        return int(missing.value)
+
+    def symhash(self):
+        out = (C.c_uint64 * 4)()
+        _check(self.lib.smg_engine_symhash(self.h, out, self._buf, 512), self._buf)
+        return [int(v) for v in out]
+
+    def pass2(self, plot_ptr: int):
+        _check(self.lib.smg_engine_pass2(self.h, plot_ptr, self._buf, 512), self._buf)
+
+    def stats(self) -> dict:
+        st = Stats()
+        self.lib.smg_engine_stats(self.h, C.byref(st))
+        return st.asdict()

@@ -1,0 +1,179 @@
+"""One-process-per-GPU hetmers over a PREFIX-SHARDED table (RCCL through torch.distributed).
+
+Rank r owns a contiguous range of the globally sorted table (cut between k-mers, i.e. on a
+k-mer prefix boundary).  The reference has no distributed mode; its nearest analogue is the
+prefix-subtree task decomposition of `small_window` (src/lib/PloidyPlot.c:1040-1084).
+
+Data path per run (see DESIGN.md "Multi-GPU"):
+  1. pass 1 on every shard (window scan of the suffix-side positions: always shard local);
+  2. ONE exchange: every entry that owns a suffix-side pair sends (rc(kmer), count, S_hi) to the
+     rank that owns the reverse complement  -> all_to_all_single over xGMI;
+     the symmetry proof rides along: fingerprints (4 x u64) + missing count -> all_reduce;
+  3. pass 2 on every shard;
+  4. ONE all_reduce(SUM, int64[1001*501]) of the per-GPU 2-D histograms.
+
+torch is plumbing here: device buffers and collectives.  The compute is the C-ABI engine
+(`engine.Engine`); `engine_factory` lets the CPU test-suite substitute a numpy stand-in so the
+world_size>1 orchestration is exercised under gloo without a GPU.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import engine as _engine
+
+PLOT_CELLS = _engine.PLOT_CELLS
+
+
+class NotSymmetric(RuntimeError):
+    """The sharded path needs a reverse-complement closed table (what Symmex produces)."""
+
+
+class TorchEngine:
+    """Adapter: `engine.Engine` with torch tensors instead of raw device pointers."""
+
+    def __init__(self, device: torch.device):
+        assert device.type == "cuda", "the HIP engine needs a GPU (no CPU fallback)"
+        self.device = device
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        stream = torch.cuda.current_stream(device).cuda_stream
+        self.e = _engine.Engine(index, stream)
+
+    def bind(self, k, keys, counts):
+        self._keep = (keys, counts)
+        self.e.bind(k, counts.numel(), keys.data_ptr(), counts.data_ptr())
+
+    def pass1(self, symcheck):
+        self.e.pass1(symcheck)
+
+    def nreq(self):
+        return self.e.nreq()
+
+    def record_words(self):
+        return self.e.record_words()
+
+    def route(self, splitters, nranks, send):
+        return self.e.route(splitters, nranks, send.data_ptr(), send.numel() // self.e.record_words())
+
+    def apply(self, recv, nrecv):
+        return self.e.apply(recv.data_ptr(), nrecv)
+
+    def symhash(self):
+        return self.e.symhash()
+
+    def pass2(self, plot):
+        self.e.pass2(plot.data_ptr())
+
+    def stats(self):
+        return self.e.stats()
+
+
+def shard_bounds(n: int, world: int, keys_first_word=None):
+    """Even cut points [0..n] for `world` shards.  Cuts fall between k-mers, which is all the
+    window scan needs when the cut is also a window-block boundary; `fix_cut` moves them."""
+    return [(n * r) // world for r in range(world + 1)]
+
+
+def fix_cut(keys_u64: np.ndarray, words: int, k: int, cut: int) -> int:
+    """Move a cut forward to the next window-block boundary (entries that share their first
+    k//2 bases must stay on one rank)."""
+    n = len(keys_u64) // words
+    if cut <= 0 or cut >= n:
+        return min(max(cut, 0), n)
+    p0 = k // 2
+    kw = keys_u64.reshape(n, words)
+
+    def prefix(i):
+        out = []
+        for w in range(words):
+            bases = min(32, max(0, p0 - 32 * w))
+            if bases == 0:
+                break
+            out.append(int(kw[i, w]) >> (64 - 2 * bases))
+        return tuple(out)
+
+    while cut < n and prefix(cut) == prefix(cut - 1):
+        cut += 1
+    return cut
+
+
+def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: str = "hash",
+                    engine_factory=TorchEngine, group=None):
+    """Run hetmers on this rank's shard; returns (plot int64[1001*501] on the shard's device,
+    summed over all ranks, and a stats dict).  Collective: every rank must call it.
+
+    keys   : int64 tensor viewing the shard's uint64 k-mer words (n * ceil(k/32)), sorted
+    counts : int16 tensor viewing the shard's uint16 counts (n)
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    dev = keys.device
+    words = (k + 31) // 32
+    n = counts.numel()
+
+    eng = engine_factory(dev)
+    eng.bind(k, keys, counts)
+
+    # splitters = first k-mer of ranks 1..world-1 (an empty shard inherits its successor's)
+    first = torch.full((words,), -1, dtype=torch.int64, device=dev)       # all ones = +inf
+    if n > 0:
+        first.copy_(keys[:words])
+    if world > 1:
+        allfirst = [torch.empty_like(first) for _ in range(world)]
+        dist.all_gather(allfirst, first, group=group)
+        ns = torch.tensor([n], dtype=torch.int64, device=dev)
+        alln = [torch.empty_like(ns) for _ in range(world)]
+        dist.all_gather(alln, ns, group=group)
+        firsts = [t.cpu().numpy().view(np.uint64).copy() for t in allfirst]
+        sizes = [int(t.item()) for t in alln]
+        for r in range(world - 2, -1, -1):
+            if sizes[r] == 0:
+                firsts[r] = firsts[r + 1]
+        splitters = np.concatenate(firsts[1:]) if world > 1 else np.zeros(0, np.uint64)
+    else:
+        splitters = np.zeros(0, np.uint64)
+
+    eng.pass1(symcheck)
+    rw = eng.record_words()
+    nreq = eng.nreq()
+    send = torch.empty(max(nreq, 1) * rw, dtype=torch.int64, device=dev)
+    send_counts = eng.route(splitters, world, send)
+
+    if world > 1:
+        sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
+        rcnt = torch.empty_like(sc)
+        dist.all_to_all_single(rcnt, sc, group=group)
+        recv_counts = [int(v) for v in rcnt.cpu().tolist()]
+        nrecv = sum(recv_counts)
+        recv = torch.empty(max(nrecv, 1) * rw, dtype=torch.int64, device=dev)
+        dist.all_to_all_single(recv[: nrecv * rw], send[: nreq * rw],
+                               output_split_sizes=[c * rw for c in recv_counts],
+                               input_split_sizes=[c * rw for c in send_counts], group=group)
+    else:
+        recv, nrecv = send, nreq
+
+    missing = eng.apply(recv, nrecv)
+
+    # symmetry proof, reduced over ranks: missing == 0 and fingerprint(T) == fingerprint(rc T)
+    proof = np.array([missing] + eng.symhash(), dtype=np.uint64).view(np.int64)
+    proof_t = torch.from_numpy(proof.copy()).to(dev)
+    if world > 1:
+        dist.all_reduce(proof_t, op=dist.ReduceOp.SUM, group=group)      # wraps mod 2^64
+    pv = proof_t.cpu().numpy().view(np.uint64)
+    symmetric = pv[0] == 0
+    if symcheck == "hash":
+        symmetric = symmetric and pv[1] == pv[3] and pv[2] == pv[4]
+    if not symmetric:
+        raise NotSymmetric("table is not closed under reverse complement with equal counts; "
+                           "run the single-GPU engine (general path) or condition the table")
+
+    plot = torch.zeros(PLOT_CELLS, dtype=torch.int64, device=dev)
+    eng.pass2(plot)
+    if world > 1:
+        dist.all_reduce(plot, op=dist.ReduceOp.SUM, group=group)
+    st = eng.stats()
+    st.update(rank=rank, world=world, shard_nels=n, sent=nreq, received=nrecv)
+    return plot, st

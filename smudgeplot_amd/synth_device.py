@@ -1,0 +1,86 @@
+"""On-device generation of the BASELINE "synthetic diploid" table (k <= 31) with torch.
+
+torch is plumbing: the bench needs a ~2-3e9-entry conditioned FastK-like table resident in HBM
+and there is neither network, FastK nor enough host time to build it on the CPU.
+
+Model: a uniform random haploid genome of G bases, a second
+haplotype that differs by SNPs at rate `het`, all k-mers of both haplotypes and of their reverse
+complements; a k-mer seen in both haplotypes gets coverage ~Poisson(cov), one seen in a single
+haplotype ~Poisson(cov/2) (normal approximation from a hash of the canonical k-mer, so a k-mer
+and its complement always carry the same count), clipped to [L, 32767].  The result is sorted,
+duplicate free, trimmed and reverse-complement closed: exactly what `hetmers` expects after
+Logex/Symmex conditioning.
+"""
+
+from __future__ import annotations
+
+import math
+
+import torch
+
+
+def _kmers_of(bases: torch.Tensor, k: int) -> torch.Tensor:
+    """bases uint8 [G] in 0..3 -> int64 [G-k+1], k-mer right aligned in 2k bits."""
+    g = bases.numel()
+    out = torch.zeros(g - k + 1, dtype=torch.int64, device=bases.device)
+    for j in range(k):
+        out <<= 2
+        out |= bases[j: g - k + 1 + j].to(torch.int64)
+    return out
+
+
+def _revcomp_right(x: torch.Tensor, k: int) -> torch.Tensor:
+    """reverse complement of right-aligned 2k-bit k-mers (k <= 31)"""
+    m = (1 << (2 * k)) - 1
+    x = (~x) & m
+    x = ((x >> 2) & 0x3333333333333333) | ((x & 0x3333333333333333) << 2)
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0F) | ((x & 0x0F0F0F0F0F0F0F0F) << 4)
+    x = ((x >> 8) & 0x00FF00FF00FF00FF) | ((x & 0x00FF00FF00FF00FF) << 8)
+    x = ((x >> 16) & 0x0000FFFF0000FFFF) | ((x & 0x0000FFFF0000FFFF) << 16)
+    x = ((x >> 32) & 0x00000000FFFFFFFF) | ((x & 0x00000000FFFFFFFF) << 32)
+    # logical shift right by 64-2k: clear the sign-extension afterwards
+    return (x >> (64 - 2 * k)) & m
+
+
+def _mix(z: torch.Tensor) -> torch.Tensor:
+    z = (z ^ (z >> 30)) * -4658895280553007687          # 0xbf58476d1ce4e5b9
+    z = (z ^ ((z >> 27) & 0x1FFFFFFFFF)) * -7723592293110705685   # 0x94d049bb133111eb
+    return z ^ ((z >> 31) & 0x1FFFFFFFF)
+
+
+def diploid_table(G: int, k: int = 31, het: float = 0.01, cov: float = 50.0, L: int = 10,
+                  seed: int = 1, device="cuda", chunks: int = 1):
+    """-> (keys int64 viewing LEFT-aligned uint64 k-mers, sorted as unsigned; counts int16
+    viewing uint16).  k <= 31 so the right-aligned value is non-negative and sorts correctly."""
+    assert k <= 31
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    h1 = torch.randint(0, 4, (G,), dtype=torch.uint8, device=device, generator=gen)
+    snp = torch.rand(G, device=device, generator=gen) < het
+    delta = torch.randint(1, 4, (G,), dtype=torch.uint8, device=device, generator=gen)
+    h2 = torch.where(snp, (h1 + delta) & 3, h1)
+    del snp, delta
+    parts = []
+    for h in (h1, h2):
+        km = _kmers_of(h, k)
+        parts.append(km)
+        parts.append(_revcomp_right(km, k))
+    del h1, h2
+    allk = torch.cat(parts)
+    del parts, km
+    keys, mult = torch.unique(allk, sorted=True, return_counts=True)
+    del allk
+    # multiplicity 2+ => present in both haplotypes (or a genomic repeat): homozygous coverage
+    canon = torch.minimum(keys, _revcomp_right(keys, k))
+    u1 = (_mix(canon ^ 0x243F6A8885A308D3) >> 11).to(torch.float64) / float(1 << 53)
+    u2 = (_mix(canon ^ 0x13198A2E03707344) >> 11).to(torch.float64) / float(1 << 53)
+    del canon
+    u1 = u1 - torch.floor(u1); u2 = u2 - torch.floor(u2)
+    z = torch.sqrt(-2.0 * torch.log(u1.clamp_min(1e-300))) * torch.cos(2 * math.pi * u2)
+    del u1, u2
+    mean = torch.where(mult >= 2, torch.tensor(float(cov), device=device, dtype=torch.float64),
+                       torch.tensor(float(cov) / 2, device=device, dtype=torch.float64))
+    cnt = torch.round(mean + torch.sqrt(mean) * z).clamp_(L, 32767).to(torch.int16)
+    del z, mean, mult
+    keys <<= (64 - 2 * k)                      # left align: base 0 in bits 63..62
+    return keys, cnt

@@ -1,0 +1,207 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP engine, called through the C ABI,
+against the reference's golden vectors and the CPU oracle.  Integer work: the bar is bit-exact."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import brute
+from conftest import HETMERS_BIN, ORACLE_BIN, golden_names, load_golden, make_table
+from smudgeplot_amd import engine, ktab, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def table_from(packed, cnt, k, ibyte=1, nparts=1):
+    return make_table(dict(packed=packed, counts=cnt, k=k, ibyte=ibyte, nparts=nparts))
+
+
+@pytest.mark.parametrize("mode", ["exact", "hash", "none"])
+@pytest.mark.parametrize("name", golden_names())
+def test_engine_matches_reference_golden(name, mode):
+    g = load_golden(name)
+    plot, st = engine.hetmers_run(make_table(g), symcheck=mode)
+    assert engine.smu_text(plot) == g["smu"]
+    assert st["path"] == (2 if mode == "none" else 1)
+    assert st["nels"] == len(g["counts"])
+
+
+@pytest.mark.parametrize("name", ["k31_i1", "k32_i1_p2", "k21_i2_p2", "k51_i1_p3", "k100_wrap"])
+def test_hetmers_executable_is_byte_identical(name, tmp_path):
+    """the drop-in binary: same argv as the CLI passes, .smu compared byte for byte"""
+    g = load_golden(name)
+    ktab.write_ktab(str(tmp_path / "t"), g["k"], g["packed"], g["counts"], ibyte=g["ibyte"],
+                    nparts=g["nparts"])
+    r = subprocess.run([HETMERS_BIN, "-okmerpairs", f"-e{g['L']}", "-T4", "-v", "t.ktab"],
+                       cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "  The input table is trimmed and symmetric\n" in r.stderr
+    assert "  Count complete, outputting table\n" in r.stderr
+    assert (tmp_path / "kmerpairs.smu").read_text() == g["smu"]
+    # and the C oracle agrees on the same files
+    subprocess.run([ORACLE_BIN, f"-e{g['L']}", f"-o{tmp_path}/orc", str(tmp_path / "t")], check=True)
+    assert (tmp_path / "orc.smu").read_text() == g["smu"]
+
+
+@pytest.mark.parametrize("k,seed", [(19, 1), (27, 2), (31, 3), (32, 4), (35, 5), (47, 6), (63, 7),
+                                    (66, 8), (96, 9), (97, 10), (128, 11)])
+def test_fresh_tables_vs_oracle(k, seed):
+    packed, cnt = synth.adversarial_table(k, 2500, 4, seed, low_complexity=150, dense=2)
+    want = brute.hetmers_plot(packed, cnt, k)
+    for mode in ("exact", "hash", "none"):
+        plot, _ = engine.hetmers_run(table_from(packed, cnt, k), symcheck=mode)
+        assert np.array_equal(plot, want), (k, mode)
+
+
+def test_big_window_blocks():
+    """thousands of entries sharing their first k/2 bases: the binary-search branch"""
+    k = 31
+    rng = np.random.default_rng(5)
+    lc = np.zeros((6000, k), np.uint8)
+    lc[:, 20:] = rng.integers(0, 4, size=(6000, 11), dtype=np.uint8)
+    lc[:3000, 0] = 1
+    packed = ktab.pack_bases(lc)
+    cnt = rng.integers(5, 60, size=len(packed)).astype(np.uint16)
+    packed, cnt = ktab.sort_unique_packed(packed, cnt)
+    packed, cnt = ktab.symmetrize(packed, cnt, k)
+    want = brute.hetmers_plot(packed, cnt, k)
+    assert want.sum() > 0
+    for mode in ("exact", "hash", "none"):
+        plot, _ = engine.hetmers_run(table_from(packed, cnt, k), symcheck=mode)
+        assert np.array_equal(plot, want), mode
+
+
+def test_asymmetric_tables_fall_back_to_the_general_path():
+    """tables that are NOT reverse-complement closed (the reference only probes entry #1)"""
+    k = 31
+    packed, cnt = synth.adversarial_table(k, 3000, 4, seed=21, low_complexity=100, dense=2)
+    rng = np.random.default_rng(1)
+    # (a) drop 5% of the entries at random, keep entry #1 and its complement
+    keep = rng.random(len(cnt)) > 0.05
+    rc1 = ktab.revcomp_packed(packed[1:2], k)[0]
+    keep[1] = True
+    keep[(packed == rc1).all(axis=1)] = True
+    pa, ca = packed[keep], cnt[keep]
+    want = brute.hetmers_plot(pa, ca, k)
+    for mode in ("exact", "hash"):
+        plot, st = engine.hetmers_run(table_from(pa, ca, k), symcheck=mode)
+        assert st["path"] == 2, "asymmetry must be detected"
+        assert np.array_equal(plot, want), mode
+    # (b) all k-mers present but ONE count differs between a k-mer and its complement
+    cb = cnt.copy()
+    j = int(np.nonzero((packed != ktab.revcomp_packed(packed, k)).any(axis=1))[0][7])
+    cb[j] += 1
+    want = brute.hetmers_plot(packed, cb, k)
+    for mode in ("exact", "hash"):
+        plot, st = engine.hetmers_run(table_from(packed, cb, k), symcheck=mode)
+        assert st["path"] == 2
+        assert np.array_equal(plot, want), mode
+
+
+def test_canonical_only_table_general_path():
+    """half of every complement pair missing (a raw, unsymmetrised FastK table)"""
+    k = 25
+    packed, cnt = synth.adversarial_table(k, 2000, 4, seed=33)
+    rc = ktab.revcomp_packed(packed, k)
+    canon = ktab._as_void(packed) <= ktab._as_void(rc)
+    pa, ca = packed[canon], cnt[canon]
+    want = brute.hetmers_plot(pa, ca, k)
+    plot, st = engine.hetmers_run(table_from(pa, ca, k), symcheck="exact")
+    assert st["path"] == 2 and np.array_equal(plot, want)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 5])
+def test_empty_and_tiny_tables(n):
+    k = 31
+    rng = np.random.default_rng(n)
+    bases = rng.integers(0, 4, size=(n, k), dtype=np.uint8)
+    packed = ktab.pack_bases(bases)
+    cnt = np.full(len(packed), 7, np.uint16)
+    packed, cnt = ktab.sort_unique_packed(packed, cnt)
+    packed, cnt = ktab.symmetrize(packed, cnt, k) if n else (packed, cnt)
+    plot, st = engine.hetmers_run(table_from(packed, cnt, k), symcheck="exact")
+    assert np.array_equal(plot, brute.hetmers_plot(packed, cnt, k))
+
+
+def test_unsorted_table_is_rejected():
+    k = 31
+    packed, cnt = synth.adversarial_table(k, 300, 4, seed=8)
+    packed = packed.copy()
+    packed[[10, 11]] = packed[[11, 10]]
+    t = table_from(packed, cnt, k)
+    with pytest.raises(engine.EngineError) as ei:
+        engine.hetmers_run(t)
+    assert ei.value.code == -4
+
+
+def test_medium_table_vs_c_oracle(tmp_path):
+    """4e5 entries, multi-part, ibyte 2: engine == C oracle == properties of the plot"""
+    k = 31
+    keys, cnt = synth.diploid_table_u64(150000, k=k, seed=5, het_frac=0.3, cov=40, L=8)
+    packed = ktab.u64_to_packed(keys, k)
+    ktab.write_ktab(str(tmp_path / "t"), k, packed, cnt, ibyte=2, nparts=3)
+    subprocess.run([ORACLE_BIN, "-e8", f"-o{tmp_path}/orc", str(tmp_path / "t")], check=True)
+    r = subprocess.run([HETMERS_BIN, "-e8", "-T4", "-ogpu", "t"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "gpu.smu").read_text() == (tmp_path / "orc.smu").read_text()
+    env = dict(os.environ, SMUDGEPLOT_SYMCHECK="hash")
+    r = subprocess.run([HETMERS_BIN, "-e8", "-ogpuh", "t"], cwd=tmp_path, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "gpuh.smu").read_text() == (tmp_path / "orc.smu").read_text()
+
+
+def test_engine_object_with_torch_tensors_and_manual_two_shard_exchange():
+    """phase-level API on device tensors; then the same table split into two prefix shards on
+    one GPU with the request exchange done by hand (what sharded.py does with all_to_all)"""
+    import torch
+    from smudgeplot_amd import sharded
+    k = 31
+    keys, cnt = synth.diploid_table_u64(60000, k=k, seed=9, het_frac=0.35, cov=30, L=6)
+    want = brute.hetmers_plot(ktab.u64_to_packed(keys, k), cnt, k)
+    dev = torch.device("cuda:0")
+    tk = torch.from_numpy(keys.view(np.int64)).to(dev)
+    tc = torch.from_numpy(cnt.view(np.int16)).to(dev)
+    plot = torch.zeros(engine.PLOT_CELLS, dtype=torch.int64, device=dev)
+    e = engine.Engine(0, torch.cuda.current_stream().cuda_stream)
+    e.bind(k, len(cnt), tk.data_ptr(), tc.data_ptr())
+    for mode in ("exact", "hash", "none"):
+        st = e.run(plot.data_ptr(), mode)
+        torch.cuda.synchronize()
+        assert np.array_equal(plot.cpu().numpy().reshape(1001, 501), want), mode
+        assert st["nels"] == len(cnt) and st["ms_total"] > 0
+
+    # single-rank driver (world size 1, no process group)
+    p1, st1 = sharded.hetmers_sharded(k, tk, tc, symcheck="hash")
+    assert np.array_equal(p1.cpu().numpy().reshape(1001, 501), want)
+
+    # two shards, manual exchange
+    cut = sharded.fix_cut(keys, 1, k, len(cnt) // 2)
+    shards = [(tk[:cut].contiguous(), tc[:cut].contiguous()), (tk[cut:].contiguous(), tc[cut:].contiguous())]
+    engs = [sharded.TorchEngine(dev) for _ in range(2)]
+    split = keys[cut:cut + 1].copy()
+    sends, counts = [], []
+    for (sk, sc), en in zip(shards, engs):
+        en.bind(k, sk, sc)
+        en.pass1("hash")
+        buf = torch.empty(max(en.nreq(), 1) * en.record_words(), dtype=torch.int64, device=dev)
+        counts.append(en.route(split, 2, buf))
+        sends.append(buf)
+    rw = engs[0].record_words()
+    total = torch.zeros(engine.PLOT_CELLS, dtype=torch.int64, device=dev)
+    fps = np.zeros(4, dtype=np.uint64)
+    for dst, en in enumerate(engs):
+        parts = []
+        for src in range(2):
+            off = sum(counts[src][:dst]) * rw
+            parts.append(sends[src][off: off + counts[src][dst] * rw])
+        recv = torch.cat(parts)
+        assert en.apply(recv, recv.numel() // rw) == 0
+        fps = fps + np.array(en.symhash(), dtype=np.uint64)
+    assert fps[0] == fps[2] and fps[1] == fps[3]
+    for en in engs:
+        pl = torch.zeros(engine.PLOT_CELLS, dtype=torch.int64, device=dev)
+        en.pass2(pl)
+        total += pl
+    torch.cuda.synchronize()
+    assert np.array_equal(total.cpu().numpy().reshape(1001, 501), want)

@@ -1,0 +1,130 @@
+"""CPU tests of the host side: format F round trips, the C table loader behind the drop-in
+executable, argv / exit-code behaviour of `hetmers`, and that the C-ABI library loads and
+exports every symbol include/smg_hetmers.h declares (no compute calls: there is no GPU here)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import HETMERS_BIN, LIB, ROOT
+from smudgeplot_amd import engine, ktab, synth
+
+
+@pytest.mark.parametrize("k,ibyte,nparts", [(31, 1, 1), (31, 2, 3), (21, 1, 2), (51, 2, 4), (65, 1, 1)])
+def test_ktab_roundtrip(k, ibyte, nparts, tmp_path):
+    packed, cnt = synth.adversarial_table(k, 500, 4, seed=k + ibyte)
+    ktab.write_ktab(str(tmp_path / "x.ktab"), k, packed, cnt, ibyte=ibyte, nparts=nparts)
+    t = ktab.read_ktab(str(tmp_path / "x"))
+    assert t.k == k and t.ibyte == ibyte and t.nparts == nparts
+    assert np.array_equal(t.packed, packed) and np.array_equal(t.counts, cnt)
+    assert t.index[-1] == len(cnt) and int(t.part_nels.sum()) == len(cnt)
+
+
+def test_symmetric_generator_is_closed_under_revcomp():
+    packed, cnt = synth.adversarial_table(32, 800, 4, seed=9, low_complexity=50, dense=1)
+    rc = ktab.revcomp_packed(packed, 32)
+    v, r = ktab._as_void(packed), ktab._as_void(rc)
+    j = np.searchsorted(v, r)
+    assert (v[j] == r).all() and (cnt[j] == cnt).all()
+
+
+def test_u64_helpers_agree_with_packed():
+    packed, cnt = synth.adversarial_table(31, 300, 4, seed=2)
+    keys = ktab.packed_to_u64(packed)
+    assert (np.diff(keys.astype(np.float64)) >= 0).all()
+    assert np.array_equal(ktab.u64_to_packed(keys, 31), packed)
+    assert np.array_equal(ktab.u64_to_packed(ktab.revcomp_u64(keys, 31), 31), ktab.revcomp_packed(packed, 31))
+    k2, c2 = synth.diploid_table_u64(5000, k=31, seed=3)
+    assert (k2[1:] > k2[:-1]).all()
+    j = np.searchsorted(k2, ktab.revcomp_u64(k2, 31))
+    assert (k2[j] == ktab.revcomp_u64(k2, 31)).all() and (c2[j] == c2).all()
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "smg_hetmers.h")).read()
+    declared = set(re.findall(r"\b(smg_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = engine.load_library()
+    for name in declared:
+        assert getattr(lib, name) is not None, name
+    assert declared == set(engine.EXPORTS)
+    assert b"gfx950" in lib.smg_version()
+    out = subprocess.run(["nm", "-D", "--defined-only", LIB], capture_output=True, text=True).stdout
+    for name in declared:
+        assert f" T {name}" in out
+
+
+def run(args, cwd, stdin=None):
+    return subprocess.run([HETMERS_BIN, *args], cwd=cwd, capture_output=True, text=True, input=stdin)
+
+
+def test_hetmers_usage_and_argument_errors(tmp_path):
+    r = run([], tmp_path)
+    assert r.returncode == 1 and r.stderr.startswith("\nUsage: hetmers  [-v] [-T<int(4)>] [-P<dir(/tmp)>]")
+    assert "      -P: Place all temporary files in directory -P.\n" in r.stderr
+    r = run(["a", "b"], tmp_path)
+    assert r.returncode == 1 and "Usage: hetmers" in r.stderr
+    r = run(["-x", "t"], tmp_path)
+    assert r.returncode == 1 and r.stderr == "hetmers: -x is an illegal option\n"
+    r = run(["-eabc", "t"], tmp_path)
+    assert r.returncode == 1 and r.stderr == "hetmers: -e 'abc' argument is not an integer\n"
+    r = run(["-e0", "t"], tmp_path)
+    assert r.returncode == 1 and r.stderr == "hetmers: Error-mer threshold must be positive (0)\n"
+    r = run(["-T-3", "t"], tmp_path)
+    assert r.returncode == 1 and r.stderr == "hetmers: Number of threads must be positive (-3)\n"
+    r = run(["-T100", "-klfs", "missing"], tmp_path)
+    assert r.returncode == 1
+    assert r.stderr == ("hetmers: Warning, only 64 threads will be used\n"
+                        "hetmers: Cannot open k-mer table missing\n")
+
+
+def test_hetmers_table_errors_and_prompt(tmp_path):
+    packed, cnt = synth.adversarial_table(31, 200, 4, seed=4)
+    ktab.write_ktab(str(tmp_path / "t"), 31, packed, cnt, ibyte=1, nparts=2)
+    # existing .smu + "y" => reuse, exit 0, nothing recomputed
+    (tmp_path / "out.smu").write_text("1\t2\t3\n")
+    r = run(["-e4", "-oout", "t.ktab"], tmp_path, stdin="yes\n")
+    assert r.returncode == 0
+    assert r.stdout == "\n  Found het-table out.smu, use it? "
+    assert r.stderr == "\n  Using the found het-table, done\n"
+    assert (tmp_path / "out.smu").read_text() == "1\t2\t3\n"
+    # default output name = source minus .ktab
+    (tmp_path / "t.smu").write_text("x")
+    r = run(["-e4", "t.ktab"], tmp_path, stdin="Y\n")
+    assert r.returncode == 0 and "Found het-table t.smu" in r.stdout
+    os.remove(tmp_path / "t.smu"); os.remove(tmp_path / "out.smu")
+    # missing part
+    os.rename(tmp_path / ".t.ktab.2", tmp_path / "hidden")
+    r = run(["-e4", "-oout", "t"], tmp_path)
+    assert r.returncode == 1 and r.stderr == "hetmers: Table part ./.t.ktab.2 is missing ?\n"
+    os.rename(tmp_path / "hidden", tmp_path / ".t.ktab.2")
+    # k mismatch between stub and part
+    raw = bytearray((tmp_path / ".t.ktab.2").read_bytes()); raw[0] = 30
+    (tmp_path / ".t.ktab.2").write_bytes(bytes(raw))
+    r = run(["-e4", "-oout", "t"], tmp_path)
+    assert r.returncode == 1
+    assert r.stderr == "hetmers: Table part ./.t.ktab.2 does not have k-mer length matching stub ?\n"
+
+
+def test_hetmers_conditioning_decision_and_no_cpu_fallback(tmp_path):
+    """Without a GPU the executable must fail loudly AFTER the host-side table probe."""
+    if engine.device_count() > 0:
+        pytest.skip("a GPU is visible: covered by the gpu tests")
+    packed, cnt = synth.adversarial_table(31, 200, 6, seed=5)
+    ktab.write_ktab(str(tmp_path / "t"), 31, packed, cnt, ibyte=1)
+    r = run(["-e6", "-v", "-oout", "t"], tmp_path)
+    assert r.returncode == 1
+    assert r.stderr.startswith("\n  The input table is trimmed and symmetric\n"
+                               "\n  Starting to count covariant pairs\n")
+    assert r.stderr.endswith("hetmers: no HIP device available (this engine has no CPU fallback)\n")
+    assert not (tmp_path / "out.smu").exists()
+    # untrimmed table: same decision and same shell-out as the reference (Logex is not installed)
+    r = run(["-e9", "-v", "-T3", "-oout", "t"], tmp_path)
+    assert r.returncode == 1
+    assert "  The input table is untrimmed yet symmetric\n" in r.stderr
+    assert "  Trimming k-mers in table with count < 9\n" in r.stderr
+    assert r.stderr.endswith("hetmers: Command 'Logex -T3 '.trim=A[9-]' t' failed\n")
+    with pytest.raises(engine.EngineError):
+        engine.Engine(0)
