@@ -1,0 +1,427 @@
+// smg_fast.hpp -- the MI355X fast path (k <= 85, reverse-complement closed table).
+//
+// Three persistent, tile-based kernels.  No per-wave / per-thread atomics on shared addresses:
+// a device-scope atomic on ONE address costs ~12 ns on gfx950 (8 XCDs, memory-side atomics), so
+// every counter is aggregated per workgroup first (measured: profiles/r01_v1_*).
+//
+//   kf_pass1  tile of 1024 entries (+32 halo each side) staged in LDS; one thread walks the
+//             window block of its entry in LDS (suffix-side positions only) and emits
+//               code[i]   : 1 byte  -- 0 none | 63 several pairs | 31+delta (the unique partner is
+//                           entry i+delta, |delta| <= 30) | 62 unique but farther; bit 6 = the
+//                           pair is not self-mirrored (weight 2)
+//               bstart[]  : the bucket directory (built on the fly from the staged tile)
+//               requests  : rc(kmer) of every entry that owns a pair at p > k-1-p, compacted
+//                           through an LDS queue and written, coalesced, into per-workgroup
+//                           chunks of F_CH records (one global atomic per chunk)
+//               fingerprints of T and rc(T) (per-workgroup partial sums, no atomics)
+//   kf_apply  one workgroup per chunk: directory look-up of the complement, atomicOr of the
+//             "has a prefix-side pair" bit  P[j]  (the S_hi(rc(x)) > 0 term of the degree)
+//   kf_pass2  needs no k-mers at all: entry i with a unique local partner j = i+delta > i counts
+//             iff neither i nor j has its P bit and j's code is "unique" too; the (sum,min) cell is
+//             bumped in an LDS tile (sum < 256, triangular, u32), flushed once per workgroup.
+//
+// Why the code byte is enough (k <= 85, so a uint8 degree cannot wrap, PloidyPlot.c:163):
+//   deg(x) = S_all(x) + P(x), P(x) = number of prefix-side pairs = S_hi(rc(x)).
+//   A suffix-side pair (i,j) enters the plot iff deg(i) <= 1 and deg(j) <= 1
+//   <=> S_all(i) = S_all(j) = 1 and P(i) = P(j) = 0   (the pair itself is the 1).
+
+#pragma once
+#include "smg_device.hpp"
+
+#define F_TPB    256
+#define F_ITEMS  4
+#define F_TILE   (F_TPB * F_ITEMS)
+#define F_HALO   32
+#define F_SPAN   (F_TILE + 2 * F_HALO)
+#define F_CH     4096                 // records per request chunk
+#define F_NOCHUNK 0xFFFFFFFFu
+
+#define CODE_NONE   0
+#define CODE_MULTI  63
+#define CODE_FAR    62
+#define CODE_W2     64
+
+#define P2_TPB   1024
+#define P2_SMAX  256                  // LDS plot tile covers sums < P2_SMAX
+#define P2_CELLS ((P2_SMAX / 2) * (P2_SMAX / 2 + 1))     // 16512
+
+struct FastArgs
+{ const u64      *keys;
+  const uint16_t *cnt;
+  int64_t         n;
+  Geo             g;
+  Dir             dir;           // bstart written by pass 1, read by apply
+  uint8_t        *code;
+  uint32_t       *pbits;
+};
+
+struct FastCtl                    // device control words of the fast path
+{ unsigned n_chunks;             // chunks handed out (may exceed max_chunks => rerun)
+  unsigned missing;              // a complement was absent or carried another count
+  unsigned unsorted;             // order violation seen
+  unsigned pad;
+  u64      nreq;                 // requests written
+};
+
+// ---- helpers -----------------------------------------------------------------------------------
+
+template <int W> SMG_DEV Key<W> lds_key(const u64 *sk, int idx)
+{ Key<W> x;
+#pragma unroll
+  for (int w = 0; w < W; w++) x.w[w] = sk[idx * W + w];
+  return x;
+}
+
+// slow exact walk of a window block that outgrows the halo: binary searches in global memory
+template <int W> __device__ __noinline__ void
+big_block_scan(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, int64_t n,
+               const Geo g, int64_t i, unsigned &s_all, unsigned &s_hi, int64_t &partner,
+               unsigned &w2)
+{ const Key<W> x = load_key<W>(keys, i);
+  const unsigned c = cnt[i];
+  int64_t a = 0, b = i;
+  while (a < b)
+    { const int64_t m = (a + b) >> 1;
+      if (same_block<W>(x, load_key<W>(keys, m), g)) b = m; else a = m + 1;
+    }
+  const int64_t blo = a;
+  a = i + 1; b = n;
+  while (a < b)
+    { const int64_t m = (a + b) >> 1;
+      if (!same_block<W>(x, load_key<W>(keys, m), g)) b = m; else a = m + 1;
+    }
+  const int64_t bhi = a;
+  s_all = 0; s_hi = 0; partner = -1; w2 = 0;
+  for (int p = g.p0; p < g.k; p++)
+    for (int d = 1; d <= 3; d++)
+      { const Key<W> y = flip_base<W>(x, p, d);
+        const int64_t j = lower_bound_key<W>(keys, blo, bhi, y);
+        if (j < bhi && key_eq<W>(load_key<W>(keys, j), y) && c + (unsigned) cnt[j] <= SMG_SMAX)
+          { const unsigned hi = (p != g.k - 1 - p);
+            if (s_all == 0) { partner = j; w2 = hi; }
+            s_all++; s_hi += hi;
+          }
+      }
+}
+
+SMG_DEV unsigned make_code(unsigned s_all, int64_t delta, unsigned w2)
+{ if (s_all == 0) return CODE_NONE;
+  if (s_all >= 2) return CODE_MULTI;
+  unsigned c = (delta >= -30 && delta <= 30) ? (unsigned) (31 + delta) : CODE_FAR;
+  return c | (w2 ? CODE_W2 : 0);
+}
+
+// ---- pass 1 ------------------------------------------------------------------------------------
+
+template <int W> __global__ void __launch_bounds__(F_TPB)
+kf_pass1(FastArgs A, uint32_t *__restrict__ bstart, u64 *__restrict__ req,
+         uint32_t *__restrict__ chunk_fill, unsigned max_chunks, int emit_all, int want_fp,
+         u64 *__restrict__ partials, FastCtl *__restrict__ ctl, int64_t ntiles)
+{ __shared__ u64      sk[F_SPAN * W];
+  __shared__ uint16_t sc[F_SPAN];
+  __shared__ u64      sq[F_TILE * (W + 1)];
+  __shared__ u64      sfp[F_TPB / 64][4];
+  __shared__ unsigned s_qn, s_chunk, s_used;
+  __shared__ u64      s_base, s_total;
+
+  const int t = threadIdx.x;
+  const Geo g = A.g;
+  const int64_t n = A.n;
+  u64 f0 = 0, f1 = 0, f2 = 0, f3 = 0;
+  if (t == 0) { s_chunk = F_NOCHUNK; s_used = 0; s_total = 0; }
+
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
+    { const int64_t lo = tile * F_TILE;
+      // stage keys + counts of [lo-HALO, lo+TILE+HALO) in LDS (coalesced)
+      for (int idx = t; idx < F_SPAN; idx += F_TPB)
+        { const int64_t gi = lo - F_HALO + idx;
+          if (gi >= 0 && gi < n)
+            { const Key<W> x = load_key<W>(A.keys, gi);
+#pragma unroll
+              for (int w = 0; w < W; w++) sk[idx * W + w] = x.w[w];
+              sc[idx] = A.cnt[gi];
+            }
+        }
+      if (t == 0) s_qn = 0;
+      __syncthreads();
+
+#pragma unroll 1
+      for (int r = 0; r < F_ITEMS; r++)
+        { const int li = t + r * F_TPB;
+          const int64_t i = lo + li;
+          if (i >= n) continue;
+          const int idx = li + F_HALO;
+          const Key<W> x = lds_key<W>(sk, idx);
+          const unsigned c = sc[idx];
+          unsigned s_all = 0, s_hi = 0, w2 = 0;
+          int64_t delta = 0;
+          bool big = false;
+          // forward neighbours
+          for (int d = 1; d <= F_HALO; d++)
+            { if (i + d >= n) break;
+              const Key<W> y = lds_key<W>(sk, idx + d);
+              if (!same_block<W>(x, y, g)) break;
+              if (d == F_HALO) { big = true; break; }
+              const int p = pair_pos<W>(x, y);
+              if (p >= 0 && c + (unsigned) sc[idx + d] <= SMG_SMAX)
+                { const unsigned hi = (p != g.k - 1 - p);
+                  if (s_all == 0) { delta = d; w2 = hi; }
+                  s_all++; s_hi += hi;
+                }
+            }
+          // backward neighbours
+          if (!big)
+            for (int d = 1; d <= F_HALO; d++)
+              { if (i - d < 0) break;
+                const Key<W> y = lds_key<W>(sk, idx - d);
+                if (!same_block<W>(x, y, g)) break;
+                if (d == F_HALO) { big = true; break; }
+                const int p = pair_pos<W>(x, y);
+                if (p >= 0 && c + (unsigned) sc[idx - d] <= SMG_SMAX)
+                  { const unsigned hi = (p != g.k - 1 - p);
+                    if (s_all == 0) { delta = -d; w2 = hi; }
+                    s_all++; s_hi += hi;
+                  }
+              }
+          if (big)
+            { int64_t partner;
+              big_block_scan<W>(A.keys, A.cnt, n, g, i, s_all, s_hi, partner, w2);
+              delta = partner - i;
+            }
+          A.code[i] = (uint8_t) make_code(s_all, delta, w2);
+
+          // bucket directory + strict order check (the predecessor is in the halo)
+          { const int64_t bcur = (int64_t) ((x.w[0] - A.dir.base) >> A.dir.shift);
+            int64_t bprev = -1;
+            if (i > 0)
+              { const Key<W> pv = lds_key<W>(sk, idx - 1);
+                bprev = (int64_t) ((pv.w[0] - A.dir.base) >> A.dir.shift);
+                if (!key_lt<W>(pv, x)) ctl->unsorted = 1;
+              }
+            for (int64_t b = bprev + 1; b <= bcur; b++) bstart[b] = (uint32_t) i;
+            if (i == n - 1)
+              for (int64_t b = bcur + 1; b <= (int64_t) A.dir.nb; b++) bstart[b] = (uint32_t) n;
+          }
+
+          const bool emit = emit_all || s_hi > 0;
+          if (emit || want_fp)
+            { const Key<W> rc = revcomp<W>(x, g.k);
+              if (emit)
+                { const unsigned q = atomicAdd(&s_qn, 1u);
+#pragma unroll
+                  for (int w = 0; w < W; w++) sq[q * (W + 1) + w] = rc.w[w];
+                  sq[q * (W + 1) + W] = (u64) c | ((u64) (s_hi > 0) << 16);
+                }
+              if (want_fp)
+                { f0 += hash_entry<W>(x, c, 0x243f6a8885a308d3ull);
+                  f1 += hash_entry<W>(x, c, 0x13198a2e03707344ull);
+                  f2 += hash_entry<W>(rc, c, 0x243f6a8885a308d3ull);
+                  f3 += hash_entry<W>(rc, c, 0x13198a2e03707344ull);
+                }
+            }
+        }
+      __syncthreads();
+
+      // flush the LDS queue into this workgroup's current chunk (coalesced)
+      const unsigned qn = s_qn;
+      if (qn > 0)
+        { if (t == 0)
+            { if (s_chunk == F_NOCHUNK || s_used + qn > F_CH)
+                { if (s_chunk != F_NOCHUNK && s_chunk < max_chunks) chunk_fill[s_chunk] = s_used;
+                  s_chunk = atomicAdd(&ctl->n_chunks, 1u);
+                  s_used = 0;
+                }
+              s_base = (u64) s_chunk * F_CH + s_used;
+              s_used += qn;
+              s_total += qn;
+            }
+          __syncthreads();
+          if (s_chunk < max_chunks)
+            { u64 *o = req + s_base * (W + 1);
+              for (unsigned e = t; e < qn * (W + 1); e += F_TPB) o[e] = sq[e];
+            }
+        }
+      __syncthreads();
+    }
+
+  if (t == 0)
+    { if (s_chunk != F_NOCHUNK && s_chunk < max_chunks) chunk_fill[s_chunk] = s_used;
+      if (s_total) atomicAdd(&ctl->nreq, s_total);
+    }
+  if (want_fp)
+    { f0 = wave_sum_u64(f0); f1 = wave_sum_u64(f1); f2 = wave_sum_u64(f2); f3 = wave_sum_u64(f3);
+      if ((t & 63) == 0) { sfp[t >> 6][0] = f0; sfp[t >> 6][1] = f1; sfp[t >> 6][2] = f2; sfp[t >> 6][3] = f3; }
+      __syncthreads();
+      if (t < 4)
+        { u64 s = 0;
+          for (int w = 0; w < F_TPB / 64; w++) s += sfp[w][t];
+          partials[(size_t) blockIdx.x * 4 + t] = s;
+        }
+    }
+}
+
+// ---- apply: set the P bit of every requested complement ---------------------------------------
+// chunk_fill != NULL : one workgroup per chunk of the local request list
+// chunk_fill == NULL : flat list of nflat records (received from other ranks), grid-stride
+
+template <int W> __global__ void __launch_bounds__(F_TPB)
+kf_apply(FastArgs A, const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill,
+         int64_t nflat, int check_count, FastCtl *__restrict__ ctl)
+{ int64_t first, count, stride;
+  if (chunk_fill)
+    { first = (int64_t) blockIdx.x * F_CH + threadIdx.x; count = (int64_t) blockIdx.x * F_CH + chunk_fill[blockIdx.x];
+      stride = F_TPB;
+    }
+  else
+    { first = (int64_t) blockIdx.x * F_TPB + threadIdx.x; count = nflat; stride = (int64_t) gridDim.x * F_TPB; }
+  for (int64_t r = first; r < count; r += stride)
+    { const u64 *q = req + r * (W + 1);
+      Key<W> y;
+#pragma unroll
+      for (int w = 0; w < W; w++) y.w[w] = q[w];
+      const u64 meta = q[W];
+      const int64_t j = find_key<W>(A.keys, A.dir, y);
+      bool bad = j < 0;
+      if (!bad && check_count) bad = A.cnt[j] != (unsigned) (meta & 0xFFFF);
+      if (bad) { if (ctl->missing == 0) ctl->missing = 1; continue; }
+      if (meta >> 16 & 1) atomicOr(A.pbits + (j >> 5), 1u << (j & 31));
+    }
+}
+
+// exact symmetry proof of every local entry against the local table (single GPU)
+template <int W> __global__ void __launch_bounds__(F_TPB)
+kf_verify(FastArgs A, FastCtl *__restrict__ ctl)
+{ const int64_t stride = (int64_t) gridDim.x * F_TPB;
+  for (int64_t i = (int64_t) blockIdx.x * F_TPB + threadIdx.x; i < A.n; i += stride)
+    { const Key<W> r = revcomp<W>(load_key<W>(A.keys, i), A.g.k);
+      const int64_t j = find_key<W>(A.keys, A.dir, r);
+      if (j < 0 || A.cnt[j] != A.cnt[i]) { if (ctl->missing == 0) ctl->missing = 1; }
+    }
+}
+
+// ---- pass 2 ------------------------------------------------------------------------------------
+
+SMG_DEV unsigned tri_index(unsigned s, unsigned m)       // cell of (sum, min) in the LDS tile
+{ const unsigned a = s >> 1;
+  return (a + 1) * (a + (s & 1)) + m;
+}
+
+SMG_DEV bool pbit(const uint32_t *__restrict__ pbits, int64_t i)
+{ return (pbits[i >> 5] >> (i & 31)) & 1u; }
+
+SMG_DEV void plot_bump(unsigned *tile, u64 *__restrict__ plot, unsigned ci, unsigned cj, unsigned wgt)
+{ const unsigned s = ci + cj, m = ci < cj ? ci : cj;
+  if (s < P2_SMAX) atomicAdd(tile + tri_index(s, m), wgt);
+  else atomicAdd(plot + (size_t) s * SMG_PLOT_COLS + m, (u64) wgt);
+}
+
+// rare: the unique partner is more than 30 entries away -- search it again
+template <int W> __device__ __noinline__ void
+far_partner(const FastArgs &A, int64_t i, int64_t &partner, unsigned &w2)
+{ unsigned s_all, s_hi;
+  big_block_scan<W>(A.keys, A.cnt, A.n, A.g, i, s_all, s_hi, partner, w2);
+}
+
+template <int W> __global__ void __launch_bounds__(P2_TPB)
+kf_pass2(FastArgs A, u64 *__restrict__ plot)
+{ __shared__ unsigned tile[P2_CELLS];
+  const int t = threadIdx.x;
+  for (int c = t; c < P2_CELLS; c += P2_TPB) tile[c] = 0;
+  __syncthreads();
+
+  const int64_t stride = (int64_t) gridDim.x * P2_TPB;
+  for (int64_t i = (int64_t) blockIdx.x * P2_TPB + t; i < A.n; i += stride)
+    { const unsigned ci = A.code[i];
+      const unsigned lo6 = ci & 63;
+      if (lo6 == CODE_NONE || lo6 == CODE_MULTI) continue;
+      int64_t j;
+      unsigned w2 = (ci & CODE_W2) != 0;
+      if (lo6 == CODE_FAR)
+        far_partner<W>(A, i, j, w2);
+      else
+        j = i + (int) lo6 - 31;
+      if (j <= i) continue;                               // the lower entry of a pair reports it
+      const unsigned lj = A.code[j] & 63;
+      if (lj == CODE_NONE || lj == CODE_MULTI) continue;  // partner has several pairs
+      if (pbit(A.pbits, i) || pbit(A.pbits, j)) continue; // a prefix-side pair exists as well
+      plot_bump(tile, plot, A.cnt[i], A.cnt[j], w2 ? 2u : 1u);
+    }
+  __syncthreads();
+
+  // flush the LDS tile: (sum,min) rows are laid out triangularly
+  for (int c = t; c < P2_CELLS; c += P2_TPB)
+    { const unsigned v = tile[c];
+      if (!v) continue;
+      unsigned a = (unsigned) ((sqrtf(4.0f * c + 1.0f) - 1.0f) * 0.5f);
+      while ((a + 1) * (a + 2) <= (unsigned) c) a++;
+      while (a * (a + 1) > (unsigned) c) a--;
+      unsigned s, m;
+      if ((unsigned) c >= (a + 1) * (a + 1)) { s = 2 * a + 1; m = c - (a + 1) * (a + 1); }
+      else { s = 2 * a; m = c - a * (a + 1); }
+      atomicAdd(plot + (size_t) s * SMG_PLOT_COLS + m, (u64) v);
+    }
+}
+
+// total weight in the plot (stat only)
+__global__ void __launch_bounds__(1024) kf_plot_sum(const u64 *__restrict__ plot, u64 *__restrict__ out)
+{ __shared__ u64 part[16];
+  u64 s = 0;
+  for (int c = threadIdx.x; c < SMG_PLOT_CELLS; c += 1024) s += plot[c];
+  s = wave_sum_u64(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    { u64 tot = 0;
+      for (int w = 0; w < 16; w++) tot += part[w];
+      *out = tot;
+    }
+}
+
+// ---- routing (sharded runs): requests -> per-destination contiguous send buffer ----------------
+
+template <int W> SMG_DEV int rank_of(const u64 *q, const u64 *__restrict__ split, int nranks)
+{ Key<W> y;
+#pragma unroll
+  for (int w = 0; w < W; w++) y.w[w] = q[w];
+  int r = 0;
+  for (int s = 0; s < nranks - 1; s++)
+    { Key<W> sp;
+#pragma unroll
+      for (int w = 0; w < W; w++) sp.w[w] = split[s * W + w];
+      if (!key_lt<W>(y, sp)) r = s + 1;
+    }
+  return r;
+}
+
+// counts[chunk][rank]
+template <int W> __global__ void __launch_bounds__(F_TPB)
+kf_route_count(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill,
+               const u64 *__restrict__ split, int nranks, uint32_t *__restrict__ counts)
+{ __shared__ unsigned cnt[16];
+  if (threadIdx.x < 16) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const unsigned fill = chunk_fill[blockIdx.x];
+  for (unsigned r = threadIdx.x; r < fill; r += F_TPB)
+    atomicAdd(&cnt[rank_of<W>(req + ((size_t) blockIdx.x * F_CH + r) * (W + 1), split, nranks)], 1u);
+  __syncthreads();
+  if ((int) threadIdx.x < nranks) counts[(size_t) blockIdx.x * nranks + threadIdx.x] = cnt[threadIdx.x];
+}
+
+// offsets[chunk][rank] = first record slot of that (chunk, rank) group in the send buffer
+template <int W> __global__ void __launch_bounds__(F_TPB)
+kf_route_scatter(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill,
+                 const u64 *__restrict__ split, int nranks, const u64 *__restrict__ offsets,
+                 u64 *__restrict__ out)
+{ __shared__ unsigned cur[16];
+  if (threadIdx.x < 16) cur[threadIdx.x] = 0;
+  __syncthreads();
+  const unsigned fill = chunk_fill[blockIdx.x];
+  for (unsigned r = threadIdx.x; r < fill; r += F_TPB)
+    { const u64 *q = req + ((size_t) blockIdx.x * F_CH + r) * (W + 1);
+      const int d = rank_of<W>(q, split, nranks);
+      const u64 slot = offsets[(size_t) blockIdx.x * nranks + d] + atomicAdd(&cur[d], 1u);
+      u64 *o = out + slot * (W + 1);
+#pragma unroll
+      for (int w = 0; w <= W; w++) o[w] = q[w];
+    }
+}

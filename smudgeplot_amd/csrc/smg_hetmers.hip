@@ -33,6 +33,7 @@
 
 #include "smg_hetmers.h"
 #include "smg_device.hpp"
+#include "smg_fast.hpp"
 
 #define WIN_LIM   32          // window blocks up to this many entries are walked linearly
 #define TPB       256
@@ -46,9 +47,8 @@ struct Ctrl                    // small control block in device memory, zeroed p
   u64      missing;            // complements absent / wrong count
   u64      unsorted;           // order violations found while building the directory
   u64      fp[4];              // fingerprints: T (2 seeds), rc(T) (2 seeds)
-  u64      npairs;             // weighted pairs entered into the plot
-  u64      route_cnt[16];      // per-destination counters for route
-  u64      route_cur[16];
+  u64      plot_sum;           // total weight in the plot (kf_plot_sum)
+  FastCtl  fast;               // control words of the fast path
 };
 
 struct Tab                     // kernel argument block (passed by value)
@@ -103,7 +103,7 @@ k_directory(Tab t, uint32_t *__restrict__ bstart, Ctrl *__restrict__ ctrl)
   if (i < t.n)
     { bcur = (int64_t) ((t.keys[i * W] - t.dir.base) >> t.dir.shift);
       if (i > 0 && !key_lt<W>(load_key<W>(t.keys, i - 1), load_key<W>(t.keys, i)))
-        atomicAdd(&ctrl->unsorted, 1ull);
+        ctrl->unsorted = 1;
     }
   for (int64_t b = bprev + 1; b <= bcur; b++) bstart[b] = (uint32_t) i;
 }
@@ -231,7 +231,7 @@ k_apply(Tab t, const u64 *__restrict__ req, int64_t nreq, Ctrl *__restrict__ ctr
   for (int w = 0; w < W; w++) y.w[w] = q[w];
   const unsigned c = (unsigned) (q[W] & 0xFFFF), v = (unsigned) ((q[W] >> 16) & 0xFF);
   const int64_t j = find_key<W>(t.keys, t.dir, y);
-  if (j < 0 || t.cnt[j] != c) { atomicAdd(&ctrl->missing, 1ull); return; }
+  if (j < 0 || t.cnt[j] != c) { if (ctrl->missing == 0) ctrl->missing = 1; return; }
   if (v) deg_add(t.deg, j, v, t.g.wrap);
 }
 
@@ -242,7 +242,7 @@ k_verify(Tab t, int64_t lo, int64_t hi, Ctrl *__restrict__ ctrl)
   if (i >= hi) return;
   const Key<W> r = revcomp<W>(load_key<W>(t.keys, i), t.g.k);
   const int64_t j = find_key<W>(t.keys, t.dir, r);
-  if (j < 0 || t.cnt[j] != t.cnt[i]) atomicAdd(&ctrl->missing, 1ull);
+  if (j < 0 || t.cnt[j] != t.cnt[i]) { if (ctrl->missing == 0) ctrl->missing = 1; }
 }
 
 // ---- pass 2 -------------------------------------------------------------------------------
@@ -256,7 +256,7 @@ SMG_DEV void plot_add(u64 *__restrict__ plot, unsigned ci, unsigned cj, unsigned
 }
 
 template <int W, bool SYM> __global__ void __launch_bounds__(TPB)
-k_pass2(Tab t, int64_t lo, int64_t hi, u64 *__restrict__ plot, Ctrl *__restrict__ ctrl)
+k_pass2(Tab t, int64_t lo, int64_t hi, u64 *__restrict__ plot)
 { const int64_t i = lo + (int64_t) blockIdx.x * TPB + threadIdx.x;
   if (i >= hi) return;
   const Geo g = t.g;
@@ -265,7 +265,6 @@ k_pass2(Tab t, int64_t lo, int64_t hi, u64 *__restrict__ plot, Ctrl *__restrict_
   if (di == 0 && !g.wrap) return;            // no wrap possible: degree 0 means no pair at all
   const Key<W> x = load_key<W>(t.keys, i);
   const unsigned c = t.cnt[i];
-  unsigned found = 0;
 
   bool big = false;
   if (i + WIN_LIM < t.n) big = same_block<W>(x, load_key<W>(t.keys, i + WIN_LIM), g);
@@ -278,7 +277,7 @@ k_pass2(Tab t, int64_t lo, int64_t hi, u64 *__restrict__ plot, Ctrl *__restrict_
             { const unsigned cj = t.cnt[j];
               if (c + cj <= SMG_SMAX && t.deg[j] <= 1)
                 { const unsigned wgt = (SYM && p != g.k - 1 - p) ? 2 : 1;
-                  plot_add(plot, c, cj, wgt); found += wgt;
+                  plot_add(plot, c, cj, wgt);
                 }
             }
         }
@@ -299,7 +298,7 @@ k_pass2(Tab t, int64_t lo, int64_t hi, u64 *__restrict__ plot, Ctrl *__restrict_
               { const unsigned cj = t.cnt[j];
                 if (c + cj <= SMG_SMAX && t.deg[j] <= 1)
                   { const unsigned wgt = (SYM && p != g.k - 1 - p) ? 2 : 1;
-                    plot_add(plot, c, cj, wgt); found += wgt;
+                    plot_add(plot, c, cj, wgt);
                   }
               }
           }
@@ -312,53 +311,19 @@ k_pass2(Tab t, int64_t lo, int64_t hi, u64 *__restrict__ plot, Ctrl *__restrict_
             const int64_t j = find_key<W>(t.keys, t.dir, y);
             if (j >= 0)
               { const unsigned cj = t.cnt[j];
-                if (c + cj <= SMG_SMAX && t.deg[j] <= 1) { plot_add(plot, c, cj, 1); found++; }
+                if (c + cj <= SMG_SMAX && t.deg[j] <= 1) plot_add(plot, c, cj, 1);
               }
           }
     }
-  if (found) atomicAdd(&ctrl->npairs, (u64) found);
-}
-
-// ---- routing of requests to the rank that owns the complement (sharded runs) ----------------
-
-template <int W> SMG_DEV int dest_rank(const u64 *q, const u64 *__restrict__ split, int nranks)
-{ Key<W> y;
-#pragma unroll
-  for (int w = 0; w < W; w++) y.w[w] = q[w];
-  int r = 0;
-  for (int s = 0; s < nranks - 1; s++)
-    { Key<W> sp;
-#pragma unroll
-      for (int w = 0; w < W; w++) sp.w[w] = split[s * W + w];
-      if (!key_lt<W>(y, sp)) r = s + 1;
-    }
-  return r;
-}
-
-template <int W> __global__ void __launch_bounds__(TPB)
-k_route_count(const u64 *__restrict__ req, int64_t nreq, const u64 *__restrict__ split,
-              int nranks, Ctrl *__restrict__ ctrl)
-{ const int64_t r = (int64_t) blockIdx.x * TPB + threadIdx.x;
-  if (r >= nreq) return;
-  atomicAdd(&ctrl->route_cnt[dest_rank<W>(req + r * (W + 1), split, nranks)], 1ull);
-}
-
-template <int W> __global__ void __launch_bounds__(TPB)
-k_route_scatter(const u64 *__restrict__ req, int64_t nreq, const u64 *__restrict__ split,
-                int nranks, u64 *__restrict__ out, Ctrl *__restrict__ ctrl)
-{ const int64_t r = (int64_t) blockIdx.x * TPB + threadIdx.x;
-  if (r >= nreq) return;
-  const u64 *q = req + r * (W + 1);
-  const int d = dest_rank<W>(q, split, nranks);
-  const u64 slot = atomicAdd(&ctrl->route_cur[d], 1ull);
-  u64 *o = out + slot * (W + 1);
-#pragma unroll
-  for (int w = 0; w <= W; w++) o[w] = q[w];
 }
 
 // ------------------------------------------------------------------------------------------
 //  Host side
 // ------------------------------------------------------------------------------------------
+
+#define FAST_MAX_K   85        // above this a uint8 degree can wrap: counted path (v1 kernels)
+#define P1_GRID      2048      // persistent workgroups of kf_pass1 (8 per CU)
+#define P2_GRID      512       // persistent workgroups of kf_pass2 (2 per CU, 66 KB LDS each)
 
 struct smg_engine
 { int          device;
@@ -369,15 +334,25 @@ struct smg_engine
   const uint16_t *cnt;
   u64         *own_keys;      // owned copies (decode path)
   uint16_t    *own_cnt;
-  uint8_t     *deg;  int64_t deg_cap;
+  uint8_t     *deg;    int64_t deg_cap;      // degree bytes (counted path) / code bytes (fast path)
+  uint32_t    *pbits;  int64_t pbits_cap;
   uint32_t    *bstart; int64_t bstart_cap;
-  u64         *req;  int64_t req_cap;      // capacity in records
+  u64         *req;    int64_t req_cap;      // bytes
+  uint32_t    *chunk_fill; int64_t chunk_cap; // bytes
+  unsigned     max_chunks;
+  uint32_t    *route_cnt;  int64_t route_cnt_cap;
+  u64         *route_off;  int64_t route_off_cap;
+  u64         *partials;   // [P1_GRID][4]
   u64         *d_split;
   Ctrl        *ctrl;
   Ctrl        *h_ctrl;        // pinned mirror
+  u64         *h_partials;    // pinned
   Geo          geo;
   Dir          dir;
-  bool         prepared;
+  bool         prepared;      // pass 1 of the current table has run
+  bool         fast;          // fast path in use
+  unsigned     n_chunks;
+  u64          fp[4];
   smg_stats    st;
   hipEvent_t   ev[8];
 };
@@ -393,7 +368,13 @@ static int fail(char *errbuf, size_t errlen, int code, const char *fmt, const ch
          return fail(errbuf, errlen, _e == hipErrorOutOfMemory ? SMG_ENOMEM : SMG_ENODEV,     \
                      "HIP error: %s (" #call ")", hipGetErrorString(_e)); } while (0)
 
-extern "C" const char *smg_version(void) { return "smudgeplot_amd 0.1 (hetmers engine, gfx950)"; }
+#define DISPATCH_W(e, CALL)                                                                   \
+  switch ((e)->W) { case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break;  \
+                    default: CALL(4); break; }
+#define DISPATCH_W3(e, CALL)                                                                  \
+  switch ((e)->W) { case 1: CALL(1); break; case 2: CALL(2); break; default: CALL(3); break; }
+
+extern "C" const char *smg_version(void) { return "smudgeplot_amd 0.2 (hetmers engine, gfx950)"; }
 
 extern "C" int smg_device_count(void)
 { int n = 0;
@@ -418,6 +399,8 @@ extern "C" smg_engine *smg_engine_create(int device, void *stream, char *errbuf,
   e->stream = (hipStream_t) stream;
   if (hipMalloc(&e->ctrl, sizeof(Ctrl)) != hipSuccess
       || hipHostMalloc(&e->h_ctrl, sizeof(Ctrl)) != hipSuccess
+      || hipMalloc(&e->partials, sizeof(u64) * 4 * P1_GRID) != hipSuccess
+      || hipHostMalloc(&e->h_partials, sizeof(u64) * 4 * P1_GRID) != hipSuccess
       || hipMalloc(&e->d_split, sizeof(u64) * 16 * 4) != hipSuccess)
     { fail(errbuf, errlen, SMG_ENOMEM, "cannot allocate the control block%s");
       delete e; return NULL;
@@ -430,8 +413,10 @@ extern "C" void smg_engine_destroy(smg_engine *e)
 { if (!e) return;
   hipSetDevice(e->device);
   hipStreamSynchronize(e->stream);
-  hipFree(e->own_keys); hipFree(e->own_cnt); hipFree(e->deg); hipFree(e->bstart);
-  hipFree(e->req); hipFree(e->ctrl); hipFree(e->d_split); hipHostFree(e->h_ctrl);
+  hipFree(e->own_keys); hipFree(e->own_cnt); hipFree(e->deg); hipFree(e->pbits); hipFree(e->bstart);
+  hipFree(e->req); hipFree(e->chunk_fill); hipFree(e->route_cnt); hipFree(e->route_off);
+  hipFree(e->partials); hipFree(e->ctrl); hipFree(e->d_split);
+  hipHostFree(e->h_ctrl); hipHostFree(e->h_partials);
   for (int i = 0; i < 8; i++) hipEventDestroy(e->ev[i]);
   delete e;
 }
@@ -451,26 +436,25 @@ static int set_table(smg_engine *e, int kmer, int64_t nels, char *errbuf, size_t
   return SMG_OK;
 }
 
-static void set_geo(smg_engine *e, bool sym)
+static void set_geo(smg_engine *e)
 { Geo &g = e->geo;
   g.k = e->kmer;
   // first scanned position p0 = ceil((k-1)/2) = k/2 (integer division) for both parities: on
   // the symmetric path positions below it are the mirror images of the scanned ones, on the
   // general path they are resolved by directory look-ups
-  (void) sym;
   g.p0 = e->kmer / 2;
   g.pw = g.p0 >> 5;
   const int r = g.p0 & 31;
   g.pmask = r ? ~0ull << (64 - 2 * r) : 0ull;
   g.mid = (e->kmer & 1) ? (e->kmer - 1) / 2 : -1;
-  g.wrap = e->kmer > 85;
+  g.wrap = e->kmer > FAST_MAX_K;
 }
 
-static int grow(void **p, int64_t *cap, int64_t need_bytes, char *errbuf, size_t errlen)
-{ if (*cap >= need_bytes) return SMG_OK;
+template <typename T> static int grow(T **p, int64_t *cap, int64_t need_bytes, char *errbuf, size_t errlen)
+{ if (*cap >= need_bytes && *p) return SMG_OK;
   if (*p) hipFree(*p);
   *p = NULL; *cap = 0;
-  HIPCHK(hipMalloc(p, (size_t) need_bytes));
+  HIPCHK(hipMalloc((void **) p, (size_t) need_bytes));
   *cap = need_bytes;
   return SMG_OK;
 }
@@ -516,10 +500,36 @@ extern "C" int smg_engine_decode(smg_engine *e, int kmer, int ibyte, int64_t nel
   return SMG_OK;
 }
 
-template <int W> static void launch_directory(smg_engine *e, Tab &t)
-{ const unsigned nblk = (unsigned) ((e->n + 1 + TPB - 1) / TPB);
-  hipLaunchKernelGGL(k_directory<W>, dim3(nblk), dim3(TPB), 0, e->stream, t, e->bstart, e->ctrl);
+static int read_ctrl(smg_engine *e, char *errbuf, size_t errlen)
+{ HIPCHK(hipMemcpyAsync(e->h_ctrl, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return SMG_OK;
 }
+
+// directory geometry over the first key word: ~2-4 entries per bucket across the shard's range
+static int dir_geometry(smg_engine *e, char *errbuf, size_t errlen)
+{ u64 first = 0, last = 0;
+  if (e->n > 0)
+    { HIPCHK(hipMemcpyAsync(&first, e->keys, 8, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipMemcpyAsync(&last, e->keys + (size_t) (e->n - 1) * e->W, 8, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+    }
+  if (last < first) return fail(errbuf, errlen, SMG_EFORMAT, "table entries are not strictly increasing%s");
+  int bits = 4;
+  while (bits < 30 && (1ll << (bits + 1)) <= e->n / 2) bits++;
+  const u64 span = last - first;
+  int shift = 0;
+  while (shift < 63 && (span >> shift) >= (1ull << bits)) shift++;
+  e->dir.base = first;
+  e->dir.shift = shift;
+  e->dir.nb = (uint32_t) ((span >> shift) + 1);
+  int rc = grow(&e->bstart, &e->bstart_cap, (int64_t) sizeof(uint32_t) * ((int64_t) e->dir.nb + 2), errbuf, errlen);
+  if (rc) return rc;
+  e->dir.bstart = e->bstart;
+  return SMG_OK;
+}
+
+// ---- counted path (k > 85, and the general all-positions fallback at any k) ---------------------
 
 static Tab make_tab(smg_engine *e)
 { Tab t;
@@ -527,262 +537,368 @@ static Tab make_tab(smg_engine *e)
   return t;
 }
 
-// allocate degrees, build the directory, validate the order; zero the control block
-static int prepare(smg_engine *e, char *errbuf, size_t errlen)
-{ HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipMemsetAsync(e->ctrl, 0, sizeof(Ctrl), e->stream));
-  int64_t cap;
-  cap = e->deg_cap;
-  int rc = grow((void **) &e->deg, &cap, ((e->n + 3) & ~3ll) + 4, errbuf, errlen);
-  e->deg_cap = cap;
+static int counted_prepare(smg_engine *e, char *errbuf, size_t errlen)
+{ HIPCHK(hipMemsetAsync(e->ctrl, 0, sizeof(Ctrl), e->stream));
+  set_geo(e);
+  const int64_t dbytes = ((e->n + 3) & ~3ll) + 4;
+  int rc = grow(&e->deg, &e->deg_cap, dbytes, errbuf, errlen);
   if (rc) return rc;
-  HIPCHK(hipMemsetAsync(e->deg, 0, (size_t) (((e->n + 3) & ~3ll) + 4), e->stream));
-
-  // directory geometry: ~2-4 entries per bucket over the shard's first-word range
-  u64 first = 0, last = 0;
-  if (e->n > 0)
-    { HIPCHK(hipMemcpyAsync(&first, e->keys, 8, hipMemcpyDeviceToHost, e->stream));
-      HIPCHK(hipMemcpyAsync(&last, e->keys + (size_t) (e->n - 1) * e->W, 8, hipMemcpyDeviceToHost, e->stream));
-      HIPCHK(hipStreamSynchronize(e->stream));
-    }
-  if (last < first) return fail(errbuf, errlen, SMG_EFORMAT, "table is not sorted%s");
-  int bits = 4;
-  while (bits < 28 && (1ll << (bits + 1)) <= e->n / 2) bits++;
-  const u64 span = last - first;
-  int shift = 0;
-  while (shift < 63 && (span >> shift) >= (1ull << bits)) shift++;
-  if ((span >> shift) >= (1ull << bits)) shift = 64 - bits;   // unreachable guard
-  e->dir.base = first;
-  e->dir.shift = shift;
-  e->dir.nb = (uint32_t) ((span >> shift) + 1);
-  cap = e->bstart_cap;
-  rc = grow((void **) &e->bstart, &cap, sizeof(uint32_t) * ((int64_t) e->dir.nb + 2), errbuf, errlen);
-  e->bstart_cap = cap;
-  if (rc) return rc;
-  e->dir.bstart = e->bstart;
-
+  HIPCHK(hipMemsetAsync(e->deg, 0, (size_t) dbytes, e->stream));
+  if ((rc = dir_geometry(e, errbuf, errlen))) return rc;
   Tab t = make_tab(e);
-  switch (e->W)
-  { case 1: launch_directory<1>(e, t); break;
-    case 2: launch_directory<2>(e, t); break;
-    case 3: launch_directory<3>(e, t); break;
-    default: launch_directory<4>(e, t); break;
-  }
-  HIPCHK(hipGetLastError());
-  e->prepared = true;
-  return SMG_OK;
-}
-
-static int read_ctrl(smg_engine *e, char *errbuf, size_t errlen)
-{ HIPCHK(hipMemcpyAsync(e->h_ctrl, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
-  return SMG_OK;
-}
-
-template <int W, bool SYM> static void launch_pass1(smg_engine *e, int emit_all, int want_fp)
-{ Tab t = make_tab(e);
-  if (e->n <= 0) return;
-  const unsigned nblk = (unsigned) ((e->n + TPB - 1) / TPB);
-  hipLaunchKernelGGL((k_pass1<W, SYM>), dim3(nblk), dim3(TPB), 0, e->stream, t, (int64_t) 0,
-                     e->n, emit_all, want_fp, e->req, e->req_cap, e->ctrl);
-}
-
-template <int W, bool SYM> static void launch_pass2(smg_engine *e, int64_t *d_plot)
-{ Tab t = make_tab(e);
-  if (e->n <= 0) return;
-  const unsigned nblk = (unsigned) ((e->n + TPB - 1) / TPB);
-  hipLaunchKernelGGL((k_pass2<W, SYM>), dim3(nblk), dim3(TPB), 0, e->stream, t, (int64_t) 0,
-                     e->n, (u64 *) d_plot, e->ctrl);
-}
-
-template <int W> static void launch_apply(smg_engine *e, const u64 *req, int64_t nreq)
-{ Tab t = make_tab(e);
-  if (nreq <= 0) return;
-  const unsigned nblk = (unsigned) ((nreq + TPB - 1) / TPB);
-  hipLaunchKernelGGL(k_apply<W>, dim3(nblk), dim3(TPB), 0, e->stream, t, req, nreq, e->ctrl);
-}
-
-template <int W> static void launch_verify(smg_engine *e)
-{ Tab t = make_tab(e);
-  if (e->n <= 0) return;
-  const unsigned nblk = (unsigned) ((e->n + TPB - 1) / TPB);
-  hipLaunchKernelGGL(k_verify<W>, dim3(nblk), dim3(TPB), 0, e->stream, t, (int64_t) 0, e->n, e->ctrl);
-}
-
-#define DISPATCH_W(e, CALL)                                                                   \
-  switch ((e)->W) { case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break;  \
-                    default: CALL(4); break; }
-
-static int ensure_req(smg_engine *e, int64_t records, char *errbuf, size_t errlen)
-{ if (records < 1024) records = 1024;
-  if (e->req_cap >= records) return SMG_OK;
-  if (e->req) hipFree(e->req);
-  e->req = NULL; e->req_cap = 0;
-  HIPCHK(hipMalloc(&e->req, sizeof(u64) * (size_t) records * (e->W + 1)));
-  e->req_cap = records;
-  return SMG_OK;
-}
-
-// pass 1 of the symmetric path, with the capacity retry
-static int do_pass1_sym(smg_engine *e, int emit_all, int want_fp, char *errbuf, size_t errlen)
-{ int rc;
-  if (!e->prepared && (rc = prepare(e, errbuf, errlen))) return rc;
-  set_geo(e, true);
-  rc = ensure_req(e, emit_all ? e->n : e->n / 4 + 1024, errbuf, errlen);
-  if (rc) return rc;
-  for (int attempt = 0; attempt < 2; attempt++)
-    { hipEventRecord(e->ev[2], e->stream);
-#define CALL(WW) launch_pass1<WW, true>(e, emit_all, want_fp)
-      DISPATCH_W(e, CALL)
+  const unsigned nblk = (unsigned) ((e->n + 1 + TPB - 1) / TPB);
+#define CALL(WW) hipLaunchKernelGGL(k_directory<WW>, dim3(nblk), dim3(TPB), 0, e->stream, t, e->bstart, e->ctrl)
+  DISPATCH_W(e, CALL)
 #undef CALL
+  HIPCHK(hipGetLastError());
+  return SMG_OK;
+}
+
+static int plot_sum(smg_engine *e, int64_t *d_plot, char *errbuf, size_t errlen)
+{ hipLaunchKernelGGL(kf_plot_sum, dim3(1), dim3(1024), 0, e->stream, (const u64 *) d_plot, &e->ctrl->plot_sum);
+  int rc = read_ctrl(e, errbuf, errlen);
+  if (rc) return rc;
+  e->st.npairs = (int64_t) e->h_ctrl->plot_sum;
+  return SMG_OK;
+}
+
+// symmetric half-scan with counted degrees (exact uint8 wrap emulation), k > 85
+static int counted_symmetric(smg_engine *e, int symcheck, int64_t *d_plot, bool *symmetric,
+                             char *errbuf, size_t errlen)
+{ int rc;
+  if ((rc = counted_prepare(e, errbuf, errlen))) return rc;
+  const unsigned nblk = (unsigned) ((e->n + TPB - 1) / TPB);
+  int64_t cap = e->n / 4 + 1024;
+  for (int attempt = 0; attempt < 2; attempt++)
+    { if ((rc = grow(&e->req, &e->req_cap, cap * (int64_t) sizeof(u64) * (e->W + 1), errbuf, errlen))) return rc;
+      Tab t = make_tab(e);
+      hipEventRecord(e->ev[2], e->stream);
+      if (e->n > 0)
+        {
+#define CALL(WW) hipLaunchKernelGGL((k_pass1<WW, true>), dim3(nblk), dim3(TPB), 0, e->stream, t, \
+                   (int64_t) 0, e->n, 0, symcheck == SMG_SYM_HASH, e->req, cap, e->ctrl)
+          DISPATCH_W(e, CALL)
+#undef CALL
+        }
       hipEventRecord(e->ev[3], e->stream);
-      HIPCHK(hipGetLastError());
       if ((rc = read_ctrl(e, errbuf, errlen))) return rc;
       if (e->h_ctrl->unsorted)
         return fail(errbuf, errlen, SMG_EFORMAT, "table entries are not strictly increasing%s");
-      if ((int64_t) e->h_ctrl->nreq <= e->req_cap) break;
-      // request list overflowed its first-guess capacity: size it exactly and redo the pass
-      const int64_t need = (int64_t) e->h_ctrl->nreq;
-      if ((rc = ensure_req(e, need, errbuf, errlen))) return rc;
+      if ((int64_t) e->h_ctrl->nreq <= cap) break;
+      cap = (int64_t) e->h_ctrl->nreq;
       HIPCHK(hipMemsetAsync(&e->ctrl->nreq, 0, sizeof(u64), e->stream));
       HIPCHK(hipMemsetAsync(e->ctrl->fp, 0, sizeof(u64) * 4, e->stream));
     }
   float ms = 0; hipEventElapsedTime(&ms, e->ev[2], e->ev[3]);
   e->st.ms_pass1 = ms;
-  e->st.nrequests = (int64_t) e->h_ctrl->nreq;
-  return SMG_OK;
-}
-
-extern "C" int smg_engine_pass1(smg_engine *e, int symcheck, char *errbuf, size_t errlen)
-{ if (!e) return fail(errbuf, errlen, SMG_EINVAL, "null engine%s");
-  HIPCHK(hipSetDevice(e->device));
-  e->prepared = false;
-  return do_pass1_sym(e, symcheck == SMG_SYM_EXACT, symcheck == SMG_SYM_HASH, errbuf, errlen);
-}
-
-extern "C" int64_t smg_engine_nreq(smg_engine *e) { return e ? (int64_t) e->h_ctrl->nreq : 0; }
-extern "C" int smg_engine_record_words(smg_engine *e) { return e ? e->W + 1 : 0; }
-
-extern "C" int smg_engine_apply(smg_engine *e, const uint64_t *d_recv, int64_t nrecv,
-                                int64_t *missing, char *errbuf, size_t errlen)
-{ if (!e || !e->prepared) return fail(errbuf, errlen, SMG_EINVAL, "apply before pass1%s");
-  HIPCHK(hipSetDevice(e->device));
-  hipEventRecord(e->ev[4], e->stream);
-#define CALL(WW) launch_apply<WW>(e, (const u64 *) d_recv, nrecv)
-  DISPATCH_W(e, CALL)
-#undef CALL
-  hipEventRecord(e->ev[5], e->stream);
-  HIPCHK(hipGetLastError());
-  int rc = read_ctrl(e, errbuf, errlen);
-  if (rc) return rc;
-  float ms = 0; hipEventElapsedTime(&ms, e->ev[4], e->ev[5]);
-  e->st.ms_rclookup += ms;
-  if (missing) *missing = (int64_t) e->h_ctrl->missing;
-  return SMG_OK;
-}
-
-extern "C" int smg_engine_apply_own(smg_engine *e, int64_t *missing, char *errbuf, size_t errlen)
-{ if (!e) return fail(errbuf, errlen, SMG_EINVAL, "null engine%s");
-  return smg_engine_apply(e, (const uint64_t *) e->req, (int64_t) e->h_ctrl->nreq, missing, errbuf, errlen);
-}
-
-extern "C" int smg_engine_symhash(smg_engine *e, uint64_t out[4], char *errbuf, size_t errlen)
-{ if (!e || !out) return fail(errbuf, errlen, SMG_EINVAL, "null argument%s");
-  for (int i = 0; i < 4; i++) out[i] = e->h_ctrl->fp[i];
-  return SMG_OK;
-}
-
-extern "C" int smg_engine_route(smg_engine *e, const uint64_t *splitters, int nranks,
-                                uint64_t *d_send, int64_t capacity, int64_t *counts,
-                                char *errbuf, size_t errlen)
-{ if (!e || !counts || nranks < 1 || nranks > 16)
-    return fail(errbuf, errlen, SMG_EINVAL, "bad route arguments (1..16 ranks)%s");
-  HIPCHK(hipSetDevice(e->device));
   const int64_t nreq = (int64_t) e->h_ctrl->nreq;
-  if (nreq > capacity) return fail(errbuf, errlen, SMG_EINVAL, "send buffer too small%s");
-  if (nranks > 1)
-    HIPCHK(hipMemcpyAsync(e->d_split, splitters, sizeof(u64) * (nranks - 1) * e->W,
-                          hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipMemsetAsync(e->ctrl->route_cnt, 0, sizeof(u64) * 32, e->stream));
-  const unsigned nblk = (unsigned) ((nreq + TPB - 1) / TPB);
-  if (nreq > 0)
-    {
-#define CALL(WW) hipLaunchKernelGGL(k_route_count<WW>, dim3(nblk), dim3(TPB), 0, e->stream, \
-                                    e->req, nreq, e->d_split, nranks, e->ctrl)
-      DISPATCH_W(e, CALL)
+  e->st.nrequests = nreq;
+  hipEventRecord(e->ev[4], e->stream);
+  { Tab t = make_tab(e);
+    if (nreq > 0)
+      { const unsigned rb = (unsigned) ((nreq + TPB - 1) / TPB);
+#define CALL(WW) hipLaunchKernelGGL(k_apply<WW>, dim3(rb), dim3(TPB), 0, e->stream, t, e->req, nreq, e->ctrl)
+        DISPATCH_W(e, CALL)
 #undef CALL
-    }
-  int rc = read_ctrl(e, errbuf, errlen);
-  if (rc) return rc;
-  u64 cur[16], acc = 0;
-  for (int r = 0; r < 16; r++)
-    { cur[r] = acc;
-      if (r < nranks) { counts[r] = (int64_t) e->h_ctrl->route_cnt[r]; acc += e->h_ctrl->route_cnt[r]; }
-    }
-  HIPCHK(hipMemcpyAsync(e->ctrl->route_cur, cur, sizeof(cur), hipMemcpyHostToDevice, e->stream));
-  if (nreq > 0)
-    {
-#define CALL(WW) hipLaunchKernelGGL(k_route_scatter<WW>, dim3(nblk), dim3(TPB), 0, e->stream, \
-                                    e->req, nreq, e->d_split, nranks, (u64 *) d_send, e->ctrl)
-      DISPATCH_W(e, CALL)
+      }
+    if (symcheck == SMG_SYM_EXACT && e->n > 0)
+      {
+#define CALL(WW) hipLaunchKernelGGL(k_verify<WW>, dim3(nblk), dim3(TPB), 0, e->stream, t, (int64_t) 0, e->n, e->ctrl)
+        DISPATCH_W(e, CALL)
 #undef CALL
-    }
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(e->stream));
-  return SMG_OK;
-}
-
-extern "C" int smg_engine_pass2(smg_engine *e, int64_t *d_plot, char *errbuf, size_t errlen)
-{ if (!e || !e->prepared || !d_plot) return fail(errbuf, errlen, SMG_EINVAL, "pass2 before pass1%s");
-  HIPCHK(hipSetDevice(e->device));
+      }
+  }
+  hipEventRecord(e->ev[5], e->stream);
+  if ((rc = read_ctrl(e, errbuf, errlen))) return rc;
+  hipEventElapsedTime(&ms, e->ev[4], e->ev[5]);
+  e->st.ms_rclookup = ms;
+  *symmetric = e->h_ctrl->missing == 0;
+  if (*symmetric && symcheck == SMG_SYM_HASH)
+    *symmetric = e->h_ctrl->fp[0] == e->h_ctrl->fp[2] && e->h_ctrl->fp[1] == e->h_ctrl->fp[3];
+  if (!*symmetric) return SMG_OK;
   HIPCHK(hipMemsetAsync(d_plot, 0, sizeof(int64_t) * SMG_PLOT_CELLS, e->stream));
   hipEventRecord(e->ev[6], e->stream);
-#define CALL(WW) launch_pass2<WW, true>(e, d_plot)
-  DISPATCH_W(e, CALL)
+  if (e->n > 0)
+    { Tab t = make_tab(e);
+#define CALL(WW) hipLaunchKernelGGL((k_pass2<WW, true>), dim3(nblk), dim3(TPB), 0, e->stream, t, \
+                   (int64_t) 0, e->n, (u64 *) d_plot)
+      DISPATCH_W(e, CALL)
 #undef CALL
+    }
   hipEventRecord(e->ev[7], e->stream);
-  HIPCHK(hipGetLastError());
-  int rc = read_ctrl(e, errbuf, errlen);
-  if (rc) return rc;
-  float ms = 0; hipEventElapsedTime(&ms, e->ev[6], e->ev[7]);
+  if ((rc = plot_sum(e, d_plot, errbuf, errlen))) return rc;
+  hipEventElapsedTime(&ms, e->ev[6], e->ev[7]);
   e->st.ms_pass2 = ms;
-  e->st.npairs = (int64_t) e->h_ctrl->npairs;
   e->st.path = 1;
-  return SMG_OK;
-}
-
-extern "C" int smg_engine_stats(smg_engine *e, smg_stats *stats)
-{ if (!e || !stats) return SMG_EINVAL;
-  *stats = e->st;
   return SMG_OK;
 }
 
 // general (assumption-free) path: both passes over every position
 static int run_general(smg_engine *e, int64_t *d_plot, char *errbuf, size_t errlen)
 { int rc;
-  e->prepared = false;
-  if ((rc = prepare(e, errbuf, errlen))) return rc;
-  set_geo(e, false);
+  if ((rc = counted_prepare(e, errbuf, errlen))) return rc;
+  const unsigned nblk = (unsigned) ((e->n + TPB - 1) / TPB);
+  Tab t = make_tab(e);
   hipEventRecord(e->ev[2], e->stream);
-#define CALL(WW) launch_pass1<WW, false>(e, 0, 0)
-  DISPATCH_W(e, CALL)
+  if (e->n > 0)
+    {
+#define CALL(WW) hipLaunchKernelGGL((k_pass1<WW, false>), dim3(nblk), dim3(TPB), 0, e->stream, t, \
+                   (int64_t) 0, e->n, 0, 0, (u64 *) NULL, (int64_t) 0, e->ctrl)
+      DISPATCH_W(e, CALL)
 #undef CALL
+    }
   hipEventRecord(e->ev[3], e->stream);
   HIPCHK(hipMemsetAsync(d_plot, 0, sizeof(int64_t) * SMG_PLOT_CELLS, e->stream));
   hipEventRecord(e->ev[6], e->stream);
-#define CALL(WW) launch_pass2<WW, false>(e, d_plot)
-  DISPATCH_W(e, CALL)
+  if (e->n > 0)
+    {
+#define CALL(WW) hipLaunchKernelGGL((k_pass2<WW, false>), dim3(nblk), dim3(TPB), 0, e->stream, t, \
+                   (int64_t) 0, e->n, (u64 *) d_plot)
+      DISPATCH_W(e, CALL)
 #undef CALL
+    }
   hipEventRecord(e->ev[7], e->stream);
   HIPCHK(hipGetLastError());
-  if ((rc = read_ctrl(e, errbuf, errlen))) return rc;
+  if ((rc = plot_sum(e, d_plot, errbuf, errlen))) return rc;
   if (e->h_ctrl->unsorted)
     return fail(errbuf, errlen, SMG_EFORMAT, "table entries are not strictly increasing%s");
   float ms = 0;
   hipEventElapsedTime(&ms, e->ev[2], e->ev[3]); e->st.ms_pass1 += ms;
   hipEventElapsedTime(&ms, e->ev[6], e->ev[7]); e->st.ms_pass2 = ms;
-  e->st.npairs = (int64_t) e->h_ctrl->npairs;
   e->st.path = 2;
+  return SMG_OK;
+}
+
+// ---- fast path (k <= 85) --------------------------------------------------------------------------
+
+static FastArgs make_fast(smg_engine *e)
+{ FastArgs a;
+  a.keys = e->keys; a.cnt = e->cnt; a.n = e->n; a.g = e->geo; a.dir = e->dir;
+  a.code = e->deg; a.pbits = e->pbits;
+  return a;
+}
+
+static int fast_pass1(smg_engine *e, int emit_all, int want_fp, char *errbuf, size_t errlen)
+{ int rc;
+  HIPCHK(hipMemsetAsync(e->ctrl, 0, sizeof(Ctrl), e->stream));
+  set_geo(e);
+  e->fast = true;
+  if ((rc = grow(&e->deg, &e->deg_cap, ((e->n + 3) & ~3ll) + 4, errbuf, errlen))) return rc;
+  const int64_t pbytes = ((e->n + 31) / 32 + 2) * 4;
+  if ((rc = grow(&e->pbits, &e->pbits_cap, pbytes, errbuf, errlen))) return rc;
+  HIPCHK(hipMemsetAsync(e->pbits, 0, (size_t) pbytes, e->stream));
+  if ((rc = dir_geometry(e, errbuf, errlen))) return rc;
+  if (e->n == 0)
+    { HIPCHK(hipMemsetAsync(e->bstart, 0, sizeof(uint32_t) * ((size_t) e->dir.nb + 2), e->stream));
+      e->n_chunks = 0; e->prepared = true;
+      memset(e->fp, 0, sizeof(e->fp));
+      return SMG_OK;
+    }
+  const int64_t ntiles = (e->n + F_TILE - 1) / F_TILE;
+  const unsigned grid = (unsigned) (ntiles < P1_GRID ? ntiles : P1_GRID);
+  int64_t want_rec = (emit_all ? e->n : e->n / 4) + (int64_t) (grid + 16) * F_CH;
+  for (int attempt = 0; attempt < 2; attempt++)
+    { const unsigned maxc = (unsigned) ((want_rec + F_CH - 1) / F_CH);
+      if ((rc = grow(&e->req, &e->req_cap, (int64_t) maxc * F_CH * (int64_t) sizeof(u64) * (e->W + 1), errbuf, errlen))) return rc;
+      if ((rc = grow(&e->chunk_fill, &e->chunk_cap, (int64_t) maxc * 4 + 4, errbuf, errlen))) return rc;
+      e->max_chunks = maxc;
+      FastArgs a = make_fast(e);
+      hipEventRecord(e->ev[2], e->stream);
+#define CALL(WW) hipLaunchKernelGGL(kf_pass1<WW>, dim3(grid), dim3(F_TPB), 0, e->stream, a, e->bstart, \
+                   e->req, e->chunk_fill, maxc, emit_all, want_fp, e->partials, &e->ctrl->fast, ntiles)
+      DISPATCH_W3(e, CALL)
+#undef CALL
+      hipEventRecord(e->ev[3], e->stream);
+      HIPCHK(hipGetLastError());
+      if (want_fp)
+        HIPCHK(hipMemcpyAsync(e->h_partials, e->partials, sizeof(u64) * 4 * grid, hipMemcpyDeviceToHost, e->stream));
+      if ((rc = read_ctrl(e, errbuf, errlen))) return rc;
+      if (e->h_ctrl->fast.unsorted)
+        return fail(errbuf, errlen, SMG_EFORMAT, "table entries are not strictly increasing%s");
+      if (e->h_ctrl->fast.n_chunks <= maxc) break;
+      // the request list outgrew its first-guess capacity: size it from the count and redo
+      want_rec = (int64_t) (e->h_ctrl->fast.n_chunks + 16) * F_CH;
+      HIPCHK(hipMemsetAsync(&e->ctrl->fast, 0, sizeof(FastCtl), e->stream));
+    }
+  e->n_chunks = e->h_ctrl->fast.n_chunks;
+  memset(e->fp, 0, sizeof(e->fp));
+  if (want_fp)
+    for (unsigned b = 0; b < grid; b++)
+      for (int q = 0; q < 4; q++) e->fp[q] += e->h_partials[b * 4 + q];
+  float ms = 0; hipEventElapsedTime(&ms, e->ev[2], e->ev[3]);
+  e->st.ms_pass1 = ms;
+  e->st.nrequests = (int64_t) e->h_ctrl->fast.nreq;
+  e->prepared = true;
+  return SMG_OK;
+}
+
+static int fast_apply(smg_engine *e, const u64 *flat, int64_t nflat, int check_count, int64_t *missing,
+                      char *errbuf, size_t errlen)
+{ FastArgs a = make_fast(e);
+  hipEventRecord(e->ev[4], e->stream);
+  if (!flat && e->n_chunks > 0)
+    {
+#define CALL(WW) hipLaunchKernelGGL(kf_apply<WW>, dim3(e->n_chunks), dim3(F_TPB), 0, e->stream, a, e->req, \
+                   e->chunk_fill, (int64_t) 0, check_count, &e->ctrl->fast)
+      DISPATCH_W3(e, CALL)
+#undef CALL
+    }
+  else if (flat && nflat > 0)
+    { int64_t nb = (nflat + F_TPB - 1) / F_TPB;
+      if (nb > 8192) nb = 8192;
+#define CALL(WW) hipLaunchKernelGGL(kf_apply<WW>, dim3((unsigned) nb), dim3(F_TPB), 0, e->stream, a, flat, \
+                   (const uint32_t *) NULL, nflat, check_count, &e->ctrl->fast)
+      DISPATCH_W3(e, CALL)
+#undef CALL
+    }
+  hipEventRecord(e->ev[5], e->stream);
+  HIPCHK(hipGetLastError());
+  int rc = read_ctrl(e, errbuf, errlen);
+  if (rc) return rc;
+  float ms = 0; hipEventElapsedTime(&ms, e->ev[4], e->ev[5]);
+  e->st.ms_rclookup += ms;
+  if (missing) *missing = e->h_ctrl->fast.missing;
+  return SMG_OK;
+}
+
+static int fast_verify(smg_engine *e, int64_t *missing, char *errbuf, size_t errlen)
+{ FastArgs a = make_fast(e);
+  hipEventRecord(e->ev[4], e->stream);
+  if (e->n > 0)
+    { int64_t nb = (e->n + F_TPB - 1) / F_TPB;
+      if (nb > 16384) nb = 16384;
+#define CALL(WW) hipLaunchKernelGGL(kf_verify<WW>, dim3((unsigned) nb), dim3(F_TPB), 0, e->stream, a, &e->ctrl->fast)
+      DISPATCH_W3(e, CALL)
+#undef CALL
+    }
+  hipEventRecord(e->ev[5], e->stream);
+  int rc = read_ctrl(e, errbuf, errlen);
+  if (rc) return rc;
+  float ms = 0; hipEventElapsedTime(&ms, e->ev[4], e->ev[5]);
+  e->st.ms_rclookup += ms;
+  if (missing) *missing = e->h_ctrl->fast.missing;
+  return SMG_OK;
+}
+
+static int fast_pass2(smg_engine *e, int64_t *d_plot, char *errbuf, size_t errlen)
+{ HIPCHK(hipMemsetAsync(d_plot, 0, sizeof(int64_t) * SMG_PLOT_CELLS, e->stream));
+  FastArgs a = make_fast(e);
+  hipEventRecord(e->ev[6], e->stream);
+  if (e->n > 0)
+    { int64_t nb = (e->n + P2_TPB - 1) / P2_TPB;
+      if (nb > P2_GRID) nb = P2_GRID;
+#define CALL(WW) hipLaunchKernelGGL(kf_pass2<WW>, dim3((unsigned) nb), dim3(P2_TPB), 0, e->stream, a, (u64 *) d_plot)
+      DISPATCH_W3(e, CALL)
+#undef CALL
+    }
+  hipEventRecord(e->ev[7], e->stream);
+  HIPCHK(hipGetLastError());
+  int rc = plot_sum(e, d_plot, errbuf, errlen);
+  if (rc) return rc;
+  float ms = 0; hipEventElapsedTime(&ms, e->ev[6], e->ev[7]);
+  e->st.ms_pass2 = ms;
+  e->st.path = 1;
+  return SMG_OK;
+}
+
+// ---- public phase API (sharded runs; fast path only) ---------------------------------------------
+
+#define NEED_FAST(e)                                                                          \
+  if (!(e)) return fail(errbuf, errlen, SMG_EINVAL, "null engine%s");                          \
+  if ((e)->kmer > FAST_MAX_K)                                                                 \
+    return fail(errbuf, errlen, SMG_EINVAL, "the phase API supports k <= 85 (use smg_engine_run)%s");
+
+extern "C" int smg_engine_pass1(smg_engine *e, int symcheck, char *errbuf, size_t errlen)
+{ NEED_FAST(e)
+  HIPCHK(hipSetDevice(e->device));
+  e->st.ms_rclookup = 0;
+  return fast_pass1(e, symcheck == SMG_SYM_EXACT, symcheck == SMG_SYM_HASH, errbuf, errlen);
+}
+
+extern "C" int64_t smg_engine_nreq(smg_engine *e) { return e ? e->st.nrequests : 0; }
+extern "C" int smg_engine_record_words(smg_engine *e) { return e ? e->W + 1 : 0; }
+
+extern "C" int smg_engine_apply(smg_engine *e, const uint64_t *d_recv, int64_t nrecv,
+                                int64_t *missing, char *errbuf, size_t errlen)
+{ NEED_FAST(e)
+  if (!e->prepared) return fail(errbuf, errlen, SMG_EINVAL, "apply before pass1%s");
+  HIPCHK(hipSetDevice(e->device));
+  return fast_apply(e, (const u64 *) d_recv, nrecv, 1, missing, errbuf, errlen);
+}
+
+extern "C" int smg_engine_apply_own(smg_engine *e, int64_t *missing, char *errbuf, size_t errlen)
+{ NEED_FAST(e)
+  if (!e->prepared) return fail(errbuf, errlen, SMG_EINVAL, "apply before pass1%s");
+  HIPCHK(hipSetDevice(e->device));
+  return fast_apply(e, NULL, 0, 1, missing, errbuf, errlen);
+}
+
+extern "C" int smg_engine_symhash(smg_engine *e, uint64_t out[4], char *errbuf, size_t errlen)
+{ if (!e || !out) return fail(errbuf, errlen, SMG_EINVAL, "null argument%s");
+  for (int i = 0; i < 4; i++) out[i] = e->fp[i];
+  return SMG_OK;
+}
+
+extern "C" int smg_engine_route(smg_engine *e, const uint64_t *splitters, int nranks,
+                                uint64_t *d_send, int64_t capacity, int64_t *counts,
+                                char *errbuf, size_t errlen)
+{ NEED_FAST(e)
+  if (!counts || nranks < 1 || nranks > 16)
+    return fail(errbuf, errlen, SMG_EINVAL, "bad route arguments (1..16 ranks)%s");
+  if (!e->prepared) return fail(errbuf, errlen, SMG_EINVAL, "route before pass1%s");
+  HIPCHK(hipSetDevice(e->device));
+  const int64_t nreq = e->st.nrequests;
+  if (nreq > capacity) return fail(errbuf, errlen, SMG_EINVAL, "send buffer too small%s");
+  for (int r = 0; r < nranks; r++) counts[r] = 0;
+  const unsigned nc = e->n_chunks;
+  if (nc == 0) return SMG_OK;
+  int rc;
+  if (nranks > 1)
+    HIPCHK(hipMemcpyAsync(e->d_split, splitters, sizeof(u64) * (nranks - 1) * e->W,
+                          hipMemcpyHostToDevice, e->stream));
+  if ((rc = grow(&e->route_cnt, &e->route_cnt_cap, (int64_t) nc * nranks * 4, errbuf, errlen))) return rc;
+  if ((rc = grow(&e->route_off, &e->route_off_cap, (int64_t) nc * nranks * 8, errbuf, errlen))) return rc;
+#define CALL(WW) hipLaunchKernelGGL(kf_route_count<WW>, dim3(nc), dim3(F_TPB), 0, e->stream, e->req, \
+                   e->chunk_fill, e->d_split, nranks, e->route_cnt)
+  DISPATCH_W3(e, CALL)
+#undef CALL
+  uint32_t *hc = (uint32_t *) malloc(sizeof(uint32_t) * (size_t) nc * nranks);
+  u64 *ho = (u64 *) malloc(sizeof(u64) * (size_t) nc * nranks);
+  if (!hc || !ho) { free(hc); free(ho); return fail(errbuf, errlen, SMG_ENOMEM, "out of host memory%s"); }
+  if (hipMemcpyAsync(hc, e->route_cnt, sizeof(uint32_t) * (size_t) nc * nranks, hipMemcpyDeviceToHost, e->stream) != hipSuccess
+      || hipStreamSynchronize(e->stream) != hipSuccess)
+    { free(hc); free(ho); return fail(errbuf, errlen, SMG_ENODEV, "route: device to host copy failed%s"); }
+  u64 acc = 0;
+  for (int r = 0; r < nranks; r++)          // destination-major, chunk order inside a destination
+    for (unsigned c = 0; c < nc; c++)
+      { ho[(size_t) c * nranks + r] = acc;
+        acc += hc[(size_t) c * nranks + r];
+        counts[r] += hc[(size_t) c * nranks + r];
+      }
+  hipError_t he = hipMemcpyAsync(e->route_off, ho, sizeof(u64) * (size_t) nc * nranks, hipMemcpyHostToDevice, e->stream);
+  if (he == hipSuccess)
+    {
+#define CALL(WW) hipLaunchKernelGGL(kf_route_scatter<WW>, dim3(nc), dim3(F_TPB), 0, e->stream, e->req, \
+                   e->chunk_fill, e->d_split, nranks, e->route_off, (u64 *) d_send)
+      DISPATCH_W3(e, CALL)
+#undef CALL
+      he = hipStreamSynchronize(e->stream);
+    }
+  free(hc); free(ho);
+  if (he != hipSuccess) return fail(errbuf, errlen, SMG_ENODEV, "route: %s", hipGetErrorString(he));
+  return SMG_OK;
+}
+
+extern "C" int smg_engine_pass2(smg_engine *e, int64_t *d_plot, char *errbuf, size_t errlen)
+{ NEED_FAST(e)
+  if (!e->prepared || !d_plot) return fail(errbuf, errlen, SMG_EINVAL, "pass2 before pass1%s");
+  HIPCHK(hipSetDevice(e->device));
+  return fast_pass2(e, d_plot, errbuf, errlen);
+}
+
+extern "C" int smg_engine_stats(smg_engine *e, smg_stats *stats)
+{ if (!e || !stats) return SMG_EINVAL;
+  *stats = e->st;
   return SMG_OK;
 }
 
@@ -796,28 +912,23 @@ extern "C" int smg_engine_run(smg_engine *e, int symcheck, int64_t *d_plot, smg_
   hipEventRecord(t0, e->stream);
   e->st.ms_pass1 = e->st.ms_rclookup = e->st.ms_pass2 = 0;
   bool symmetric = false;
-  if (symcheck != SMG_SYM_NONE)
-    { e->prepared = false;
-      rc = do_pass1_sym(e, 0, symcheck == SMG_SYM_HASH, errbuf, errlen);
+  if (symcheck != SMG_SYM_NONE && e->kmer <= FAST_MAX_K)
+    { rc = fast_pass1(e, 0, symcheck == SMG_SYM_HASH, errbuf, errlen);
       if (rc) return rc;
       int64_t missing = 0;
-      if ((rc = smg_engine_apply_own(e, &missing, errbuf, errlen))) return rc;
+      // hash mode: the fingerprint covers (k-mer, count), the per-request count check is redundant
+      if ((rc = fast_apply(e, NULL, 0, symcheck != SMG_SYM_HASH, &missing, errbuf, errlen))) return rc;
       symmetric = (missing == 0);
       if (symmetric && symcheck == SMG_SYM_HASH)
-        symmetric = e->h_ctrl->fp[0] == e->h_ctrl->fp[2] && e->h_ctrl->fp[1] == e->h_ctrl->fp[3];
+        symmetric = e->fp[0] == e->fp[2] && e->fp[1] == e->fp[3];
       if (symmetric && symcheck == SMG_SYM_EXACT)
-        { hipEventRecord(e->ev[4], e->stream);
-#define CALL(WW) launch_verify<WW>(e)
-          DISPATCH_W(e, CALL)
-#undef CALL
-          hipEventRecord(e->ev[5], e->stream);
-          if ((rc = read_ctrl(e, errbuf, errlen))) return rc;
-          float ms = 0; hipEventElapsedTime(&ms, e->ev[4], e->ev[5]);
-          e->st.ms_rclookup += ms;
-          symmetric = (e->h_ctrl->missing == 0);
+        { if ((rc = fast_verify(e, &missing, errbuf, errlen))) return rc;
+          symmetric = (missing == 0);
         }
-      if (symmetric && (rc = smg_engine_pass2(e, d_plot, errbuf, errlen))) return rc;
+      if (symmetric && (rc = fast_pass2(e, d_plot, errbuf, errlen))) return rc;
     }
+  else if (symcheck != SMG_SYM_NONE)
+    { if ((rc = counted_symmetric(e, symcheck, d_plot, &symmetric, errbuf, errlen))) return rc; }
   if (!symmetric && (rc = run_general(e, d_plot, errbuf, errlen))) return rc;
   hipEventRecord(t1, e->stream);
   HIPCHK(hipStreamSynchronize(e->stream));

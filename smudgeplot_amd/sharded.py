@@ -61,6 +61,9 @@ class TorchEngine:
     def apply(self, recv, nrecv):
         return self.e.apply(recv.data_ptr(), nrecv)
 
+    def apply_own(self):
+        return self.e.apply_own()
+
     def symhash(self):
         return self.e.symhash()
 
@@ -139,10 +142,10 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
     eng.pass1(symcheck)
     rw = eng.record_words()
     nreq = eng.nreq()
-    send = torch.empty(max(nreq, 1) * rw, dtype=torch.int64, device=dev)
-    send_counts = eng.route(splitters, world, send)
 
     if world > 1:
+        send = torch.empty(max(nreq, 1) * rw, dtype=torch.int64, device=dev)
+        send_counts = eng.route(splitters, world, send)
         sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
         rcnt = torch.empty_like(sc)
         dist.all_to_all_single(rcnt, sc, group=group)
@@ -152,10 +155,10 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
         dist.all_to_all_single(recv[: nrecv * rw], send[: nreq * rw],
                                output_split_sizes=[c * rw for c in recv_counts],
                                input_split_sizes=[c * rw for c in send_counts], group=group)
+        missing = eng.apply(recv, nrecv)
     else:
-        recv, nrecv = send, nreq
-
-    missing = eng.apply(recv, nrecv)
+        nrecv = nreq
+        missing = eng.apply_own()          # every complement is local: no routing, no copy
 
     # symmetry proof, reduced over ranks: missing == 0 and fingerprint(T) == fingerprint(rc T)
     proof = np.array([missing] + eng.symhash(), dtype=np.uint64).view(np.int64)
