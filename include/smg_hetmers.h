@@ -138,10 +138,12 @@ int smg_engine_run(smg_engine *e, int symcheck, int64_t *d_plot, smg_stats *stat
              and the per-rank counts into counts[nranks] (host).  A record is
              (words+1) uint64: the complement k-mer, then count | value<<16.
              splitters = (nranks-1)*words host uint64, the first k-mer of ranks 1..nranks-1.
+             Bound device tables must be 16-byte (k-mers) / 8-byte (counts) aligned.
    apply   : adds received (or own) requests to the local degrees; *missing counts requests
              whose k-mer is absent or carries another count (=> table not symmetric).
-   symhash : out[0..1] = fingerprint of T, out[2..3] = fingerprint of rc(T) (sum over ranks
-             with wrap-around and compare).
+   symhash : out[0..1] = 128-bit signed canonical fingerprint residue of the shard (sum over ranks
+             with wrap-around: zero iff T == rc(T) with equal counts, up to a 2^-128 collision),
+             out[2..3] = 0 (the value to compare with).
    pass2   : histogram of unique pairs into d_plot (device int64[SMG_PLOT_CELLS], overwritten).*/
 int     smg_engine_pass1(smg_engine *e, int symcheck, char *errbuf, size_t errlen);
 int64_t smg_engine_nreq(smg_engine *e);

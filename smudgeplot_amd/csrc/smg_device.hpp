@@ -98,11 +98,8 @@ template <int W> SMG_DEV Key<W> flip_base(const Key<W> &x, int p, int d)
 }
 
 SMG_DEV u64 rev2_word(u64 x)        // reverse the order of the 32 2-bit groups of a word
-{ x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
-  x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
-  x = ((x >> 8) & 0x00FF00FF00FF00FFull) | ((x & 0x00FF00FF00FF00FFull) << 8);
-  x = ((x >> 16) & 0x0000FFFF0000FFFFull) | ((x & 0x0000FFFF0000FFFFull) << 16);
-  return (x >> 32) | (x << 32);
+{ const u64 y = __brevll(x);        // v_bfrev_b32 x2: groups reversed, the 2 bits of a group swapped
+  return ((y >> 1) & 0x5555555555555555ull) | ((y & 0x5555555555555555ull) << 1);
 }
 
 // reverse complement of a left aligned k-mer (restates compress_comp, PloidyPlot.c:1143-1165)
@@ -163,6 +160,42 @@ template <int W> SMG_DEV u64 hash_entry(const Key<W> &x, unsigned c, u64 seed)
 #pragma unroll
   for (int w = 0; w < W; w++) a = mix64(a ^ x.w[w]);
   return mix64(a ^ (u64) c ^ 0x9e3779b97f4a7c15ull);
+}
+
+// 128-bit mixing of (k-mer, count) from full-rate 32-bit add/xor/rotate only (64-bit integer
+// multiplies are quarter rate on CDNA): ChaCha-style quarter rounds over a 4-word state.
+SMG_DEV void arx_qr(unsigned &a, unsigned &b, unsigned &c, unsigned &d)
+{ a += b; d ^= a; d = __builtin_rotateleft32(d, 16);
+  c += d; b ^= c; b = __builtin_rotateleft32(b, 12);
+  a += b; d ^= a; d = __builtin_rotateleft32(d, 8);
+  c += d; b ^= c; b = __builtin_rotateleft32(b, 7);
+}
+
+template <int W> SMG_DEV void arx_hash(const Key<W> &x, unsigned cnt, u64 &ha, u64 &hb)
+{ unsigned a = 0x61707865u ^ cnt, b = 0x3320646eu, c = 0x79622d32u, d = 0x6b206574u;
+#pragma unroll
+  for (int w = 0; w < W; w++)
+    { a ^= (unsigned) x.w[w]; b ^= (unsigned) (x.w[w] >> 32);
+      arx_qr(a, b, c, d);
+      if (w + 1 < W) arx_qr(a, b, c, d);
+    }
+  arx_qr(a, b, c, d);
+  arx_qr(a, b, c, d);
+  ha = (u64) a | ((u64) b << 32);
+  hb = (u64) c | ((u64) d << 32);
+}
+
+// Signed canonical fingerprint of one entry: +g(min(x,rc),cnt) when x < rc(x), -g when x > rc(x),
+// 0 for a self-complementary k-mer.  Summed (mod 2^64, two lanes) over a table that is closed under
+// reverse complement with equal counts, every class {x, rc(x)} cancels exactly; any entry whose
+// complement is absent or carries another count leaves a 128-bit residue.
+template <int W> SMG_DEV void fp_accumulate(const Key<W> &x, const Key<W> &rc, unsigned cnt,
+                                            u64 &fa, u64 &fb)
+{ const bool lt = key_lt<W>(x, rc), gt = key_lt<W>(rc, x);
+  u64 ha, hb;
+  arx_hash<W>(lt ? x : rc, cnt, ha, hb);
+  if (lt) { fa += ha; fb += hb; }
+  if (gt) { fa -= ha; fb -= hb; }
 }
 
 SMG_DEV u64 wave_sum_u64(u64 v)

@@ -127,20 +127,43 @@ kf_pass1(FastArgs A, uint32_t *__restrict__ bstart, u64 *__restrict__ req,
   const int t = threadIdx.x;
   const Geo g = A.g;
   const int64_t n = A.n;
-  u64 f0 = 0, f1 = 0, f2 = 0, f3 = 0;
+  u64 f0 = 0, f1 = 0;
   if (t == 0) { s_chunk = F_NOCHUNK; s_used = 0; s_total = 0; }
 
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
     { const int64_t lo = tile * F_TILE;
-      // stage keys + counts of [lo-HALO, lo+TILE+HALO) in LDS (coalesced)
-      for (int idx = t; idx < F_SPAN; idx += F_TPB)
-        { const int64_t gi = lo - F_HALO + idx;
-          if (gi >= 0 && gi < n)
-            { const Key<W> x = load_key<W>(A.keys, gi);
-#pragma unroll
-              for (int w = 0; w < W; w++) sk[idx * W + w] = x.w[w];
-              sc[idx] = A.cnt[gi];
+      // stage keys + counts of [lo-HALO, lo+TILE+HALO) in LDS: 16-byte key loads, 8-byte count
+      // loads (lo-HALO is a multiple of 32 entries, so the groups never straddle the tile)
+      if constexpr (W == 1)
+        { for (int p = t; p < F_SPAN / 2; p += F_TPB)
+            { const int64_t gi = lo - F_HALO + 2 * p;
+              if (gi >= 0 && gi + 1 < n)
+                { const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(A.keys + gi);
+                  sk[2 * p] = v.x; sk[2 * p + 1] = v.y;
+                }
+              else if (gi >= 0 && gi < n)
+                sk[2 * p] = A.keys[gi];
             }
+        }
+      else
+        { for (int idx = t; idx < F_SPAN; idx += F_TPB)
+            { const int64_t gi = lo - F_HALO + idx;
+              if (gi >= 0 && gi < n)
+                { const Key<W> x = load_key<W>(A.keys, gi);
+#pragma unroll
+                  for (int w = 0; w < W; w++) sk[idx * W + w] = x.w[w];
+                }
+            }
+        }
+      for (int p = t; p < F_SPAN / 4; p += F_TPB)
+        { const int64_t gi = lo - F_HALO + 4 * p;
+          if (gi >= 0 && gi + 3 < n)
+            { const ushort4 v = *reinterpret_cast<const ushort4 *>(A.cnt + gi);
+              sc[4 * p] = v.x; sc[4 * p + 1] = v.y; sc[4 * p + 2] = v.z; sc[4 * p + 3] = v.w;
+            }
+          else
+            for (int q = 0; q < 4; q++)
+              if (gi + q >= 0 && gi + q < n) sc[4 * p + q] = A.cnt[gi + q];
         }
       if (t == 0) s_qn = 0;
       __syncthreads();
@@ -212,12 +235,7 @@ kf_pass1(FastArgs A, uint32_t *__restrict__ bstart, u64 *__restrict__ req,
                   for (int w = 0; w < W; w++) sq[q * (W + 1) + w] = rc.w[w];
                   sq[q * (W + 1) + W] = (u64) c | ((u64) (s_hi > 0) << 16);
                 }
-              if (want_fp)
-                { f0 += hash_entry<W>(x, c, 0x243f6a8885a308d3ull);
-                  f1 += hash_entry<W>(x, c, 0x13198a2e03707344ull);
-                  f2 += hash_entry<W>(rc, c, 0x243f6a8885a308d3ull);
-                  f3 += hash_entry<W>(rc, c, 0x13198a2e03707344ull);
-                }
+              if (want_fp) fp_accumulate<W>(x, rc, c, f0, f1);
             }
         }
       __syncthreads();
@@ -249,13 +267,14 @@ kf_pass1(FastArgs A, uint32_t *__restrict__ bstart, u64 *__restrict__ req,
       if (s_total) atomicAdd(&ctl->nreq, s_total);
     }
   if (want_fp)
-    { f0 = wave_sum_u64(f0); f1 = wave_sum_u64(f1); f2 = wave_sum_u64(f2); f3 = wave_sum_u64(f3);
-      if ((t & 63) == 0) { sfp[t >> 6][0] = f0; sfp[t >> 6][1] = f1; sfp[t >> 6][2] = f2; sfp[t >> 6][3] = f3; }
+    { f0 = wave_sum_u64(f0); f1 = wave_sum_u64(f1);
+      if ((t & 63) == 0) { sfp[t >> 6][0] = f0; sfp[t >> 6][1] = f1; }
       __syncthreads();
-      if (t < 4)
+      if (t < 2)
         { u64 s = 0;
           for (int w = 0; w < F_TPB / 64; w++) s += sfp[w][t];
           partials[(size_t) blockIdx.x * 4 + t] = s;
+          partials[(size_t) blockIdx.x * 4 + 2 + t] = 0;
         }
     }
 }
@@ -322,6 +341,8 @@ far_partner(const FastArgs &A, int64_t i, int64_t &partner, unsigned &w2)
   big_block_scan<W>(A.keys, A.cnt, A.n, A.g, i, s_all, s_hi, partner, w2);
 }
 
+#define P2_VEC 16          // consecutive entries per thread per iteration: one 16-byte code load
+
 template <int W> __global__ void __launch_bounds__(P2_TPB)
 kf_pass2(FastArgs A, u64 *__restrict__ plot)
 { __shared__ unsigned tile[P2_CELLS];
@@ -329,22 +350,38 @@ kf_pass2(FastArgs A, u64 *__restrict__ plot)
   for (int c = t; c < P2_CELLS; c += P2_TPB) tile[c] = 0;
   __syncthreads();
 
-  const int64_t stride = (int64_t) gridDim.x * P2_TPB;
-  for (int64_t i = (int64_t) blockIdx.x * P2_TPB + t; i < A.n; i += stride)
-    { const unsigned ci = A.code[i];
-      const unsigned lo6 = ci & 63;
-      if (lo6 == CODE_NONE || lo6 == CODE_MULTI) continue;
-      int64_t j;
-      unsigned w2 = (ci & CODE_W2) != 0;
-      if (lo6 == CODE_FAR)
-        far_partner<W>(A, i, j, w2);
-      else
-        j = i + (int) lo6 - 31;
-      if (j <= i) continue;                               // the lower entry of a pair reports it
-      const unsigned lj = A.code[j] & 63;
-      if (lj == CODE_NONE || lj == CODE_MULTI) continue;  // partner has several pairs
-      if (pbit(A.pbits, i) || pbit(A.pbits, j)) continue; // a prefix-side pair exists as well
-      plot_bump(tile, plot, A.cnt[i], A.cnt[j], w2 ? 2u : 1u);
+  const int64_t stride = (int64_t) gridDim.x * P2_TPB * P2_VEC;
+  for (int64_t i0 = ((int64_t) blockIdx.x * P2_TPB + t) * P2_VEC; i0 < A.n; i0 += stride)
+    { // the code array is 16-byte aligned and padded past n
+      const uint4 cv = *reinterpret_cast<const uint4 *>(A.code + i0);
+      const unsigned wv[4] = { cv.x, cv.y, cv.z, cv.w };
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        { unsigned word = wv[q];
+          // quick reject: no byte of this word is a "unique pair, partner above" candidate
+          if (word == 0) continue;
+#pragma unroll
+          for (int bb = 0; bb < 4; bb++)
+            { const unsigned ci = (word >> (8 * bb)) & 0xFF;
+              const unsigned lo6 = ci & 63;
+              if (lo6 == CODE_NONE || lo6 == CODE_MULTI) continue;
+              if (lo6 < 32) continue;                        // partner below: it reports the pair
+              const int64_t i = i0 + 4 * q + bb;
+              if (i >= A.n) continue;
+              int64_t j;
+              unsigned w2 = (ci & CODE_W2) != 0;
+              if (lo6 == CODE_FAR)
+                { far_partner<W>(A, i, j, w2);
+                  if (j <= i) continue;
+                }
+              else
+                j = i + (int) lo6 - 31;
+              const unsigned lj = A.code[j] & 63;
+              if (lj == CODE_NONE || lj == CODE_MULTI) continue;  // partner has several pairs
+              if (pbit(A.pbits, i) || pbit(A.pbits, j)) continue; // a prefix-side pair exists too
+              plot_bump(tile, plot, A.cnt[i], A.cnt[j], w2 ? 2u : 1u);
+            }
+        }
     }
   __syncthreads();
 

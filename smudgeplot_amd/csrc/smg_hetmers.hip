@@ -463,6 +463,8 @@ extern "C" int smg_engine_bind(smg_engine *e, int kmer, int64_t nels, const uint
                                const uint16_t *d_counts, char *errbuf, size_t errlen)
 { if (!e) return fail(errbuf, errlen, SMG_EINVAL, "null engine%s");
   if (nels > 0 && (!d_keys || !d_counts)) return fail(errbuf, errlen, SMG_EINVAL, "null table pointer%s");
+  if (((uintptr_t) d_keys & 15) || ((uintptr_t) d_counts & 7))
+    return fail(errbuf, errlen, SMG_EINVAL, "table pointers must be aligned (k-mers 16 bytes, counts 8 bytes)%s");
   HIPCHK(hipSetDevice(e->device));
   int rc = set_table(e, kmer, nels, errbuf, errlen);
   if (rc) return rc;
@@ -683,7 +685,7 @@ static int fast_pass1(smg_engine *e, int emit_all, int want_fp, char *errbuf, si
   HIPCHK(hipMemsetAsync(e->ctrl, 0, sizeof(Ctrl), e->stream));
   set_geo(e);
   e->fast = true;
-  if ((rc = grow(&e->deg, &e->deg_cap, ((e->n + 3) & ~3ll) + 4, errbuf, errlen))) return rc;
+  if ((rc = grow(&e->deg, &e->deg_cap, ((e->n + 15) & ~15ll) + 32, errbuf, errlen))) return rc;
   const int64_t pbytes = ((e->n + 31) / 32 + 2) * 4;
   if ((rc = grow(&e->pbits, &e->pbits_cap, pbytes, errbuf, errlen))) return rc;
   HIPCHK(hipMemsetAsync(e->pbits, 0, (size_t) pbytes, e->stream));

@@ -67,11 +67,37 @@ EXPORTS = [
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """PyTorch wheels bundle their own libamdhip64.so.7 / HSA runtime.  Two HIP runtimes in one
+    process do not work (the second one finds no GPU), and stream handles must come from the
+    runtime that launches on them.  Both copies carry the same soname, so whichever is loaded
+    first serves everybody: if torch is installed but not imported yet, map ITS copy first so a
+    later `import torch` and this library share one runtime.  Without torch (the plain-C
+    `hetmers` executable) the system ROCm runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library():
     """dlopen the in-tree library; raises EngineError (never falls back) when it is missing."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_torch_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise EngineError(-1, f"{LIB_PATH} is not built (run `python -c 'import __graft_entry__ as g; "
                               f"g.build()'` or `make -C smudgeplot_amd/csrc`)")

@@ -177,7 +177,7 @@ def test_engine_object_with_torch_tensors_and_manual_two_shard_exchange():
 
     # two shards, manual exchange
     cut = sharded.fix_cut(keys, 1, k, len(cnt) // 2)
-    shards = [(tk[:cut].contiguous(), tc[:cut].contiguous()), (tk[cut:].contiguous(), tc[cut:].contiguous())]
+    shards = [(tk[:cut].clone(), tc[:cut].clone()), (tk[cut:].clone(), tc[cut:].clone())]
     engs = [sharded.TorchEngine(dev) for _ in range(2)]
     split = keys[cut:cut + 1].copy()
     sends, counts = [], []
