@@ -60,27 +60,44 @@ def diploid_table(G: int, k: int = 31, het: float = 0.01, cov: float = 50.0, L: 
     delta = torch.randint(1, 4, (G,), dtype=torch.uint8, device=device, generator=gen)
     h2 = torch.where(snp, (h1 + delta) & 3, h1)
     del snp, delta
-    parts = []
-    for h in (h1, h2):
-        km = _kmers_of(h, k)
-        parts.append(km)
-        parts.append(_revcomp_right(km, k))
+    km = [_kmers_of(h1, k), _kmers_of(h2, k)]
     del h1, h2
-    allk = torch.cat(parts)
-    del parts, km
-    keys, mult = torch.unique(allk, sorted=True, return_counts=True)
-    del allk
-    # multiplicity 2+ => present in both haplotypes (or a genomic repeat): homozygous coverage
-    canon = torch.minimum(keys, _revcomp_right(keys, k))
-    u1 = (_mix(canon ^ 0x243F6A8885A308D3) >> 11).to(torch.float64) / float(1 << 53)
-    u2 = (_mix(canon ^ 0x13198A2E03707344) >> 11).to(torch.float64) / float(1 << 53)
-    del canon
-    u1 = u1 - torch.floor(u1); u2 = u2 - torch.floor(u2)
-    z = torch.sqrt(-2.0 * torch.log(u1.clamp_min(1e-300))) * torch.cos(2 * math.pi * u2)
-    del u1, u2
-    mean = torch.where(mult >= 2, torch.tensor(float(cov), device=device, dtype=torch.float64),
-                       torch.tensor(float(cov) / 2, device=device, dtype=torch.float64))
-    cnt = torch.round(mean + torch.sqrt(mean) * z).clamp_(L, 32767).to(torch.int16)
-    del z, mean, mult
+    # torch.unique (rocPRIM) takes < 2^31 elements: split the key space by leading bits
+    total = 4 * km[0].numel()
+    nchunk = 1
+    while total / nchunk > 1.2e9:
+        nchunk *= 2
+    cb = nchunk.bit_length() - 1
+    shift = 2 * k - cb
+    key_parts, cnt_parts = [], []
+    for c in range(nchunk):
+        sel = []
+        for a in km:
+            sel.append(a[(a >> shift) == c] if cb else a)
+            r = _revcomp_right(a, k)
+            sel.append(r[(r >> shift) == c] if cb else r)
+            del r
+        allk = torch.cat(sel)
+        del sel
+        keys, mult = torch.unique(allk, sorted=True, return_counts=True)
+        del allk
+        # multiplicity 2+ => present in both haplotypes (or a genomic repeat): homozygous coverage
+        canon = torch.minimum(keys, _revcomp_right(keys, k))
+        u1 = (_mix(canon ^ 0x243F6A8885A308D3) >> 11).to(torch.float64) / float(1 << 53)
+        u2 = (_mix(canon ^ 0x13198A2E03707344) >> 11).to(torch.float64) / float(1 << 53)
+        del canon
+        u1 = u1 - torch.floor(u1); u2 = u2 - torch.floor(u2)
+        z = torch.sqrt(-2.0 * torch.log(u1.clamp_min(1e-300))) * torch.cos(2 * math.pi * u2)
+        del u1, u2
+        mean = torch.where(mult >= 2, torch.tensor(float(cov), device=device, dtype=torch.float64),
+                           torch.tensor(float(cov) / 2, device=device, dtype=torch.float64))
+        cnt = torch.round(mean + torch.sqrt(mean) * z).clamp_(L, 32767).to(torch.int16)
+        del z, mean, mult
+        key_parts.append(keys)
+        cnt_parts.append(cnt)
+    del km
+    keys = torch.cat(key_parts) if nchunk > 1 else key_parts[0]
+    cnt = torch.cat(cnt_parts) if nchunk > 1 else cnt_parts[0]
+    del key_parts, cnt_parts
     keys <<= (64 - 2 * k)                      # left align: base 0 in bits 63..62
     return keys, cnt
