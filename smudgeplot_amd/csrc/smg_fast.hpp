@@ -14,8 +14,8 @@
 //                           through an LDS queue and written, coalesced, into per-workgroup
 //                           chunks of F_CH records (one global atomic per chunk)
 //               fingerprints of T and rc(T) (per-workgroup partial sums, no atomics)
-//   kf_apply  one workgroup per chunk: directory look-up of the complement, atomicOr of the
-//             "has a prefix-side pair" bit  P[j]  (the S_hi(rc(x)) > 0 term of the degree)
+//   kf_apply  one workgroup per chunk: directory look-up of the complement, plain store of the
+//             "has a prefix-side pair" byte P[j]  (the S_hi(rc(x)) > 0 term of the degree)
 //   kf_pass2  needs no k-mers at all: entry i with a unique local partner j = i+delta > i counts
 //             iff neither i nor j has its P bit and j's code is "unique" too; the (sum,min) cell is
 //             bumped in an LDS tile (sum < 256, triangular, u32), flushed once per workgroup.
@@ -52,7 +52,7 @@ struct FastArgs
   Geo             g;
   Dir             dir;           // bstart written by pass 1, read by apply
   uint8_t        *code;
-  uint32_t       *pbits;
+  uint8_t        *pflag;         // pflag[j] != 0 : entry j has a prefix-side pair
 };
 
 struct FastCtl                    // device control words of the fast path
@@ -303,7 +303,7 @@ kf_apply(FastArgs A, const u64 *__restrict__ req, const uint32_t *__restrict__ c
       bool bad = j < 0;
       if (!bad && check_count) bad = A.cnt[j] != (unsigned) (meta & 0xFFFF);
       if (bad) { if (ctl->missing == 0) ctl->missing = 1; continue; }
-      if (meta >> 16 & 1) atomicOr(A.pbits + (j >> 5), 1u << (j & 31));
+      if (meta >> 16 & 1) A.pflag[j] = 1;          // plain byte store: no read-modify-write
     }
 }
 
@@ -325,8 +325,6 @@ SMG_DEV unsigned tri_index(unsigned s, unsigned m)       // cell of (sum, min) i
   return (a + 1) * (a + (s & 1)) + m;
 }
 
-SMG_DEV bool pbit(const uint32_t *__restrict__ pbits, int64_t i)
-{ return (pbits[i >> 5] >> (i & 31)) & 1u; }
 
 SMG_DEV void plot_bump(unsigned *tile, u64 *__restrict__ plot, unsigned ci, unsigned cj, unsigned wgt)
 { const unsigned s = ci + cj, m = ci < cj ? ci : cj;
@@ -350,36 +348,46 @@ kf_pass2(FastArgs A, u64 *__restrict__ plot)
   for (int c = t; c < P2_CELLS; c += P2_TPB) tile[c] = 0;
   __syncthreads();
 
-  const int64_t stride = (int64_t) gridDim.x * P2_TPB * P2_VEC;
-  for (int64_t i0 = ((int64_t) blockIdx.x * P2_TPB + t) * P2_VEC; i0 < A.n; i0 += stride)
-    { // the code array is 16-byte aligned and padded past n
-      const uint4 cv = *reinterpret_cast<const uint4 *>(A.code + i0);
-      const unsigned wv[4] = { cv.x, cv.y, cv.z, cv.w };
+  // each thread streams 4 independent 16-byte code loads per iteration (memory-level parallelism)
+  const int64_t chunk = (int64_t) P2_TPB * P2_VEC * 4;
+  for (int64_t c0 = (int64_t) blockIdx.x * chunk; c0 < A.n; c0 += (int64_t) gridDim.x * chunk)
+    { uint4 cv[4];
 #pragma unroll
-      for (int q = 0; q < 4; q++)
-        { unsigned word = wv[q];
-          // quick reject: no byte of this word is a "unique pair, partner above" candidate
-          if (word == 0) continue;
+      for (int u = 0; u < 4; u++)
+        { const int64_t i0 = c0 + ((int64_t) u * P2_TPB + t) * P2_VEC;
+          cv[u] = make_uint4(0, 0, 0, 0);
+          if (i0 < A.n) cv[u] = *reinterpret_cast<const uint4 *>(A.code + i0);   // padded past n
+        }
 #pragma unroll
-          for (int bb = 0; bb < 4; bb++)
-            { const unsigned ci = (word >> (8 * bb)) & 0xFF;
-              const unsigned lo6 = ci & 63;
-              if (lo6 == CODE_NONE || lo6 == CODE_MULTI) continue;
-              if (lo6 < 32) continue;                        // partner below: it reports the pair
-              const int64_t i = i0 + 4 * q + bb;
-              if (i >= A.n) continue;
-              int64_t j;
-              unsigned w2 = (ci & CODE_W2) != 0;
-              if (lo6 == CODE_FAR)
-                { far_partner<W>(A, i, j, w2);
-                  if (j <= i) continue;
+      for (int u = 0; u < 4; u++)
+        { const int64_t i0 = c0 + ((int64_t) u * P2_TPB + t) * P2_VEC;
+          const unsigned wv[4] = { cv[u].x, cv[u].y, cv[u].z, cv[u].w };
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            { const unsigned word = wv[q];
+              // candidates: "unique pair, partner above" = low 6 bits in 32..62
+              const unsigned cand = word & 0x20202020u;
+              if (cand == 0) continue;
+#pragma unroll
+              for (int bb = 0; bb < 4; bb++)
+                { const unsigned ci = (word >> (8 * bb)) & 0xFF;
+                  const unsigned lo6 = ci & 63;
+                  if (lo6 < 32 || lo6 == CODE_MULTI) continue;
+                  const int64_t i = i0 + 4 * q + bb;
+                  if (i >= A.n) continue;
+                  int64_t j;
+                  unsigned w2 = (ci & CODE_W2) != 0;
+                  if (lo6 == CODE_FAR)
+                    { far_partner<W>(A, i, j, w2);
+                      if (j <= i) continue;
+                    }
+                  else
+                    j = i + (int) lo6 - 31;
+                  const unsigned lj = A.code[j] & 63;
+                  if (lj == CODE_NONE || lj == CODE_MULTI) continue;  // partner has several pairs
+                  if (A.pflag[i] | A.pflag[j]) continue;              // a prefix-side pair exists too
+                  plot_bump(tile, plot, A.cnt[i], A.cnt[j], w2 ? 2u : 1u);
                 }
-              else
-                j = i + (int) lo6 - 31;
-              const unsigned lj = A.code[j] & 63;
-              if (lj == CODE_NONE || lj == CODE_MULTI) continue;  // partner has several pairs
-              if (pbit(A.pbits, i) || pbit(A.pbits, j)) continue; // a prefix-side pair exists too
-              plot_bump(tile, plot, A.cnt[i], A.cnt[j], w2 ? 2u : 1u);
             }
         }
     }
@@ -460,5 +468,268 @@ kf_route_scatter(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk
       u64 *o = out + slot * (W + 1);
 #pragma unroll
       for (int w = 0; w <= W; w++) o[w] = q[w];
+    }
+}
+
+// =================================================================================================
+//  kf_pass1_s : pass 1 specialised for k <= 32 (one 64-bit word per k-mer) -- the headline path.
+//
+//  Differences from the generic kf_pass1<W>:
+//   * the staged LDS entry is {prefix32 | suffix32}: the first p0 bases and the last k-p0 bases of
+//     the k-mer, so "same window block" is one 32-bit compare and the one-away test is 7 32-bit ops;
+//   * each pair is discovered ONCE, by its lower entry scanning forward in a wave-uniform loop
+//     (trip count = longest block run in the wave; rare work sits behind one branch); the upper
+//     entry is credited through a packed LDS atomic: count | hi<<8 | sum(delta)<<16;
+//   * a tile owns 992 entries and scans 1024 (its 32-entry left halo included), exactly 4 per thread;
+//   * the next tile's k-mers and counts are prefetched into registers while this one is scanned, and
+//     the workgroup barriers wait for LDS only (s_waitcnt lgkmcnt(0); s_barrier) -- __syncthreads()
+//     also drains every outstanding global store, which stalled v2 (profiles/r01_v2_pmc_*);
+//   * entries whose block reaches 32 entries to either side take the exact slow walk.
+// =================================================================================================
+
+#define S_TPB   256
+#define S_OWN   992
+#define S_HALO  32
+#define S_SCAN  1024                   // left halo + owned
+#define S_SPAN  (S_SCAN + S_HALO)      // 1056 LDS slots
+
+struct Geo32
+{ int      k;
+  int      kshift;       // 64 - 2k
+  int      sbits;        // 2 * (k - p0)
+  unsigned smask;        // low sbits set
+  unsigned midbit;       // the `t` bit of a pair at the self-mirrored position (0 when k is even)
+};
+
+SMG_DEV void lds_barrier()             // workgroup barrier that orders LDS traffic only
+{ asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ void __launch_bounds__(S_TPB)
+kf_pass1_s(FastArgs A, Geo32 G, uint32_t *__restrict__ bstart, u64 *__restrict__ req,
+           uint32_t *__restrict__ chunk_fill, unsigned max_chunks, int emit_all, int want_fp,
+           u64 *__restrict__ partials, FastCtl *__restrict__ ctl, int64_t ntiles)
+{ __shared__ u64      ent[S_SPAN];
+  __shared__ uint16_t scnt[S_SPAN];
+  __shared__ unsigned acc[S_SPAN];
+  __shared__ u64      sq[S_OWN * 2];
+  __shared__ u64      sfp[S_TPB / 64][2];
+  __shared__ unsigned s_qn, s_chunk, s_used;
+  __shared__ u64      s_base, s_total;
+
+  const int t = threadIdx.x;
+  const int64_t n = A.n;
+  u64 f0 = 0, f1 = 0;
+  if (t == 0) { s_chunk = F_NOCHUNK; s_used = 0; s_total = 0; s_qn = 0; }
+
+  // register prefetch of one tile: 528 key pairs (16 B) and 264 count quads (8 B)
+  ulonglong2 kr[3];
+  ushort4    cr[2];
+  auto prefetch = [&](int64_t tile)
+  { const int64_t g0 = tile * S_OWN - S_HALO;
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+      { const int p = t + q * S_TPB;
+        const int64_t gi = g0 + 2 * p;
+        kr[q] = make_ulonglong2(~0ull, ~0ull);
+        if (p < S_SPAN / 2)
+          { if (gi >= 0 && gi + 1 < n) kr[q] = *reinterpret_cast<const ulonglong2 *>(A.keys + gi);
+            else
+              { if (gi >= 0 && gi < n) kr[q].x = A.keys[gi];
+                if (gi + 1 >= 0 && gi + 1 < n) kr[q].y = A.keys[gi + 1];
+              }
+          }
+      }
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+      { const int p = t + q * S_TPB;
+        const int64_t gi = g0 + 4 * p;
+        cr[q] = make_ushort4(0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF);
+        if (p < S_SPAN / 4)
+          { if (gi >= 0 && gi + 3 < n) cr[q] = *reinterpret_cast<const ushort4 *>(A.cnt + gi);
+            else
+              { if (gi >= 0 && gi < n) cr[q].x = A.cnt[gi];
+                if (gi + 1 >= 0 && gi + 1 < n) cr[q].y = A.cnt[gi + 1];
+                if (gi + 2 >= 0 && gi + 2 < n) cr[q].z = A.cnt[gi + 2];
+                if (gi + 3 >= 0 && gi + 3 < n) cr[q].w = A.cnt[gi + 3];
+              }
+          }
+      }
+  };
+  // k-mer word -> {prefix32, suffix32}; slots outside the table hold (0xFFFFFFFF, 0) with count
+  // 0xFFFF, which can never pair (the sum exceeds SMAX) whatever prefix its neighbour has
+  auto split = [&](u64 x, int64_t gi) -> u64
+  { if (gi < 0 || gi >= n) return 0xFFFFFFFF00000000ull;
+    const u64 val = x >> G.kshift;
+    return ((val >> G.sbits) << 32) | (val & G.smask);
+  };
+
+  int64_t tile = blockIdx.x;
+  if (tile < ntiles) prefetch(tile);
+
+  for (; tile < ntiles; tile += gridDim.x)
+    { const int64_t lo = tile * S_OWN;          // first owned entry
+      const int64_t g0 = lo - S_HALO;           // global index of LDS slot 0
+      // ---- phase 0: registers -> LDS ------------------------------------------------------------
+#pragma unroll
+      for (int q = 0; q < 3; q++)
+        { const int p = t + q * S_TPB;
+          if (p < S_SPAN / 2)
+            { ent[2 * p]     = split(kr[q].x, g0 + 2 * p);
+              ent[2 * p + 1] = split(kr[q].y, g0 + 2 * p + 1);
+            }
+        }
+#pragma unroll
+      for (int q = 0; q < 2; q++)
+        { const int p = t + q * S_TPB;
+          if (p < S_SPAN / 4)
+            { scnt[4 * p] = cr[q].x; scnt[4 * p + 1] = cr[q].y; scnt[4 * p + 2] = cr[q].z; scnt[4 * p + 3] = cr[q].w; }
+        }
+      for (int idx = t; idx < S_SPAN; idx += S_TPB) acc[idx] = 0;
+      if (t == 0) s_qn = 0;
+      lds_barrier();
+
+      // ---- phase 1: prefetch the next tile, forward scan with credits ---------------------------
+      if (tile + gridDim.x < ntiles) prefetch(tile + gridDim.x);
+
+      unsigned pre[4], suf[4], cc[4], sa[4], sh[4], dl[4];
+      bool alive[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        { const int idx = t + r * S_TPB;
+          const u64 e = ent[idx];
+          pre[r] = (unsigned) (e >> 32); suf[r] = (unsigned) e; cc[r] = scnt[idx];
+          sa[r] = 0; sh[r] = 0; dl[r] = 0;
+          alive[r] = cc[r] != 0xFFFF;                       // slots outside the table never scan
+        }
+      for (int d = 1; d < S_HALO; d++)
+        { bool any = false;
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            { const int j = t + r * S_TPB + d;
+              const u64 y = ent[j];
+              alive[r] = alive[r] && ((unsigned) (y >> 32) == pre[r]);
+              unsigned tt = suf[r] ^ (unsigned) y;
+              tt = (tt | (tt >> 1)) & 0x55555555u;
+              const bool one = alive[r] && ((tt & (tt - 1)) == 0);
+              if (one)                                       // rare: a one-away neighbour
+                { const unsigned cy = scnt[j];
+                  if (cc[r] + cy <= SMG_SMAX)
+                    { const unsigned hi = (tt != G.midbit);
+                      if (sa[r] == 0) dl[r] = (unsigned) d | (hi << 8);
+                      sa[r]++; sh[r] += hi;
+                      atomicAdd(&acc[j], 1u | (hi << 8) | ((unsigned) d << 16));
+                    }
+                }
+              any |= alive[r];
+            }
+          if (!__any(any)) break;
+        }
+      lds_barrier();
+
+      // ---- phase 2: owned entries: combine, code, directory, complement, requests --------------
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        { const int idx = t + r * S_TPB;
+          const int64_t i = g0 + idx;
+          const bool own = idx >= S_HALO && i < n;
+          unsigned code = 0, s_hi = 0, bcur = 0;
+          u64 x = 0;
+          if (own)
+            { const unsigned a = acc[idx];
+              unsigned s_all = sa[r] + (a & 0xFF);
+              s_hi = sh[r] + ((a >> 8) & 0xFF);
+              int64_t delta = sa[r] ? (int64_t) (dl[r] & 0xFF) : -(int64_t) (a >> 16);
+              unsigned w2 = sa[r] ? (dl[r] >> 8) : ((a >> 8) & 0xFF);
+              // a block that reaches 32 entries to either side: exact slow walk
+              const bool big = (unsigned) (ent[idx - S_HALO] >> 32) == pre[r]
+                            || (unsigned) (ent[idx + S_HALO] >> 32) == pre[r];
+              if (big)
+                { int64_t partner;
+                  big_block_scan<1>(A.keys, A.cnt, n, A.g, i, s_all, s_hi, partner, w2);
+                  delta = partner - i;
+                }
+              code = make_code(s_all, delta, w2);
+              x = ((((u64) pre[r]) << G.sbits) | suf[r]) << G.kshift;
+              bcur = (unsigned) ((x - A.dir.base) >> A.dir.shift);
+              if (i > 0 && !(ent[idx - 1] < ent[idx])) ctl->unsorted = 1;
+            }
+          // directory: buckets (bprev, bcur] start at i; the predecessor's bucket comes from the
+          // neighbouring lane (lane 0 recomputes it from the staged predecessor)
+          unsigned bprev = __shfl_up(bcur, 1, 64);
+          if ((t & 63) == 0 && own && i > 0)
+            { const u64 pe = ent[idx - 1];
+              const u64 px = ((((u64) (unsigned) (pe >> 32)) << G.sbits) | (unsigned) pe) << G.kshift;
+              bprev = (unsigned) ((px - A.dir.base) >> A.dir.shift);
+            }
+          if (own)
+            { A.code[i] = (uint8_t) code;
+              long long b = (i == 0 || idx == S_HALO) ? -1 : (long long) bprev;
+              if (idx == S_HALO && i > 0)                   // first owned entry of the tile
+                { const u64 pe = ent[idx - 1];
+                  const u64 px = ((((u64) (unsigned) (pe >> 32)) << G.sbits) | (unsigned) pe) << G.kshift;
+                  b = (long long) ((px - A.dir.base) >> A.dir.shift);
+                }
+              for (b = b + 1; b <= (long long) bcur; b++) bstart[b] = (uint32_t) i;
+              if (i == n - 1)
+                for (b = (long long) bcur + 1; b <= (long long) A.dir.nb; b++) bstart[b] = (uint32_t) n;
+            }
+          const bool emit = own && (emit_all || s_hi > 0);
+          if (__any(emit || (own && want_fp)))
+            { Key<1> kx, rc;
+              kx.w[0] = x;
+              rc = revcomp<1>(kx, G.k);
+              const u64 em = __ballot(emit);
+              if (em)
+                { const int lane = t & 63, lead = __ffsll((long long) em) - 1;
+                  unsigned qb = 0;
+                  if (lane == lead) qb = atomicAdd(&s_qn, (unsigned) __popcll(em));
+                  qb = __shfl(qb, lead, 64);
+                  if (emit)
+                    { const unsigned q = qb + __popcll(em & ((1ull << lane) - 1));
+                      sq[2 * q] = rc.w[0];
+                      sq[2 * q + 1] = (u64) cc[r] | ((u64) (s_hi > 0) << 16);
+                    }
+                }
+              if (own && want_fp) fp_accumulate<1>(kx, rc, cc[r], f0, f1);
+            }
+        }
+      lds_barrier();
+
+      // ---- phase 3: flush the request queue into this workgroup's chunk --------------------------
+      const unsigned qn = s_qn;
+      if (qn > 0)
+        { if (t == 0)
+            { if (s_chunk == F_NOCHUNK || s_used + qn > F_CH)
+                { if (s_chunk != F_NOCHUNK && s_chunk < max_chunks) chunk_fill[s_chunk] = s_used;
+                  s_chunk = atomicAdd(&ctl->n_chunks, 1u);
+                  s_used = 0;
+                }
+              s_base = (u64) s_chunk * F_CH + s_used;
+              s_used += qn;
+              s_total += qn;
+            }
+          lds_barrier();
+          if (s_chunk < max_chunks)
+            { u64 *o = req + s_base * 2;
+              for (unsigned e = t; e < qn * 2; e += S_TPB) o[e] = sq[e];
+            }
+          lds_barrier();
+        }
+    }
+
+  if (t == 0)
+    { if (s_chunk != F_NOCHUNK && s_chunk < max_chunks) chunk_fill[s_chunk] = s_used;
+      if (s_total) atomicAdd(&ctl->nreq, s_total);
+    }
+  if (want_fp)
+    { f0 = wave_sum_u64(f0); f1 = wave_sum_u64(f1);
+      if ((t & 63) == 0) { sfp[t >> 6][0] = f0; sfp[t >> 6][1] = f1; }
+      lds_barrier();
+      if (t < 2)
+        { u64 s = 0;
+          for (int w = 0; w < S_TPB / 64; w++) s += sfp[w][t];
+          partials[(size_t) blockIdx.x * 4 + t] = s;
+          partials[(size_t) blockIdx.x * 4 + 2 + t] = 0;
+        }
     }
 }

@@ -335,7 +335,7 @@ struct smg_engine
   u64         *own_keys;      // owned copies (decode path)
   uint16_t    *own_cnt;
   uint8_t     *deg;    int64_t deg_cap;      // degree bytes (counted path) / code bytes (fast path)
-  uint32_t    *pbits;  int64_t pbits_cap;
+  uint8_t     *pflag;  int64_t pflag_cap;
   uint32_t    *bstart; int64_t bstart_cap;
   u64         *req;    int64_t req_cap;      // bytes
   uint32_t    *chunk_fill; int64_t chunk_cap; // bytes
@@ -413,7 +413,7 @@ extern "C" void smg_engine_destroy(smg_engine *e)
 { if (!e) return;
   hipSetDevice(e->device);
   hipStreamSynchronize(e->stream);
-  hipFree(e->own_keys); hipFree(e->own_cnt); hipFree(e->deg); hipFree(e->pbits); hipFree(e->bstart);
+  hipFree(e->own_keys); hipFree(e->own_cnt); hipFree(e->deg); hipFree(e->pflag); hipFree(e->bstart);
   hipFree(e->req); hipFree(e->chunk_fill); hipFree(e->route_cnt); hipFree(e->route_off);
   hipFree(e->partials); hipFree(e->ctrl); hipFree(e->d_split);
   hipHostFree(e->h_ctrl); hipHostFree(e->h_partials);
@@ -508,7 +508,7 @@ static int read_ctrl(smg_engine *e, char *errbuf, size_t errlen)
   return SMG_OK;
 }
 
-// directory geometry over the first key word: ~2-4 entries per bucket across the shard's range
+// directory geometry over the first key word: ~8-16 entries per bucket (one 128-byte line of k-mers)
 static int dir_geometry(smg_engine *e, char *errbuf, size_t errlen)
 { u64 first = 0, last = 0;
   if (e->n > 0)
@@ -518,7 +518,7 @@ static int dir_geometry(smg_engine *e, char *errbuf, size_t errlen)
     }
   if (last < first) return fail(errbuf, errlen, SMG_EFORMAT, "table entries are not strictly increasing%s");
   int bits = 4;
-  while (bits < 30 && (1ll << (bits + 1)) <= e->n / 2) bits++;
+  while (bits < 30 && (1ll << (bits + 1)) <= e->n / 8) bits++;
   const u64 span = last - first;
   int shift = 0;
   while (shift < 63 && (span >> shift) >= (1ull << bits)) shift++;
@@ -676,7 +676,7 @@ static int run_general(smg_engine *e, int64_t *d_plot, char *errbuf, size_t errl
 static FastArgs make_fast(smg_engine *e)
 { FastArgs a;
   a.keys = e->keys; a.cnt = e->cnt; a.n = e->n; a.g = e->geo; a.dir = e->dir;
-  a.code = e->deg; a.pbits = e->pbits;
+  a.code = e->deg; a.pflag = e->pflag;
   return a;
 }
 
@@ -686,9 +686,9 @@ static int fast_pass1(smg_engine *e, int emit_all, int want_fp, char *errbuf, si
   set_geo(e);
   e->fast = true;
   if ((rc = grow(&e->deg, &e->deg_cap, ((e->n + 15) & ~15ll) + 32, errbuf, errlen))) return rc;
-  const int64_t pbytes = ((e->n + 31) / 32 + 2) * 4;
-  if ((rc = grow(&e->pbits, &e->pbits_cap, pbytes, errbuf, errlen))) return rc;
-  HIPCHK(hipMemsetAsync(e->pbits, 0, (size_t) pbytes, e->stream));
+  const int64_t pbytes = ((e->n + 15) & ~15ll) + 32;
+  if ((rc = grow(&e->pflag, &e->pflag_cap, pbytes, errbuf, errlen))) return rc;
+  HIPCHK(hipMemsetAsync(e->pflag, 0, (size_t) pbytes, e->stream));
   if ((rc = dir_geometry(e, errbuf, errlen))) return rc;
   if (e->n == 0)
     { HIPCHK(hipMemsetAsync(e->bstart, 0, sizeof(uint32_t) * ((size_t) e->dir.nb + 2), e->stream));
@@ -696,8 +696,14 @@ static int fast_pass1(smg_engine *e, int emit_all, int want_fp, char *errbuf, si
       memset(e->fp, 0, sizeof(e->fp));
       return SMG_OK;
     }
-  const int64_t ntiles = (e->n + F_TILE - 1) / F_TILE;
+  const bool narrow = e->W == 1;                       // k <= 32: the specialised kernel
+  const int64_t ntiles = narrow ? (e->n + S_OWN - 1) / S_OWN : (e->n + F_TILE - 1) / F_TILE;
   const unsigned grid = (unsigned) (ntiles < P1_GRID ? ntiles : P1_GRID);
+  Geo32 g32;
+  g32.k = e->kmer; g32.kshift = 64 - 2 * e->kmer;
+  g32.sbits = 2 * (e->kmer - e->kmer / 2);
+  g32.smask = g32.sbits >= 32 ? 0xFFFFFFFFu : ((1u << g32.sbits) - 1u);
+  g32.midbit = (e->kmer & 1) ? 1u << (g32.sbits - 2) : 0u;
   int64_t want_rec = (emit_all ? e->n : e->n / 4) + (int64_t) (grid + 16) * F_CH;
   for (int attempt = 0; attempt < 2; attempt++)
     { const unsigned maxc = (unsigned) ((want_rec + F_CH - 1) / F_CH);
@@ -706,10 +712,16 @@ static int fast_pass1(smg_engine *e, int emit_all, int want_fp, char *errbuf, si
       e->max_chunks = maxc;
       FastArgs a = make_fast(e);
       hipEventRecord(e->ev[2], e->stream);
+      if (narrow)
+        hipLaunchKernelGGL(kf_pass1_s, dim3(grid), dim3(S_TPB), 0, e->stream, a, g32, e->bstart, e->req,
+                           e->chunk_fill, maxc, emit_all, want_fp, e->partials, &e->ctrl->fast, ntiles);
+      else
+        {
 #define CALL(WW) hipLaunchKernelGGL(kf_pass1<WW>, dim3(grid), dim3(F_TPB), 0, e->stream, a, e->bstart, \
                    e->req, e->chunk_fill, maxc, emit_all, want_fp, e->partials, &e->ctrl->fast, ntiles)
-      DISPATCH_W3(e, CALL)
+          DISPATCH_W3(e, CALL)
 #undef CALL
+        }
       hipEventRecord(e->ev[3], e->stream);
       HIPCHK(hipGetLastError());
       if (want_fp)
