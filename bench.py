@@ -107,9 +107,11 @@ def main():
     torch.cuda.empty_cache()
 
     eng_stats = []
+    eng = sharded.TorchEngine(dev)        # device buffers are allocated once and reused by every step
 
     def step():
-        plot, st = sharded.hetmers_sharded(args.k, keys, cnt, symcheck=args.symcheck)
+        plot, st = sharded.hetmers_sharded(args.k, keys, cnt, symcheck=args.symcheck, eng=eng)
+        st.pop("engine", None)
         eng_stats.append(st)
         return plot
 

@@ -65,6 +65,12 @@ struct FastCtl                    // device control words of the fast path
 
 // ---- helpers -----------------------------------------------------------------------------------
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence:
+// it also waits for every outstanding global store of the wave (vmcnt(0)), which is not needed
+// where only LDS is shared and costs a full memory round trip per barrier.
+SMG_DEV void lds_barrier()
+{ asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int W> SMG_DEV Key<W> lds_key(const u64 *sk, int idx)
 { Key<W> x;
 #pragma unroll
@@ -307,6 +313,22 @@ kf_apply(FastArgs A, const u64 *__restrict__ req, const uint32_t *__restrict__ c
     }
 }
 
+// Requests sorted by k-mer (key-only records): neighbouring lanes look up neighbouring k-mers, so the
+// directory words, the k-mer lines and the P bytes they touch are shared -- the look-ups stream the
+// table once instead of fetching ~4 random 128-byte lines per request.
+template <int W> __global__ void __launch_bounds__(F_TPB)
+kf_apply_sorted(FastArgs A, const u64 *__restrict__ keys_sorted, int64_t nreq, FastCtl *__restrict__ ctl)
+{ const int64_t stride = (int64_t) gridDim.x * F_TPB;
+  for (int64_t r = (int64_t) blockIdx.x * F_TPB + threadIdx.x; r < nreq; r += stride)
+    { Key<W> y;
+#pragma unroll
+      for (int w = 0; w < W; w++) y.w[w] = keys_sorted[r * W + w];
+      const int64_t j = find_key<W>(A.keys, A.dir, y);
+      if (j < 0) { if (ctl->missing == 0) ctl->missing = 1; continue; }
+      A.pflag[j] = 1;
+    }
+}
+
 // exact symmetry proof of every local entry against the local table (single GPU)
 template <int W> __global__ void __launch_bounds__(F_TPB)
 kf_verify(FastArgs A, FastCtl *__restrict__ ctl)
@@ -339,59 +361,81 @@ far_partner(const FastArgs &A, int64_t i, int64_t &partner, unsigned &w2)
   big_block_scan<W>(A.keys, A.cnt, A.n, A.g, i, s_all, s_hi, partner, w2);
 }
 
-#define P2_VEC 16          // consecutive entries per thread per iteration: one 16-byte code load
+#define P2_VEC   16                       // consecutive entries per thread: one 16-byte code load
+#define P2_TILE  (P2_TPB * P2_VEC)        // 16384 entries per workgroup iteration
+#define P2_QCAP  P2_TILE                  // "far" codes can make every entry a candidate
 
+// Phase A: every thread inspects 16 code bytes and pushes its "unique pair, partner above"
+//          candidates into an LDS queue (wave-aggregated slot allocation).
+// Phase B: the queue is drained densely, one candidate per lane: the five dependent-free loads
+//          (partner code, two P flags, two counts) are issued together -- walking the candidates
+//          inside the 16-entry loop serialised one memory round trip per entry (r01_v2 profile).
 template <int W> __global__ void __launch_bounds__(P2_TPB)
 kf_pass2(FastArgs A, u64 *__restrict__ plot)
 { __shared__ unsigned tile[P2_CELLS];
+  __shared__ unsigned queue[P2_QCAP];     // local index (14 bits) | code << 16
+  __shared__ unsigned s_qn;
   const int t = threadIdx.x;
   for (int c = t; c < P2_CELLS; c += P2_TPB) tile[c] = 0;
-  __syncthreads();
+  if (t == 0) s_qn = 0;
+  lds_barrier();
 
-  // each thread streams 4 independent 16-byte code loads per iteration (memory-level parallelism)
-  const int64_t chunk = (int64_t) P2_TPB * P2_VEC * 4;
-  for (int64_t c0 = (int64_t) blockIdx.x * chunk; c0 < A.n; c0 += (int64_t) gridDim.x * chunk)
-    { uint4 cv[4];
+  const int64_t step = (int64_t) gridDim.x * P2_TILE;
+  int64_t c0 = (int64_t) blockIdx.x * P2_TILE;
+  uint4 cv = make_uint4(0, 0, 0, 0);
+  if (c0 + (int64_t) t * P2_VEC < A.n) cv = *reinterpret_cast<const uint4 *>(A.code + c0 + t * P2_VEC);
+  for (; c0 < A.n; c0 += step)
+    { // ---- phase A ----
+      const unsigned wv[4] = { cv.x, cv.y, cv.z, cv.w };
 #pragma unroll
-      for (int u = 0; u < 4; u++)
-        { const int64_t i0 = c0 + ((int64_t) u * P2_TPB + t) * P2_VEC;
-          cv[u] = make_uint4(0, 0, 0, 0);
-          if (i0 < A.n) cv[u] = *reinterpret_cast<const uint4 *>(A.code + i0);   // padded past n
-        }
+      for (int q = 0; q < 4; q++)
+        {
 #pragma unroll
-      for (int u = 0; u < 4; u++)
-        { const int64_t i0 = c0 + ((int64_t) u * P2_TPB + t) * P2_VEC;
-          const unsigned wv[4] = { cv[u].x, cv[u].y, cv[u].z, cv[u].w };
-#pragma unroll
-          for (int q = 0; q < 4; q++)
-            { const unsigned word = wv[q];
-              // candidates: "unique pair, partner above" = low 6 bits in 32..62
-              const unsigned cand = word & 0x20202020u;
-              if (cand == 0) continue;
-#pragma unroll
-              for (int bb = 0; bb < 4; bb++)
-                { const unsigned ci = (word >> (8 * bb)) & 0xFF;
-                  const unsigned lo6 = ci & 63;
-                  if (lo6 < 32 || lo6 == CODE_MULTI) continue;
-                  const int64_t i = i0 + 4 * q + bb;
-                  if (i >= A.n) continue;
-                  int64_t j;
-                  unsigned w2 = (ci & CODE_W2) != 0;
-                  if (lo6 == CODE_FAR)
-                    { far_partner<W>(A, i, j, w2);
-                      if (j <= i) continue;
-                    }
-                  else
-                    j = i + (int) lo6 - 31;
-                  const unsigned lj = A.code[j] & 63;
-                  if (lj == CODE_NONE || lj == CODE_MULTI) continue;  // partner has several pairs
-                  if (A.pflag[i] | A.pflag[j]) continue;              // a prefix-side pair exists too
-                  plot_bump(tile, plot, A.cnt[i], A.cnt[j], w2 ? 2u : 1u);
+          for (int bb = 0; bb < 4; bb++)
+            { const unsigned ci = (wv[q] >> (8 * bb)) & 0xFF;
+              const unsigned lo6 = ci & 63;
+              const int li = t * P2_VEC + 4 * q + bb;
+              const bool cand = lo6 >= 32 && lo6 != CODE_MULTI && c0 + li < A.n;
+              const u64 m = __ballot(cand);
+              if (m)
+                { const int lane = t & 63, lead = __ffsll((long long) m) - 1;
+                  unsigned qb = 0;
+                  if (lane == lead) qb = atomicAdd(&s_qn, (unsigned) __popcll(m));
+                  qb = __shfl(qb, lead, 64);
+                  if (cand) queue[qb + __popcll(m & ((1ull << lane) - 1))] = (unsigned) li | (ci << 16);
                 }
             }
         }
+      // prefetch the next tile's codes while the queue is drained
+      const int64_t nx = c0 + step + (int64_t) t * P2_VEC;
+      cv = make_uint4(0, 0, 0, 0);
+      if (nx < A.n) cv = *reinterpret_cast<const uint4 *>(A.code + nx);
+      lds_barrier();
+      // ---- phase B ----
+      const unsigned qn = s_qn;
+      for (unsigned q = t; q < qn; q += P2_TPB)
+        { const unsigned e = queue[q];
+          const unsigned ci = e >> 16, lo6 = ci & 63;
+          const int64_t i = c0 + (e & 0xFFFF);
+          int64_t j;
+          unsigned w2 = (ci & CODE_W2) != 0;
+          if (lo6 == CODE_FAR)
+            { far_partner<W>(A, i, j, w2);
+              if (j <= i) continue;
+            }
+          else
+            j = i + (int) lo6 - 31;
+          const unsigned cj = A.code[j], pi = A.pflag[i], pj = A.pflag[j];
+          const unsigned ni = A.cnt[i], nj = A.cnt[j];
+          const unsigned lj = cj & 63;
+          if (lj == CODE_NONE || lj == CODE_MULTI) continue;  // partner has several pairs
+          if (pi | pj) continue;                              // a prefix-side pair exists too
+          plot_bump(tile, plot, ni, nj, w2 ? 2u : 1u);
+        }
+      lds_barrier();
+      if (t == 0) s_qn = 0;
+      lds_barrier();
     }
-  __syncthreads();
 
   // flush the LDS tile: (sum,min) rows are laid out triangularly
   for (int c = t; c < P2_CELLS; c += P2_TPB)
@@ -440,21 +484,21 @@ template <int W> SMG_DEV int rank_of(const u64 *q, const u64 *__restrict__ split
 
 // counts[chunk][rank]
 template <int W> __global__ void __launch_bounds__(F_TPB)
-kf_route_count(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill,
+kf_route_count(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill, int rw,
                const u64 *__restrict__ split, int nranks, uint32_t *__restrict__ counts)
 { __shared__ unsigned cnt[16];
   if (threadIdx.x < 16) cnt[threadIdx.x] = 0;
   __syncthreads();
   const unsigned fill = chunk_fill[blockIdx.x];
   for (unsigned r = threadIdx.x; r < fill; r += F_TPB)
-    atomicAdd(&cnt[rank_of<W>(req + ((size_t) blockIdx.x * F_CH + r) * (W + 1), split, nranks)], 1u);
+    atomicAdd(&cnt[rank_of<W>(req + ((size_t) blockIdx.x * F_CH + r) * rw, split, nranks)], 1u);
   __syncthreads();
   if ((int) threadIdx.x < nranks) counts[(size_t) blockIdx.x * nranks + threadIdx.x] = cnt[threadIdx.x];
 }
 
 // offsets[chunk][rank] = first record slot of that (chunk, rank) group in the send buffer
 template <int W> __global__ void __launch_bounds__(F_TPB)
-kf_route_scatter(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill,
+kf_route_scatter(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill, int rw,
                  const u64 *__restrict__ split, int nranks, const u64 *__restrict__ offsets,
                  u64 *__restrict__ out)
 { __shared__ unsigned cur[16];
@@ -462,12 +506,11 @@ kf_route_scatter(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk
   __syncthreads();
   const unsigned fill = chunk_fill[blockIdx.x];
   for (unsigned r = threadIdx.x; r < fill; r += F_TPB)
-    { const u64 *q = req + ((size_t) blockIdx.x * F_CH + r) * (W + 1);
+    { const u64 *q = req + ((size_t) blockIdx.x * F_CH + r) * rw;
       const int d = rank_of<W>(q, split, nranks);
       const u64 slot = offsets[(size_t) blockIdx.x * nranks + d] + atomicAdd(&cur[d], 1u);
-      u64 *o = out + slot * (W + 1);
-#pragma unroll
-      for (int w = 0; w <= W; w++) o[w] = q[w];
+      u64 *o = out + slot * rw;
+      for (int w = 0; w < rw; w++) o[w] = q[w];
     }
 }
 
@@ -501,12 +544,9 @@ struct Geo32
   unsigned midbit;       // the `t` bit of a pair at the self-mirrored position (0 when k is even)
 };
 
-SMG_DEV void lds_barrier()             // workgroup barrier that orders LDS traffic only
-{ asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 __global__ void __launch_bounds__(S_TPB)
 kf_pass1_s(FastArgs A, Geo32 G, uint32_t *__restrict__ bstart, u64 *__restrict__ req,
-           uint32_t *__restrict__ chunk_fill, unsigned max_chunks, int emit_all, int want_fp,
+           uint32_t *__restrict__ chunk_fill, unsigned max_chunks, int emit_all, int rw, int want_fp,
            u64 *__restrict__ partials, FastCtl *__restrict__ ctl, int64_t ntiles)
 { __shared__ u64      ent[S_SPAN];
   __shared__ uint16_t scnt[S_SPAN];
@@ -686,8 +726,11 @@ kf_pass1_s(FastArgs A, Geo32 G, uint32_t *__restrict__ bstart, u64 *__restrict__
                   qb = __shfl(qb, lead, 64);
                   if (emit)
                     { const unsigned q = qb + __popcll(em & ((1ull << lane) - 1));
-                      sq[2 * q] = rc.w[0];
-                      sq[2 * q + 1] = (u64) cc[r] | ((u64) (s_hi > 0) << 16);
+                      if (rw == 1) sq[q] = rc.w[0];
+                      else
+                        { sq[2 * q] = rc.w[0];
+                          sq[2 * q + 1] = (u64) cc[r] | ((u64) (s_hi > 0) << 16);
+                        }
                     }
                 }
               if (own && want_fp) fp_accumulate<1>(kx, rc, cc[r], f0, f1);
@@ -696,11 +739,16 @@ kf_pass1_s(FastArgs A, Geo32 G, uint32_t *__restrict__ bstart, u64 *__restrict__
       lds_barrier();
 
       // ---- phase 3: flush the request queue into this workgroup's chunk --------------------------
+      // (a chunk that cannot take the batch is closed: its tail is filled with all-ones records so
+      //  that the chunk array can be radix sorted as a whole)
       const unsigned qn = s_qn;
       if (qn > 0)
-        { if (t == 0)
-            { if (s_chunk == F_NOCHUNK || s_used + qn > F_CH)
-                { if (s_chunk != F_NOCHUNK && s_chunk < max_chunks) chunk_fill[s_chunk] = s_used;
+        { const unsigned old_chunk = s_chunk, old_used = s_used;
+          const bool fresh = old_chunk == F_NOCHUNK || old_used + qn > F_CH;
+          lds_barrier();
+          if (t == 0)
+            { if (fresh)
+                { if (old_chunk != F_NOCHUNK && old_chunk < max_chunks) chunk_fill[old_chunk] = old_used;
                   s_chunk = atomicAdd(&ctl->n_chunks, 1u);
                   s_used = 0;
                 }
@@ -708,15 +756,23 @@ kf_pass1_s(FastArgs A, Geo32 G, uint32_t *__restrict__ bstart, u64 *__restrict__
               s_used += qn;
               s_total += qn;
             }
+          if (fresh && old_chunk != F_NOCHUNK && old_chunk < max_chunks)
+            { u64 *o = req + ((u64) old_chunk * F_CH) * rw;
+              for (unsigned e = old_used * rw + t; e < (unsigned) F_CH * rw; e += S_TPB) o[e] = ~0ull;
+            }
           lds_barrier();
           if (s_chunk < max_chunks)
-            { u64 *o = req + s_base * 2;
-              for (unsigned e = t; e < qn * 2; e += S_TPB) o[e] = sq[e];
+            { u64 *o = req + s_base * rw;
+              for (unsigned e = t; e < qn * rw; e += S_TPB) o[e] = sq[e];
             }
           lds_barrier();
         }
     }
 
+  if (s_chunk != F_NOCHUNK && s_chunk < max_chunks)
+    { u64 *o = req + ((u64) s_chunk * F_CH) * rw;
+      for (unsigned e = s_used * rw + t; e < (unsigned) F_CH * rw; e += S_TPB) o[e] = ~0ull;
+    }
   if (t == 0)
     { if (s_chunk != F_NOCHUNK && s_chunk < max_chunks) chunk_fill[s_chunk] = s_used;
       if (s_total) atomicAdd(&ctl->nreq, s_total);

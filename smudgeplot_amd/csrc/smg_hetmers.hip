@@ -30,6 +30,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <new>
+#include <rocprim/rocprim.hpp>
 
 #include "smg_hetmers.h"
 #include "smg_device.hpp"
@@ -338,6 +339,9 @@ struct smg_engine
   uint8_t     *pflag;  int64_t pflag_cap;
   uint32_t    *bstart; int64_t bstart_cap;
   u64         *req;    int64_t req_cap;      // bytes
+  u64         *req2;   int64_t req2_cap;     // radix sort output
+  void        *sort_tmp; int64_t sort_tmp_cap;
+  int          rw;                           // 64-bit words per request record
   uint32_t    *chunk_fill; int64_t chunk_cap; // bytes
   unsigned     max_chunks;
   uint32_t    *route_cnt;  int64_t route_cnt_cap;
@@ -414,7 +418,7 @@ extern "C" void smg_engine_destroy(smg_engine *e)
   hipSetDevice(e->device);
   hipStreamSynchronize(e->stream);
   hipFree(e->own_keys); hipFree(e->own_cnt); hipFree(e->deg); hipFree(e->pflag); hipFree(e->bstart);
-  hipFree(e->req); hipFree(e->chunk_fill); hipFree(e->route_cnt); hipFree(e->route_off);
+  hipFree(e->req); hipFree(e->req2); hipFree(e->sort_tmp); hipFree(e->chunk_fill); hipFree(e->route_cnt); hipFree(e->route_off);
   hipFree(e->partials); hipFree(e->ctrl); hipFree(e->d_split);
   hipHostFree(e->h_ctrl); hipHostFree(e->h_partials);
   for (int i = 0; i < 8; i++) hipEventDestroy(e->ev[i]);
@@ -680,8 +684,10 @@ static FastArgs make_fast(smg_engine *e)
   return a;
 }
 
-static int fast_pass1(smg_engine *e, int emit_all, int want_fp, char *errbuf, size_t errlen)
+static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, char *errbuf, size_t errlen)
 { int rc;
+  // record = the complement k-mer (W words) [+ one word: count | has-hi-pair << 16]
+  e->rw = e->W + ((with_meta || e->W > 1) ? 1 : 0);
   HIPCHK(hipMemsetAsync(e->ctrl, 0, sizeof(Ctrl), e->stream));
   set_geo(e);
   e->fast = true;
@@ -707,14 +713,14 @@ static int fast_pass1(smg_engine *e, int emit_all, int want_fp, char *errbuf, si
   int64_t want_rec = (emit_all ? e->n : e->n / 4) + (int64_t) (grid + 16) * F_CH;
   for (int attempt = 0; attempt < 2; attempt++)
     { const unsigned maxc = (unsigned) ((want_rec + F_CH - 1) / F_CH);
-      if ((rc = grow(&e->req, &e->req_cap, (int64_t) maxc * F_CH * (int64_t) sizeof(u64) * (e->W + 1), errbuf, errlen))) return rc;
+      if ((rc = grow(&e->req, &e->req_cap, (int64_t) maxc * F_CH * (int64_t) sizeof(u64) * e->rw, errbuf, errlen))) return rc;
       if ((rc = grow(&e->chunk_fill, &e->chunk_cap, (int64_t) maxc * 4 + 4, errbuf, errlen))) return rc;
       e->max_chunks = maxc;
       FastArgs a = make_fast(e);
       hipEventRecord(e->ev[2], e->stream);
       if (narrow)
         hipLaunchKernelGGL(kf_pass1_s, dim3(grid), dim3(S_TPB), 0, e->stream, a, g32, e->bstart, e->req,
-                           e->chunk_fill, maxc, emit_all, want_fp, e->partials, &e->ctrl->fast, ntiles);
+                           e->chunk_fill, maxc, emit_all, e->rw, want_fp, e->partials, &e->ctrl->fast, ntiles);
       else
         {
 #define CALL(WW) hipLaunchKernelGGL(kf_pass1<WW>, dim3(grid), dim3(F_TPB), 0, e->stream, a, e->bstart, \
@@ -746,11 +752,36 @@ static int fast_pass1(smg_engine *e, int emit_all, int want_fp, char *errbuf, si
   return SMG_OK;
 }
 
+// key-only records of one-word k-mers: radix sort on the leading 32 bits, then look up in order
+static int apply_sorted(smg_engine *e, const u64 *keys_in, int64_t nsort, int64_t nvalid,
+                        char *errbuf, size_t errlen)
+{ int rc;
+  if (nsort <= 0 || nvalid <= 0) return SMG_OK;
+  if ((rc = grow(&e->req2, &e->req2_cap, nsort * (int64_t) sizeof(u64), errbuf, errlen))) return rc;
+  size_t tmp = 0;
+  HIPCHK(rocprim::radix_sort_keys(nullptr, tmp, (u64 *) keys_in, e->req2, (size_t) nsort, 32u, 64u, e->stream));
+  if ((rc = grow((char **) &e->sort_tmp, &e->sort_tmp_cap, (int64_t) tmp + 16, errbuf, errlen))) return rc;
+  HIPCHK(rocprim::radix_sort_keys(e->sort_tmp, tmp, (u64 *) keys_in, e->req2, (size_t) nsort, 32u, 64u, e->stream));
+  FastArgs a = make_fast(e);
+  int64_t nb = (nvalid + F_TPB - 1) / F_TPB;
+  if (nb > 16384) nb = 16384;
+  hipLaunchKernelGGL(kf_apply_sorted<1>, dim3((unsigned) nb), dim3(F_TPB), 0, e->stream, a, e->req2, nvalid, &e->ctrl->fast);
+  return SMG_OK;
+}
+
 static int fast_apply(smg_engine *e, const u64 *flat, int64_t nflat, int check_count, int64_t *missing,
                       char *errbuf, size_t errlen)
 { FastArgs a = make_fast(e);
+  int rc;
   hipEventRecord(e->ev[4], e->stream);
-  if (!flat && e->n_chunks > 0)
+  if (e->W == 1 && e->rw == 1)
+    { // all-ones fillers of the chunk tails sort behind every real request (ties are harmless:
+      // the first nreq sorted records are exactly the real ones)
+      if (!flat) rc = apply_sorted(e, e->req, (int64_t) e->n_chunks * F_CH, e->st.nrequests, errbuf, errlen);
+      else       rc = apply_sorted(e, flat, nflat, nflat, errbuf, errlen);
+      if (rc) return rc;
+    }
+  else if (!flat && e->n_chunks > 0)
     {
 #define CALL(WW) hipLaunchKernelGGL(kf_apply<WW>, dim3(e->n_chunks), dim3(F_TPB), 0, e->stream, a, e->req, \
                    e->chunk_fill, (int64_t) 0, check_count, &e->ctrl->fast)
@@ -767,7 +798,7 @@ static int fast_apply(smg_engine *e, const u64 *flat, int64_t nflat, int check_c
     }
   hipEventRecord(e->ev[5], e->stream);
   HIPCHK(hipGetLastError());
-  int rc = read_ctrl(e, errbuf, errlen);
+  rc = read_ctrl(e, errbuf, errlen);
   if (rc) return rc;
   float ms = 0; hipEventElapsedTime(&ms, e->ev[4], e->ev[5]);
   e->st.ms_rclookup += ms;
@@ -826,11 +857,11 @@ extern "C" int smg_engine_pass1(smg_engine *e, int symcheck, char *errbuf, size_
 { NEED_FAST(e)
   HIPCHK(hipSetDevice(e->device));
   e->st.ms_rclookup = 0;
-  return fast_pass1(e, symcheck == SMG_SYM_EXACT, symcheck == SMG_SYM_HASH, errbuf, errlen);
+  return fast_pass1(e, symcheck == SMG_SYM_EXACT, symcheck == SMG_SYM_EXACT, symcheck == SMG_SYM_HASH, errbuf, errlen);
 }
 
 extern "C" int64_t smg_engine_nreq(smg_engine *e) { return e ? e->st.nrequests : 0; }
-extern "C" int smg_engine_record_words(smg_engine *e) { return e ? e->W + 1 : 0; }
+extern "C" int smg_engine_record_words(smg_engine *e) { return e ? e->rw : 0; }
 
 extern "C" int smg_engine_apply(smg_engine *e, const uint64_t *d_recv, int64_t nrecv,
                                 int64_t *missing, char *errbuf, size_t errlen)
@@ -873,7 +904,7 @@ extern "C" int smg_engine_route(smg_engine *e, const uint64_t *splitters, int nr
   if ((rc = grow(&e->route_cnt, &e->route_cnt_cap, (int64_t) nc * nranks * 4, errbuf, errlen))) return rc;
   if ((rc = grow(&e->route_off, &e->route_off_cap, (int64_t) nc * nranks * 8, errbuf, errlen))) return rc;
 #define CALL(WW) hipLaunchKernelGGL(kf_route_count<WW>, dim3(nc), dim3(F_TPB), 0, e->stream, e->req, \
-                   e->chunk_fill, e->d_split, nranks, e->route_cnt)
+                   e->chunk_fill, e->rw, e->d_split, nranks, e->route_cnt)
   DISPATCH_W3(e, CALL)
 #undef CALL
   uint32_t *hc = (uint32_t *) malloc(sizeof(uint32_t) * (size_t) nc * nranks);
@@ -893,7 +924,7 @@ extern "C" int smg_engine_route(smg_engine *e, const uint64_t *splitters, int nr
   if (he == hipSuccess)
     {
 #define CALL(WW) hipLaunchKernelGGL(kf_route_scatter<WW>, dim3(nc), dim3(F_TPB), 0, e->stream, e->req, \
-                   e->chunk_fill, e->d_split, nranks, e->route_off, (u64 *) d_send)
+                   e->chunk_fill, e->rw, e->d_split, nranks, e->route_off, (u64 *) d_send)
       DISPATCH_W3(e, CALL)
 #undef CALL
       he = hipStreamSynchronize(e->stream);
@@ -927,7 +958,7 @@ extern "C" int smg_engine_run(smg_engine *e, int symcheck, int64_t *d_plot, smg_
   e->st.ms_pass1 = e->st.ms_rclookup = e->st.ms_pass2 = 0;
   bool symmetric = false;
   if (symcheck != SMG_SYM_NONE && e->kmer <= FAST_MAX_K)
-    { rc = fast_pass1(e, 0, symcheck == SMG_SYM_HASH, errbuf, errlen);
+    { rc = fast_pass1(e, 0, 0, symcheck == SMG_SYM_HASH, errbuf, errlen);
       if (rc) return rc;
       int64_t missing = 0;
       // hash mode: the fingerprint covers (k-mer, count), the per-request count check is redundant

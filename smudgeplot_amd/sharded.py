@@ -104,12 +104,14 @@ def fix_cut(keys_u64: np.ndarray, words: int, k: int, cut: int) -> int:
 
 
 def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: str = "hash",
-                    engine_factory=TorchEngine, group=None):
+                    engine_factory=TorchEngine, group=None, eng=None):
     """Run hetmers on this rank's shard; returns (plot int64[1001*501] on the shard's device,
     summed over all ranks, and a stats dict).  Collective: every rank must call it.
 
     keys   : int64 tensor viewing the shard's uint64 k-mer words (n * ceil(k/32)), sorted
     counts : int16 tensor viewing the shard's uint16 counts (n)
+    eng    : an engine from a previous call on the same shard (its device buffers are reused;
+             allocation is set-up cost, not part of a step)
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -117,7 +119,8 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
     words = (k + 31) // 32
     n = counts.numel()
 
-    eng = engine_factory(dev)
+    if eng is None:
+        eng = engine_factory(dev)
     eng.bind(k, keys, counts)
 
     # splitters = first k-mer of ranks 1..world-1 (an empty shard inherits its successor's)
@@ -178,5 +181,5 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
     if world > 1:
         dist.all_reduce(plot, op=dist.ReduceOp.SUM, group=group)
     st = eng.stats()
-    st.update(rank=rank, world=world, shard_nels=n, sent=nreq, received=nrecv)
+    st.update(rank=rank, world=world, shard_nels=n, sent=nreq, received=nrecv, engine=eng)
     return plot, st
