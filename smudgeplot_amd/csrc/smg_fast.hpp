@@ -313,6 +313,16 @@ kf_apply(FastArgs A, const u64 *__restrict__ req, const uint32_t *__restrict__ c
     }
 }
 
+// chunk list -> dense array: dense[off[c] + r] = chunk c, record r   (off = exclusive scan of fills)
+__global__ void __launch_bounds__(F_TPB)
+kf_compact(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill,
+           const uint32_t *__restrict__ chunk_off, int rw, u64 *__restrict__ dense)
+{ const unsigned fill = chunk_fill[blockIdx.x] * rw;
+  const u64 *src = req + (size_t) blockIdx.x * F_CH * rw;
+  u64 *dst = dense + (size_t) chunk_off[blockIdx.x] * rw;
+  for (unsigned e = threadIdx.x; e < fill; e += F_TPB) dst[e] = src[e];
+}
+
 // Requests sorted by k-mer (key-only records): neighbouring lanes look up neighbouring k-mers, so the
 // directory words, the k-mer lines and the P bytes they touch are shared -- the look-ups stream the
 // table once instead of fetching ~4 random 128-byte lines per request.
@@ -739,8 +749,8 @@ kf_pass1_s(FastArgs A, Geo32 G, uint32_t *__restrict__ bstart, u64 *__restrict__
       lds_barrier();
 
       // ---- phase 3: flush the request queue into this workgroup's chunk --------------------------
-      // (a chunk that cannot take the batch is closed: its tail is filled with all-ones records so
-      //  that the chunk array can be radix sorted as a whole)
+      // (a chunk that cannot take the batch is closed with its fill count; kf_compact squeezes the
+      //  holes out before the requests are sorted)
       const unsigned qn = s_qn;
       if (qn > 0)
         { const unsigned old_chunk = s_chunk, old_used = s_used;
@@ -756,10 +766,6 @@ kf_pass1_s(FastArgs A, Geo32 G, uint32_t *__restrict__ bstart, u64 *__restrict__
               s_used += qn;
               s_total += qn;
             }
-          if (fresh && old_chunk != F_NOCHUNK && old_chunk < max_chunks)
-            { u64 *o = req + ((u64) old_chunk * F_CH) * rw;
-              for (unsigned e = old_used * rw + t; e < (unsigned) F_CH * rw; e += S_TPB) o[e] = ~0ull;
-            }
           lds_barrier();
           if (s_chunk < max_chunks)
             { u64 *o = req + s_base * rw;
@@ -769,10 +775,6 @@ kf_pass1_s(FastArgs A, Geo32 G, uint32_t *__restrict__ bstart, u64 *__restrict__
         }
     }
 
-  if (s_chunk != F_NOCHUNK && s_chunk < max_chunks)
-    { u64 *o = req + ((u64) s_chunk * F_CH) * rw;
-      for (unsigned e = s_used * rw + t; e < (unsigned) F_CH * rw; e += S_TPB) o[e] = ~0ull;
-    }
   if (t == 0)
     { if (s_chunk != F_NOCHUNK && s_chunk < max_chunks) chunk_fill[s_chunk] = s_used;
       if (s_total) atomicAdd(&ctl->nreq, s_total);

@@ -341,6 +341,8 @@ struct smg_engine
   u64         *req;    int64_t req_cap;      // bytes
   u64         *req2;   int64_t req2_cap;     // radix sort output
   void        *sort_tmp; int64_t sort_tmp_cap;
+  u64         *dense;  int64_t dense_cap;    // compacted requests
+  uint32_t    *chunk_off; int64_t chunk_off_cap;
   int          rw;                           // 64-bit words per request record
   uint32_t    *chunk_fill; int64_t chunk_cap; // bytes
   unsigned     max_chunks;
@@ -418,7 +420,7 @@ extern "C" void smg_engine_destroy(smg_engine *e)
   hipSetDevice(e->device);
   hipStreamSynchronize(e->stream);
   hipFree(e->own_keys); hipFree(e->own_cnt); hipFree(e->deg); hipFree(e->pflag); hipFree(e->bstart);
-  hipFree(e->req); hipFree(e->req2); hipFree(e->sort_tmp); hipFree(e->chunk_fill); hipFree(e->route_cnt); hipFree(e->route_off);
+  hipFree(e->req); hipFree(e->req2); hipFree(e->sort_tmp); hipFree(e->dense); hipFree(e->chunk_off); hipFree(e->chunk_fill); hipFree(e->route_cnt); hipFree(e->route_off);
   hipFree(e->partials); hipFree(e->ctrl); hipFree(e->d_split);
   hipHostFree(e->h_ctrl); hipHostFree(e->h_partials);
   for (int i = 0; i < 8; i++) hipEventDestroy(e->ev[i]);
@@ -775,10 +777,25 @@ static int fast_apply(smg_engine *e, const u64 *flat, int64_t nflat, int check_c
   int rc;
   hipEventRecord(e->ev[4], e->stream);
   if (e->W == 1 && e->rw == 1)
-    { // all-ones fillers of the chunk tails sort behind every real request (ties are harmless:
-      // the first nreq sorted records are exactly the real ones)
-      if (!flat) rc = apply_sorted(e, e->req, (int64_t) e->n_chunks * F_CH, e->st.nrequests, errbuf, errlen);
-      else       rc = apply_sorted(e, flat, nflat, nflat, errbuf, errlen);
+    { if (!flat)
+        { // squeeze the per-workgroup chunks into one dense array, then sort + look up in order
+          const int64_t nreq = e->st.nrequests;
+          if (nreq > 0 && e->n_chunks > 0)
+            { if ((rc = grow(&e->dense, &e->dense_cap, nreq * (int64_t) sizeof(u64), errbuf, errlen))) return rc;
+              if ((rc = grow(&e->chunk_off, &e->chunk_off_cap, (int64_t) e->n_chunks * 4 + 4, errbuf, errlen))) return rc;
+              size_t tmp = 0;
+              HIPCHK(rocprim::exclusive_scan(nullptr, tmp, e->chunk_fill, e->chunk_off, 0u, (size_t) e->n_chunks,
+                                             rocprim::plus<uint32_t>(), e->stream));
+              if ((rc = grow((char **) &e->sort_tmp, &e->sort_tmp_cap, (int64_t) tmp + 16, errbuf, errlen))) return rc;
+              HIPCHK(rocprim::exclusive_scan(e->sort_tmp, tmp, e->chunk_fill, e->chunk_off, 0u, (size_t) e->n_chunks,
+                                             rocprim::plus<uint32_t>(), e->stream));
+              hipLaunchKernelGGL(kf_compact, dim3(e->n_chunks), dim3(F_TPB), 0, e->stream, e->req, e->chunk_fill,
+                                 e->chunk_off, 1, e->dense);
+              rc = apply_sorted(e, e->dense, nreq, nreq, errbuf, errlen);
+            }
+          else rc = SMG_OK;
+        }
+      else rc = apply_sorted(e, flat, nflat, nflat, errbuf, errlen);
       if (rc) return rc;
     }
   else if (!flat && e->n_chunks > 0)
