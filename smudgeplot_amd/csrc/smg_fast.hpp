@@ -323,6 +323,25 @@ kf_compact(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill,
   for (unsigned e = threadIdx.x; e < fill; e += F_TPB) dst[e] = src[e];
 }
 
+// self-check of a sort (debug / tests): order on the leading 32 bits + order-free checksums
+__global__ void __launch_bounds__(F_TPB)
+kf_check_sorted(const u64 *__restrict__ before, const u64 *__restrict__ after, int64_t n,
+                u64 *__restrict__ out /* [0]=violations [1]=sum before [2]=sum after [3]=xor both */)
+{ const int64_t stride = (int64_t) gridDim.x * F_TPB;
+  u64 bad = 0, sb = 0, sa = 0, x = 0;
+  for (int64_t i = (int64_t) blockIdx.x * F_TPB + threadIdx.x; i < n; i += stride)
+    { const u64 a = after[i], b = before[i];
+      if (i > 0 && (after[i - 1] >> 32) > (a >> 32)) bad++;
+      sb += mix64(b); sa += mix64(a); x ^= a ^ b;
+    }
+  bad = wave_sum_u64(bad); sb = wave_sum_u64(sb); sa = wave_sum_u64(sa);
+  for (int o = 32; o > 0; o >>= 1) x ^= __shfl_xor(x, o, 64);
+  if ((threadIdx.x & 63) == 0)
+    { if (bad) atomicAdd(out, bad);
+      atomicAdd(out + 1, sb); atomicAdd(out + 2, sa); atomicXor(out + 3, x);
+    }
+}
+
 // Requests sorted by k-mer (key-only records): neighbouring lanes look up neighbouring k-mers, so the
 // directory words, the k-mer lines and the P bytes they touch are shared -- the look-ups stream the
 // table once instead of fetching ~4 random 128-byte lines per request.

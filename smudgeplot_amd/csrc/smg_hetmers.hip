@@ -754,20 +754,43 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
   return SMG_OK;
 }
 
-// key-only records of one-word k-mers: radix sort on the leading 32 bits, then look up in order
-static int apply_sorted(smg_engine *e, const u64 *keys_in, int64_t nsort, int64_t nvalid,
-                        char *errbuf, size_t errlen)
+// key-only records of one-word k-mers: radix sort on the leading 32 bits, then look up in order.
+// rocPRIM's mid-size (merge sort) variant returned garbage with a partial bit range on gfx950 /
+// ROCm 7.2, so Onesweep is forced (MergeSortLimit = 0) and small batches are not sorted at all
+// (their look-ups are too few to matter).  SMG_VERIFY_SORT=1 checks every sort (order + checksums).
+#define SORT_MIN 4096
+typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                   rocprim::default_config, 0> smg_sort_config;
+
+static int apply_sorted(smg_engine *e, const u64 *keys_in, int64_t nsort, char *errbuf, size_t errlen)
 { int rc;
-  if (nsort <= 0 || nvalid <= 0) return SMG_OK;
-  if ((rc = grow(&e->req2, &e->req2_cap, nsort * (int64_t) sizeof(u64), errbuf, errlen))) return rc;
-  size_t tmp = 0;
-  HIPCHK(rocprim::radix_sort_keys(nullptr, tmp, (u64 *) keys_in, e->req2, (size_t) nsort, 32u, 64u, e->stream));
-  if ((rc = grow((char **) &e->sort_tmp, &e->sort_tmp_cap, (int64_t) tmp + 16, errbuf, errlen))) return rc;
-  HIPCHK(rocprim::radix_sort_keys(e->sort_tmp, tmp, (u64 *) keys_in, e->req2, (size_t) nsort, 32u, 64u, e->stream));
+  if (nsort <= 0) return SMG_OK;
   FastArgs a = make_fast(e);
-  int64_t nb = (nvalid + F_TPB - 1) / F_TPB;
+  int64_t nb = (nsort + F_TPB - 1) / F_TPB;
   if (nb > 16384) nb = 16384;
-  hipLaunchKernelGGL(kf_apply_sorted<1>, dim3((unsigned) nb), dim3(F_TPB), 0, e->stream, a, e->req2, nvalid, &e->ctrl->fast);
+  const u64 *src = keys_in;
+  if (nsort >= SORT_MIN)
+    { if ((rc = grow(&e->req2, &e->req2_cap, nsort * (int64_t) sizeof(u64), errbuf, errlen))) return rc;
+      size_t tmp = 0;
+      HIPCHK(rocprim::radix_sort_keys<smg_sort_config>(nullptr, tmp, (u64 *) keys_in, e->req2, (size_t) nsort,
+                                                       32u, 64u, e->stream));
+      if ((rc = grow((char **) &e->sort_tmp, &e->sort_tmp_cap, (int64_t) tmp + 16, errbuf, errlen))) return rc;
+      HIPCHK(rocprim::radix_sort_keys<smg_sort_config>(e->sort_tmp, tmp, (u64 *) keys_in, e->req2, (size_t) nsort,
+                                                       32u, 64u, e->stream));
+      src = e->req2;
+      if (getenv("SMG_VERIFY_SORT"))
+        { u64 *d_chk = NULL, h[4];
+          HIPCHK(hipMalloc(&d_chk, 32));
+          HIPCHK(hipMemsetAsync(d_chk, 0, 32, e->stream));
+          hipLaunchKernelGGL(kf_check_sorted, dim3((unsigned) nb), dim3(F_TPB), 0, e->stream, keys_in, e->req2, nsort, d_chk);
+          HIPCHK(hipMemcpyAsync(h, d_chk, 32, hipMemcpyDeviceToHost, e->stream));
+          HIPCHK(hipStreamSynchronize(e->stream));
+          hipFree(d_chk);
+          if (h[0] || h[1] != h[2] || h[3])
+            return fail(errbuf, errlen, SMG_ENODEV, "request sort self-check failed (rocPRIM radix sort)%s");
+        }
+    }
+  hipLaunchKernelGGL(kf_apply_sorted<1>, dim3((unsigned) nb), dim3(F_TPB), 0, e->stream, a, src, nsort, &e->ctrl->fast);
   return SMG_OK;
 }
 
@@ -791,11 +814,11 @@ static int fast_apply(smg_engine *e, const u64 *flat, int64_t nflat, int check_c
                                              rocprim::plus<uint32_t>(), e->stream));
               hipLaunchKernelGGL(kf_compact, dim3(e->n_chunks), dim3(F_TPB), 0, e->stream, e->req, e->chunk_fill,
                                  e->chunk_off, 1, e->dense);
-              rc = apply_sorted(e, e->dense, nreq, nreq, errbuf, errlen);
+              rc = apply_sorted(e, e->dense, nreq, errbuf, errlen);
             }
           else rc = SMG_OK;
         }
-      else rc = apply_sorted(e, flat, nflat, nflat, errbuf, errlen);
+      else rc = apply_sorted(e, flat, nflat, errbuf, errlen);
       if (rc) return rc;
     }
   else if (!flat && e->n_chunks > 0)

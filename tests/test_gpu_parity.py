@@ -151,6 +151,38 @@ def test_medium_table_vs_c_oracle(tmp_path):
     assert (tmp_path / "gpuh.smu").read_text() == (tmp_path / "orc.smu").read_text()
 
 
+def test_large_table_sorted_lookup_path_vs_reference_binary(tmp_path, monkeypatch):
+    """~7.6e6 entries: the request list is long enough for the radix-sorted look-up path; compare the
+    engine with the REFERENCE binary (oracle/_ref, prebuilt) on the same table, and let the engine
+    self-check every sort (SMG_VERIFY_SORT)."""
+    import torch
+    from conftest import REF_BIN
+    from smudgeplot_amd import synth_device
+    if not os.path.exists(REF_BIN):
+        pytest.skip("prebuilt reference binary not present")
+    monkeypatch.setenv("SMG_VERIFY_SORT", "1")
+    k = 31
+    dev = torch.device("cuda:0")
+    tk, tc = synth_device.diploid_table(3_000_000, k=k, het=0.01, cov=50.0, L=10, seed=3, device=dev)
+    keys = tk.cpu().numpy().view(np.uint64)
+    cnt = tc.cpu().numpy().view(np.uint16)
+    plot = torch.zeros(engine.PLOT_CELLS, dtype=torch.int64, device=dev)
+    e = engine.Engine(0)
+    e.bind(k, len(cnt), tk.data_ptr(), tc.data_ptr())
+    texts = {}
+    for mode in ("hash", "exact"):
+        st = e.run(plot.data_ptr(), mode)
+        torch.cuda.synchronize()
+        assert st["path"] == 1 and st["nrequests"] > 100000
+        texts[mode] = engine.smu_text(plot.cpu().numpy().reshape(1001, 501))
+    assert texts["hash"] == texts["exact"]
+    synth.write_u64_table(str(tmp_path / "t"), keys, cnt, k, ibyte=2, nparts=3)
+    r = subprocess.run([REF_BIN, "-e10", f"-T{min(16, os.cpu_count() or 1)}", "-oref", "t.ktab"], cwd=tmp_path,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "ref.smu").read_text() == texts["hash"]
+
+
 def test_engine_object_with_torch_tensors_and_manual_two_shard_exchange():
     """phase-level API on device tensors; then the same table split into two prefix shards on
     one GPU with the request exchange done by hand (what sharded.py does with all_to_all)"""
