@@ -40,6 +40,7 @@
 #define CODE_MULTI  63
 #define CODE_FAR    62
 #define CODE_W2     64
+#define CODE_DEFER  0xFF                  // placeholder until kf_bigfix has redone the entry
 
 #define P2_TPB   1024
 #define P2_SMAX  256                  // LDS plot tile covers sums < P2_SMAX
@@ -53,6 +54,7 @@ struct FastArgs
   Dir             dir;           // bstart written by pass 1, read by apply
   uint8_t        *code;
   uint8_t        *pflag;         // pflag[j] != 0 : entry j has a prefix-side pair
+  int             dbg;           // SMG_DBG_SKIP bits (timing experiments only; results invalid)
 };
 
 struct FastCtl                    // device control words of the fast path
@@ -61,6 +63,8 @@ struct FastCtl                    // device control words of the fast path
   unsigned unsorted;             // order violation seen
   unsigned pad;
   u64      nreq;                 // requests written
+  unsigned nbig;                 // entries deferred to kf_bigfix (window block longer than the halo)
+  unsigned pad2;
 };
 
 // ---- helpers -----------------------------------------------------------------------------------
@@ -83,6 +87,39 @@ template <int W> __device__ __noinline__ void
 big_block_scan(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, int64_t n,
                const Geo g, int64_t i, unsigned &s_all, unsigned &s_hi, int64_t &partner,
                unsigned &w2)
+{ const Key<W> x = load_key<W>(keys, i);
+  const unsigned c = cnt[i];
+  int64_t a = 0, b = i;
+  while (a < b)
+    { const int64_t m = (a + b) >> 1;
+      if (same_block<W>(x, load_key<W>(keys, m), g)) b = m; else a = m + 1;
+    }
+  const int64_t blo = a;
+  a = i + 1; b = n;
+  while (a < b)
+    { const int64_t m = (a + b) >> 1;
+      if (!same_block<W>(x, load_key<W>(keys, m), g)) b = m; else a = m + 1;
+    }
+  const int64_t bhi = a;
+  s_all = 0; s_hi = 0; partner = -1; w2 = 0;
+  for (int p = g.p0; p < g.k; p++)
+    for (int d = 1; d <= 3; d++)
+      { const Key<W> y = flip_base<W>(x, p, d);
+        const int64_t j = lower_bound_key<W>(keys, blo, bhi, y);
+        if (j < bhi && key_eq<W>(load_key<W>(keys, j), y) && c + (unsigned) cnt[j] <= SMG_SMAX)
+          { const unsigned hi = (p != g.k - 1 - p);
+            if (s_all == 0) { partner = j; w2 = hi; }
+            s_all++; s_hi += hi;
+          }
+      }
+}
+
+// same walk, force-inlined: inside kf_pass1_s a real call would spill live registers to scratch,
+// and every scratch reload waits on vmcnt -- which also drains the in-flight tile prefetch
+template <int W> SMG_DEV void
+big_block_scan_inl(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, int64_t n,
+                   const Geo g, int64_t i, unsigned &s_all, unsigned &s_hi, int64_t &partner,
+                   unsigned &w2)
 { const Key<W> x = load_key<W>(keys, i);
   const unsigned c = cnt[i];
   int64_t a = 0, b = i;
@@ -573,63 +610,64 @@ struct Geo32
   unsigned midbit;       // the `t` bit of a pair at the self-mirrored position (0 when k is even)
 };
 
-__global__ void __launch_bounds__(S_TPB)
+template <int RW> __global__ void __launch_bounds__(S_TPB)
 kf_pass1_s(FastArgs A, Geo32 G, uint32_t *__restrict__ bstart, u64 *__restrict__ req,
-           uint32_t *__restrict__ chunk_fill, unsigned max_chunks, int emit_all, int rw, int want_fp,
+           uint32_t *__restrict__ chunk_fill, unsigned max_chunks, uint32_t *__restrict__ biglist,
+           unsigned big_cap, int emit_all, int want_fp,
            u64 *__restrict__ partials, FastCtl *__restrict__ ctl, int64_t ntiles)
-{ __shared__ u64      ent[S_SPAN];
+{ constexpr int rw = RW;               // 64-bit words per request record: k-mer [+ count|flag]
+  __shared__ u64      ent[S_SPAN];
   __shared__ uint16_t scnt[S_SPAN];
-  __shared__ unsigned acc[S_SPAN];
-  __shared__ u64      sq[S_OWN * 2];
+  __shared__ unsigned acc[S_SPAN];      // credits from lower entries: count | hi<<8 | sum(delta)<<16
+  __shared__ unsigned res[S_SCAN];      // own forward scan:           count | hi<<8 | delta<<16 | w2<<24
+  __shared__ u64      sq[S_OWN * RW];
   __shared__ u64      sfp[S_TPB / 64][2];
-  __shared__ unsigned s_qn, s_chunk, s_used;
+  __shared__ unsigned s_qn, s_chunk, s_used, s_nbig, s_bigbase;
+  __shared__ uint32_t sbig[S_OWN];      // entries whose window block outgrows the halo (rare)
   __shared__ u64      s_base, s_total;
 
   const int t = threadIdx.x;
   const int64_t n = A.n;
   u64 f0 = 0, f1 = 0;
-  if (t == 0) { s_chunk = F_NOCHUNK; s_used = 0; s_total = 0; s_qn = 0; }
+  if (t == 0) { s_chunk = F_NOCHUNK; s_used = 0; s_total = 0; s_qn = 0; s_nbig = 0; }
 
-  // register prefetch of one tile: 528 key pairs (16 B) and 264 count quads (8 B)
+  // Register prefetch of one tile: 528 key pairs (16 B) and 264 count quads (8 B) per workgroup.
+  // The loads are UNCONDITIONAL (addresses clamped into the table, n >= 8 guaranteed by the host):
+  // any branch around them makes the compiler serialise the five loads with s_waitcnt vmcnt(0),
+  // i.e. five memory round trips per tile instead of one (measured: r01 ISA dump).  Which slots are
+  // real is decided later from the slot index alone.
   ulonglong2 kr[3];
   ushort4    cr[2];
   auto prefetch = [&](int64_t tile)
   { const int64_t g0 = tile * S_OWN - S_HALO;
 #pragma unroll
     for (int q = 0; q < 3; q++)
-      { const int p = t + q * S_TPB;
-        const int64_t gi = g0 + 2 * p;
-        kr[q] = make_ulonglong2(~0ull, ~0ull);
-        if (p < S_SPAN / 2)
-          { if (gi >= 0 && gi + 1 < n) kr[q] = *reinterpret_cast<const ulonglong2 *>(A.keys + gi);
-            else
-              { if (gi >= 0 && gi < n) kr[q].x = A.keys[gi];
-                if (gi + 1 >= 0 && gi + 1 < n) kr[q].y = A.keys[gi + 1];
-              }
-          }
+      { int64_t gi = g0 + 2 * (t + q * S_TPB);
+        gi = gi < 0 ? 0 : (gi > n - 2 ? n - 2 : gi);
+        kr[q] = *reinterpret_cast<const ulonglong2 *>(A.keys + gi);
       }
 #pragma unroll
     for (int q = 0; q < 2; q++)
-      { const int p = t + q * S_TPB;
-        const int64_t gi = g0 + 4 * p;
-        cr[q] = make_ushort4(0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF);
-        if (p < S_SPAN / 4)
-          { if (gi >= 0 && gi + 3 < n) cr[q] = *reinterpret_cast<const ushort4 *>(A.cnt + gi);
-            else
-              { if (gi >= 0 && gi < n) cr[q].x = A.cnt[gi];
-                if (gi + 1 >= 0 && gi + 1 < n) cr[q].y = A.cnt[gi + 1];
-                if (gi + 2 >= 0 && gi + 2 < n) cr[q].z = A.cnt[gi + 2];
-                if (gi + 3 >= 0 && gi + 3 < n) cr[q].w = A.cnt[gi + 3];
-              }
-          }
+      { int64_t gi = g0 + 4 * (t + q * S_TPB);
+        gi = gi < 0 ? 0 : (gi > n - 4 ? n - 4 : gi);
+        cr[q] = *reinterpret_cast<const ushort4 *>(A.cnt + gi);
       }
   };
-  // k-mer word -> {prefix32, suffix32}; slots outside the table hold (0xFFFFFFFF, 0) with count
-  // 0xFFFF, which can never pair (the sum exceeds SMAX) whatever prefix its neighbour has
-  auto split = [&](u64 x, int64_t gi) -> u64
-  { if (gi < 0 || gi >= n) return 0xFFFFFFFF00000000ull;
+  // slot -> value, undoing the clamp: a pair / quad that straddles the table end was loaded from
+  // n-2 / n-4, so the wanted element sits further up in the registers
+  auto key_of = [&](const ulonglong2 &v, int64_t gpair, int which) -> u64
+  { const int64_t gi = gpair + which;
+    if (gi < 0 || gi >= n) return 0xFFFFFFFF00000000ull;       // never pairs, see below
+    const u64 x = (gpair > n - 2) ? v.y : (which ? v.y : v.x);   // gpair == n-1: element n-1 is .y
     const u64 val = x >> G.kshift;
     return ((val >> G.sbits) << 32) | (val & G.smask);
+  };
+  auto cnt_of = [&](const ushort4 &v, int64_t gquad, int which) -> unsigned
+  { const int64_t gi = gquad + which;
+    if (gi < 0 || gi >= n) return 0xFFFFu;
+    const int sh = gquad > n - 4 ? (int) (gquad - (n - 4)) : 0;   // loaded from n-4 instead of gquad
+    const int e = which + sh;                                     // 0..3
+    return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w;
   };
 
   int64_t tile = blockIdx.x;
@@ -639,111 +677,116 @@ kf_pass1_s(FastArgs A, Geo32 G, uint32_t *__restrict__ bstart, u64 *__restrict__
     { const int64_t lo = tile * S_OWN;          // first owned entry
       const int64_t g0 = lo - S_HALO;           // global index of LDS slot 0
       // ---- phase 0: registers -> LDS ------------------------------------------------------------
+      // slots outside the table hold (0xFFFFFFFF, 0) with count 0xFFFF, which can never pair (the
+      // count sum exceeds SMAX) whatever prefix the neighbour has
 #pragma unroll
       for (int q = 0; q < 3; q++)
         { const int p = t + q * S_TPB;
           if (p < S_SPAN / 2)
-            { ent[2 * p]     = split(kr[q].x, g0 + 2 * p);
-              ent[2 * p + 1] = split(kr[q].y, g0 + 2 * p + 1);
+            { ent[2 * p]     = key_of(kr[q], g0 + 2 * p, 0);
+              ent[2 * p + 1] = key_of(kr[q], g0 + 2 * p, 1);
             }
         }
 #pragma unroll
       for (int q = 0; q < 2; q++)
         { const int p = t + q * S_TPB;
           if (p < S_SPAN / 4)
-            { scnt[4 * p] = cr[q].x; scnt[4 * p + 1] = cr[q].y; scnt[4 * p + 2] = cr[q].z; scnt[4 * p + 3] = cr[q].w; }
+            {
+#pragma unroll
+              for (int w = 0; w < 4; w++) scnt[4 * p + w] = (uint16_t) cnt_of(cr[q], g0 + 4 * p, w);
+            }
         }
       for (int idx = t; idx < S_SPAN; idx += S_TPB) acc[idx] = 0;
       if (t == 0) s_qn = 0;
+      // the next tile's loads are in flight during all of this tile's work
+      if (tile + gridDim.x < ntiles) prefetch(tile + gridDim.x);
       lds_barrier();
 
-      // ---- phase 1: prefetch the next tile, forward scan with credits ---------------------------
-      if (tile + gridDim.x < ntiles) prefetch(tile + gridDim.x);
-
-      unsigned pre[4], suf[4], cc[4], sa[4], sh[4], dl[4];
-      bool alive[4];
+      // ---- phase 1: forward scan with credits -----------------------------------------------------
+      { unsigned pre[4], suf[4], cc[4], sa[4], sh[4], dl[4];
+        bool alive[4];
 #pragma unroll
-      for (int r = 0; r < 4; r++)
-        { const int idx = t + r * S_TPB;
-          const u64 e = ent[idx];
-          pre[r] = (unsigned) (e >> 32); suf[r] = (unsigned) e; cc[r] = scnt[idx];
-          sa[r] = 0; sh[r] = 0; dl[r] = 0;
-          alive[r] = cc[r] != 0xFFFF;                       // slots outside the table never scan
-        }
-      for (int d = 1; d < S_HALO; d++)
-        { bool any = false;
+        for (int r = 0; r < 4; r++)
+          { const int idx = t + r * S_TPB;
+            const u64 e = ent[idx];
+            pre[r] = (unsigned) (e >> 32); suf[r] = (unsigned) e; cc[r] = scnt[idx];
+            sa[r] = 0; sh[r] = 0; dl[r] = 0;
+            alive[r] = cc[r] != 0xFFFF;                     // slots outside the table never scan
+          }
+        for (int d = 1; d < S_HALO && !(A.dbg & 1); d++)
+          { bool any = false;
 #pragma unroll
-          for (int r = 0; r < 4; r++)
-            { const int j = t + r * S_TPB + d;
-              const u64 y = ent[j];
-              alive[r] = alive[r] && ((unsigned) (y >> 32) == pre[r]);
-              unsigned tt = suf[r] ^ (unsigned) y;
-              tt = (tt | (tt >> 1)) & 0x55555555u;
-              const bool one = alive[r] && ((tt & (tt - 1)) == 0);
-              if (one)                                       // rare: a one-away neighbour
-                { const unsigned cy = scnt[j];
-                  if (cc[r] + cy <= SMG_SMAX)
-                    { const unsigned hi = (tt != G.midbit);
-                      if (sa[r] == 0) dl[r] = (unsigned) d | (hi << 8);
-                      sa[r]++; sh[r] += hi;
-                      atomicAdd(&acc[j], 1u | (hi << 8) | ((unsigned) d << 16));
-                    }
-                }
-              any |= alive[r];
-            }
-          if (!__any(any)) break;
-        }
+            for (int r = 0; r < 4; r++)
+              { const int j = t + r * S_TPB + d;
+                const u64 y = ent[j];
+                alive[r] = alive[r] && ((unsigned) (y >> 32) == pre[r]);
+                unsigned tt = suf[r] ^ (unsigned) y;
+                tt = (tt | (tt >> 1)) & 0x55555555u;
+                const bool one = alive[r] && ((tt & (tt - 1)) == 0);
+                if (one)                                     // rare: a one-away neighbour
+                  { const unsigned cy = scnt[j];
+                    if (cc[r] + cy <= SMG_SMAX)
+                      { const unsigned hi = (tt != G.midbit);
+                        if (sa[r] == 0) dl[r] = ((unsigned) d << 16) | (hi << 24);
+                        sa[r]++; sh[r] += hi;
+                        atomicAdd(&acc[j], 1u | (hi << 8) | ((unsigned) d << 16));
+                      }
+                  }
+                any |= alive[r];
+              }
+            if (!__any(any)) break;
+          }
+#pragma unroll
+        for (int r = 0; r < 4; r++) res[t + r * S_TPB] = sa[r] | (sh[r] << 8) | dl[r];
+      }
       lds_barrier();
 
       // ---- phase 2: owned entries: combine, code, directory, complement, requests --------------
-#pragma unroll
+#pragma unroll 1
       for (int r = 0; r < 4; r++)
         { const int idx = t + r * S_TPB;
           const int64_t i = g0 + idx;
           const bool own = idx >= S_HALO && i < n;
-          unsigned code = 0, s_hi = 0, bcur = 0;
+          unsigned code = 0, s_hi = 0, bcur = 0, cnt_i = 0;
           u64 x = 0;
           if (own)
-            { const unsigned a = acc[idx];
-              unsigned s_all = sa[r] + (a & 0xFF);
-              s_hi = sh[r] + ((a >> 8) & 0xFF);
-              int64_t delta = sa[r] ? (int64_t) (dl[r] & 0xFF) : -(int64_t) (a >> 16);
-              unsigned w2 = sa[r] ? (dl[r] >> 8) : ((a >> 8) & 0xFF);
+            { const u64 e = ent[idx];
+              const unsigned pre_i = (unsigned) (e >> 32), suf_i = (unsigned) e;
+              const unsigned a = acc[idx], f = res[idx];
+              cnt_i = scnt[idx];
+              const unsigned fa = f & 0xFF;
+              unsigned s_all = fa + (a & 0xFF);
+              s_hi = ((f >> 8) & 0xFF) + ((a >> 8) & 0xFF);
+              int64_t delta = fa ? (int64_t) ((f >> 16) & 0xFF) : -(int64_t) (a >> 16);
+              unsigned w2 = fa ? (f >> 24) : ((a >> 8) & 0xFF);
               // a block that reaches 32 entries to either side: exact slow walk
-              const bool big = (unsigned) (ent[idx - S_HALO] >> 32) == pre[r]
-                            || (unsigned) (ent[idx + S_HALO] >> 32) == pre[r];
-              if (big)
-                { int64_t partner;
-                  big_block_scan<1>(A.keys, A.cnt, n, A.g, i, s_all, s_hi, partner, w2);
-                  delta = partner - i;
-                }
+              const bool big = (unsigned) (ent[idx - S_HALO] >> 32) == pre_i
+                            || (unsigned) (ent[idx + S_HALO] >> 32) == pre_i;
               code = make_code(s_all, delta, w2);
-              x = ((((u64) pre[r]) << G.sbits) | suf[r]) << G.kshift;
+              if (big)
+                { // no global loads in this loop: they would be waited for with vmcnt(0), which also
+                  // drains the tile prefetch.  kf_bigfix redoes the entry exactly.
+                  sbig[atomicAdd(&s_nbig, 1u)] = (uint32_t) i;
+                  code = CODE_DEFER;
+                  s_hi = 0;
+                }
+              x = ((((u64) pre_i) << G.sbits) | suf_i) << G.kshift;
               bcur = (unsigned) ((x - A.dir.base) >> A.dir.shift);
-              if (i > 0 && !(ent[idx - 1] < ent[idx])) ctl->unsorted = 1;
-            }
-          // directory: buckets (bprev, bcur] start at i; the predecessor's bucket comes from the
-          // neighbouring lane (lane 0 recomputes it from the staged predecessor)
-          unsigned bprev = __shfl_up(bcur, 1, 64);
-          if ((t & 63) == 0 && own && i > 0)
-            { const u64 pe = ent[idx - 1];
-              const u64 px = ((((u64) (unsigned) (pe >> 32)) << G.sbits) | (unsigned) pe) << G.kshift;
-              bprev = (unsigned) ((px - A.dir.base) >> A.dir.shift);
-            }
-          if (own)
-            { A.code[i] = (uint8_t) code;
-              long long b = (i == 0 || idx == S_HALO) ? -1 : (long long) bprev;
-              if (idx == S_HALO && i > 0)                   // first owned entry of the tile
+              long long b = -1;
+              if (i > 0)
                 { const u64 pe = ent[idx - 1];
+                  if (!(pe < e)) ctl->unsorted = 1;
                   const u64 px = ((((u64) (unsigned) (pe >> 32)) << G.sbits) | (unsigned) pe) << G.kshift;
                   b = (long long) ((px - A.dir.base) >> A.dir.shift);
                 }
-              for (b = b + 1; b <= (long long) bcur; b++) bstart[b] = (uint32_t) i;
+              if (!(A.dbg & 8)) A.code[i] = (uint8_t) code;
+              // directory: buckets (bucket(i-1), bucket(i)] start at i
+              if (!(A.dbg & 2)) for (b = b + 1; b <= (long long) bcur; b++) bstart[b] = (uint32_t) i;
               if (i == n - 1)
                 for (b = (long long) bcur + 1; b <= (long long) A.dir.nb; b++) bstart[b] = (uint32_t) n;
             }
           const bool emit = own && (emit_all || s_hi > 0);
-          if (__any(emit || (own && want_fp)))
+          if (!(A.dbg & 4) && __any(emit || (own && want_fp)))
             { Key<1> kx, rc;
               kx.w[0] = x;
               rc = revcomp<1>(kx, G.k);
@@ -758,11 +801,11 @@ kf_pass1_s(FastArgs A, Geo32 G, uint32_t *__restrict__ bstart, u64 *__restrict__
                       if (rw == 1) sq[q] = rc.w[0];
                       else
                         { sq[2 * q] = rc.w[0];
-                          sq[2 * q + 1] = (u64) cc[r] | ((u64) (s_hi > 0) << 16);
+                          sq[2 * q + 1] = (u64) cnt_i | ((u64) (s_hi > 0) << 16);
                         }
                     }
                 }
-              if (own && want_fp) fp_accumulate<1>(kx, rc, cc[r], f0, f1);
+              if (own && want_fp) fp_accumulate<1>(kx, rc, cnt_i, f0, f1);
             }
         }
       lds_barrier();
@@ -792,6 +835,15 @@ kf_pass1_s(FastArgs A, Geo32 G, uint32_t *__restrict__ bstart, u64 *__restrict__
             }
           lds_barrier();
         }
+      const unsigned nb = s_nbig;
+      if (nb > 0)                                   // rare
+        { lds_barrier();
+          if (t == 0) { s_bigbase = atomicAdd(&ctl->nbig, nb); s_nbig = 0; }
+          lds_barrier();
+          for (unsigned e = t; e < nb; e += S_TPB)
+            if (s_bigbase + e < big_cap) biglist[s_bigbase + e] = sbig[e];
+          lds_barrier();
+        }
     }
 
   if (t == 0)
@@ -808,5 +860,61 @@ kf_pass1_s(FastArgs A, Geo32 G, uint32_t *__restrict__ bstart, u64 *__restrict__
           partials[(size_t) blockIdx.x * 4 + t] = s;
           partials[(size_t) blockIdx.x * 4 + 2 + t] = 0;
         }
+    }
+}
+
+
+// Entries deferred by kf_pass1_s (their window block is longer than the 32-entry halo): exact walk by
+// binary searches, final code byte, and -- for the ones that own a pair at p > k-1-p -- a request.
+// One chunk per workgroup iteration batch, same chunk list as pass 1.
+template <int RW> __global__ void __launch_bounds__(F_TPB)
+kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, unsigned nbig, u64 *__restrict__ req,
+          uint32_t *__restrict__ chunk_fill, unsigned max_chunks, FastCtl *__restrict__ ctl)
+{ constexpr int rw = RW;
+  __shared__ u64      sq[F_TPB * RW];
+  __shared__ unsigned s_qn, s_chunk, s_used;
+  __shared__ u64      s_base, s_total;
+  const int t = threadIdx.x;
+  if (t == 0) { s_qn = 0; s_chunk = F_NOCHUNK; s_used = 0; s_total = 0; }
+  __syncthreads();
+  for (unsigned r0 = blockIdx.x * F_TPB; r0 < nbig; r0 += gridDim.x * F_TPB)
+    { const unsigned r = r0 + t;
+      if (r < nbig)
+        { const int64_t i = biglist[r];
+          unsigned s_all, s_hi, w2;
+          int64_t partner;
+          big_block_scan<1>(A.keys, A.cnt, A.n, A.g, i, s_all, s_hi, partner, w2);
+          A.code[i] = (uint8_t) make_code(s_all, partner - i, w2);
+          if (s_hi > 0)
+            { Key<1> kx = load_key<1>(A.keys, i);
+              const Key<1> rc = revcomp<1>(kx, A.g.k);
+              const unsigned q = atomicAdd(&s_qn, 1u);
+              sq[q * rw] = rc.w[0];
+              if (rw == 2) sq[q * rw + 1] = (u64) A.cnt[i] | (1ull << 16);
+            }
+        }
+      __syncthreads();
+      const unsigned qn = s_qn;
+      if (qn > 0)
+        { if (t == 0)
+            { if (s_chunk == F_NOCHUNK || s_used + qn > F_CH)
+                { if (s_chunk != F_NOCHUNK && s_chunk < max_chunks) chunk_fill[s_chunk] = s_used;
+                  s_chunk = atomicAdd(&ctl->n_chunks, 1u);
+                  s_used = 0;
+                }
+              s_base = (u64) s_chunk * F_CH + s_used;
+              s_used += qn; s_total += qn; s_qn = 0;
+            }
+          __syncthreads();
+          if (s_chunk < max_chunks)
+            { u64 *o = req + s_base * rw;
+              for (unsigned e = t; e < qn * rw; e += F_TPB) o[e] = sq[e];
+            }
+        }
+      __syncthreads();
+    }
+  if (t == 0)
+    { if (s_chunk != F_NOCHUNK && s_chunk < max_chunks) chunk_fill[s_chunk] = s_used;
+      if (s_total) atomicAdd(&ctl->nreq, s_total);
     }
 }

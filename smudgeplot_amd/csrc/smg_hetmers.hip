@@ -323,7 +323,7 @@ k_pass2(Tab t, int64_t lo, int64_t hi, u64 *__restrict__ plot)
 // ------------------------------------------------------------------------------------------
 
 #define FAST_MAX_K   85        // above this a uint8 degree can wrap: counted path (v1 kernels)
-#define P1_GRID      2048      // persistent workgroups of kf_pass1 (8 per CU)
+#define P1_GRID      1280      // persistent workgroups of kf_pass1 (5 per CU resident: LDS bound)
 #define P2_GRID      512       // persistent workgroups of kf_pass2 (2 per CU, 66 KB LDS each)
 
 struct smg_engine
@@ -343,6 +343,7 @@ struct smg_engine
   void        *sort_tmp; int64_t sort_tmp_cap;
   u64         *dense;  int64_t dense_cap;    // compacted requests
   uint32_t    *chunk_off; int64_t chunk_off_cap;
+  uint32_t    *biglist; int64_t biglist_cap;    // bytes
   int          rw;                           // 64-bit words per request record
   uint32_t    *chunk_fill; int64_t chunk_cap; // bytes
   unsigned     max_chunks;
@@ -420,7 +421,7 @@ extern "C" void smg_engine_destroy(smg_engine *e)
   hipSetDevice(e->device);
   hipStreamSynchronize(e->stream);
   hipFree(e->own_keys); hipFree(e->own_cnt); hipFree(e->deg); hipFree(e->pflag); hipFree(e->bstart);
-  hipFree(e->req); hipFree(e->req2); hipFree(e->sort_tmp); hipFree(e->dense); hipFree(e->chunk_off); hipFree(e->chunk_fill); hipFree(e->route_cnt); hipFree(e->route_off);
+  hipFree(e->req); hipFree(e->req2); hipFree(e->sort_tmp); hipFree(e->dense); hipFree(e->chunk_off); hipFree(e->biglist); hipFree(e->chunk_fill); hipFree(e->route_cnt); hipFree(e->route_off);
   hipFree(e->partials); hipFree(e->ctrl); hipFree(e->d_split);
   hipHostFree(e->h_ctrl); hipHostFree(e->h_partials);
   for (int i = 0; i < 8; i++) hipEventDestroy(e->ev[i]);
@@ -683,6 +684,7 @@ static FastArgs make_fast(smg_engine *e)
 { FastArgs a;
   a.keys = e->keys; a.cnt = e->cnt; a.n = e->n; a.g = e->geo; a.dir = e->dir;
   a.code = e->deg; a.pflag = e->pflag;
+  { const char *d = getenv("SMG_DBG_SKIP"); a.dbg = d ? atoi(d) : 0; }
   return a;
 }
 
@@ -704,7 +706,7 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
       memset(e->fp, 0, sizeof(e->fp));
       return SMG_OK;
     }
-  const bool narrow = e->W == 1;                       // k <= 32: the specialised kernel
+  const bool narrow = e->W == 1 && e->n >= 8;          // k <= 32: the specialised kernel
   const int64_t ntiles = narrow ? (e->n + S_OWN - 1) / S_OWN : (e->n + F_TILE - 1) / F_TILE;
   const unsigned grid = (unsigned) (ntiles < P1_GRID ? ntiles : P1_GRID);
   Geo32 g32;
@@ -712,17 +714,26 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
   g32.sbits = 2 * (e->kmer - e->kmer / 2);
   g32.smask = g32.sbits >= 32 ? 0xFFFFFFFFu : ((1u << g32.sbits) - 1u);
   g32.midbit = (e->kmer & 1) ? 1u << (g32.sbits - 2) : 0u;
-  int64_t want_rec = (emit_all ? e->n : e->n / 4) + (int64_t) (grid + 16) * F_CH;
-  for (int attempt = 0; attempt < 2; attempt++)
+  int64_t want_rec = (emit_all ? e->n : e->n / 4) + (int64_t) (grid + 16 + 256) * F_CH;
+  int64_t big_cap = e->biglist_cap / 4 > (1 << 20) ? e->biglist_cap / 4 : (1 << 20);
+  for (int attempt = 0; attempt < 3; attempt++)
     { const unsigned maxc = (unsigned) ((want_rec + F_CH - 1) / F_CH);
       if ((rc = grow(&e->req, &e->req_cap, (int64_t) maxc * F_CH * (int64_t) sizeof(u64) * e->rw, errbuf, errlen))) return rc;
       if ((rc = grow(&e->chunk_fill, &e->chunk_cap, (int64_t) maxc * 4 + 4, errbuf, errlen))) return rc;
       e->max_chunks = maxc;
+      if ((rc = grow(&e->biglist, &e->biglist_cap, big_cap * 4, errbuf, errlen))) return rc;
       FastArgs a = make_fast(e);
       hipEventRecord(e->ev[2], e->stream);
       if (narrow)
-        hipLaunchKernelGGL(kf_pass1_s, dim3(grid), dim3(S_TPB), 0, e->stream, a, g32, e->bstart, e->req,
-                           e->chunk_fill, maxc, emit_all, e->rw, want_fp, e->partials, &e->ctrl->fast, ntiles);
+        { if (e->rw == 1)
+            hipLaunchKernelGGL(kf_pass1_s<1>, dim3(grid), dim3(S_TPB), 0, e->stream, a, g32, e->bstart, e->req,
+                               e->chunk_fill, maxc, e->biglist, (unsigned) big_cap, emit_all, want_fp,
+                               e->partials, &e->ctrl->fast, ntiles);
+          else
+            hipLaunchKernelGGL(kf_pass1_s<2>, dim3(grid), dim3(S_TPB), 0, e->stream, a, g32, e->bstart, e->req,
+                               e->chunk_fill, maxc, e->biglist, (unsigned) big_cap, emit_all, want_fp,
+                               e->partials, &e->ctrl->fast, ntiles);
+        }
       else
         {
 #define CALL(WW) hipLaunchKernelGGL(kf_pass1<WW>, dim3(grid), dim3(F_TPB), 0, e->stream, a, e->bstart, \
@@ -737,10 +748,38 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
       if ((rc = read_ctrl(e, errbuf, errlen))) return rc;
       if (e->h_ctrl->fast.unsorted)
         return fail(errbuf, errlen, SMG_EFORMAT, "table entries are not strictly increasing%s");
-      if (e->h_ctrl->fast.n_chunks <= maxc) break;
-      // the request list outgrew its first-guess capacity: size it from the count and redo
-      want_rec = (int64_t) (e->h_ctrl->fast.n_chunks + 16) * F_CH;
-      HIPCHK(hipMemsetAsync(&e->ctrl->fast, 0, sizeof(FastCtl), e->stream));
+      bool redo = false;
+      if (e->h_ctrl->fast.n_chunks > maxc)
+        { // the request list outgrew its first-guess capacity: size it from the count and redo
+          want_rec = (int64_t) (e->h_ctrl->fast.n_chunks + 16 + 256) * F_CH;
+          redo = true;
+        }
+      if ((int64_t) e->h_ctrl->fast.nbig > big_cap)
+        { big_cap = (int64_t) e->h_ctrl->fast.nbig + 1024; redo = true; }
+      if (redo)
+        { HIPCHK(hipMemsetAsync(&e->ctrl->fast, 0, sizeof(FastCtl), e->stream));
+          continue;
+        }
+      if (narrow && e->h_ctrl->fast.nbig > 0)
+        { // exact redo of the entries whose window block is longer than the halo
+          const unsigned nbig = e->h_ctrl->fast.nbig;
+          unsigned fb = (nbig + F_TPB - 1) / F_TPB;
+          if (fb > 256) fb = 256;
+          if (e->rw == 1)
+            hipLaunchKernelGGL(kf_bigfix<1>, dim3(fb), dim3(F_TPB), 0, e->stream, a, e->biglist, nbig, e->req,
+                               e->chunk_fill, maxc, &e->ctrl->fast);
+          else
+            hipLaunchKernelGGL(kf_bigfix<2>, dim3(fb), dim3(F_TPB), 0, e->stream, a, e->biglist, nbig, e->req,
+                               e->chunk_fill, maxc, &e->ctrl->fast);
+          hipEventRecord(e->ev[3], e->stream);
+          if ((rc = read_ctrl(e, errbuf, errlen))) return rc;
+          if (e->h_ctrl->fast.n_chunks > maxc)
+            { want_rec = (int64_t) (e->h_ctrl->fast.n_chunks + 16 + 256) * F_CH;
+              HIPCHK(hipMemsetAsync(&e->ctrl->fast, 0, sizeof(FastCtl), e->stream));
+              continue;
+            }
+        }
+      break;
     }
   e->n_chunks = e->h_ctrl->fast.n_chunks;
   memset(e->fp, 0, sizeof(e->fp));
