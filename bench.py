@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--genome", type=float, default=1e9, help="haploid genome size in bases")
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--L", type=int, default=10)
-    ap.add_argument("--symcheck", default="exact", choices=["exact", "hash"])
+    ap.add_argument("--symcheck", default="hash", choices=["exact", "hash"])
     ap.add_argument("--cpu-sample", type=int, default=8_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -135,15 +135,28 @@ def main():
 
     # ---- roofline of the dominant kernel, from HIP events recorded by the engine on its stream
     ms = {key: float(np.mean([s[key] for s in eng_stats])) for key in ("ms_pass1", "ms_rclookup", "ms_pass2")}
-    dom = max(ms, key=ms.get)
     n_local = cnt.numel()
-    if dom == "ms_rclookup":
-        # look-up kernels: algorithmic traffic = one 8-byte k-mer + 2-byte count per request
-        alg = float(np.mean([s["nrequests"] for s in eng_stats])) * 10.0 if args.symcheck == "hash" \
-            else n_local * 10.0
-    else:
-        alg = n_local * float(ALG_BYTES_PER_KMER_PASS)
-    achieved = alg / (ms[dom] * 1e-3) / 1e9 if ms[dom] > 0 else 0.0
+    nreq = float(np.mean([s["nrequests"] for s in eng_stats]))
+    # Algorithmic bytes per launch: the two scan kernels move B_alg/2 = 11 B per
+    # entry each (10 B record + 1 B degree/code); the look-up phase moves one 8-byte k-mer + 2-byte
+    # count per request (per entry in exact mode, where every complement is looked up).
+    alg = {"ms_pass1": n_local * float(ALG_BYTES_PER_KMER_PASS),
+           "ms_pass2": n_local * float(ALG_BYTES_PER_KMER_PASS),
+           "ms_rclookup": (nreq if args.symcheck == "hash" else n_local) * 10.0}
+    # the dominant KERNEL: pass 1 and pass 2 are one launch each; the look-up phase is a chain of
+    # short launches (compact, 4 radix passes, in-order look-ups), each well below pass 1
+    single = {"ms_pass1": "kf_pass1_s<%d>" % (1 if args.symcheck == "hash" else 2) if args.k <= 32 else "kf_pass1<W>",
+              "ms_pass2": "kf_pass2<1>" if args.k <= 32 else "kf_pass2<W>"}
+    dom = max(single, key=ms.get)
+    achieved = alg[dom] / (ms[dom] * 1e-3) / 1e9 if ms[dom] > 0 else 0.0
+    traffic, traffic_src = None, None
+    tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tj):
+        with open(tj) as f:
+            t = json.load(f)
+        if dom in t.get("bytes_per_entry", {}) and t.get("k") == args.k:
+            traffic = t["bytes_per_entry"][dom] * n_local
+            traffic_src = t.get("source")
 
     if rank == 0:
         cpu = None if args.no_cpu else cpu_baseline(args.cpu_sample, args.k, args.L)
@@ -156,11 +169,13 @@ def main():
             "config": {"workload": f"synthetic diploid {G:.3g} bp, 50x, 1% het, k={args.k}, L={args.L}: "
                                    f"{n_total} table entries (conditioned, rc-closed)",
                        "symcheck": args.symcheck, "sharding": f"prefix x{world}"},
-            "roofline": {"bound": "hbm", "kernel": {"ms_pass1": "k_pass1", "ms_pass2": "k_pass2",
-                                                     "ms_rclookup": "k_apply+k_verify"}[dom],
+            "roofline": {"bound": "hbm", "kernel": single[dom],
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel_ms": ms, "whole_job_frac_of_22B_roofline":
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": alg[dom], "kernel_ms": ms,
+                         "lookup_phase_GBps": alg["ms_rclookup"] / (ms["ms_rclookup"] * 1e-3) / 1e9
+                         if ms["ms_rclookup"] > 0 else 0.0,
+                         "whole_job_frac_of_22B_roofline":
                              (n_total * 22.0 / (dt / args.steps)) / 1e9 / (HBM_PEAK_GBS * world)},
             "cpu_baseline": cpu,
             "pairs_in_plot": int(plot.sum().item()),

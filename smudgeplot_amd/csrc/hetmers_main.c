@@ -13,7 +13,10 @@
  *  Additions that do not touch the reference contract (all optional, environment only, so
  *  the Python CLI stays byte-for-byte unchanged):
  *    SMUDGEPLOT_GPU=<ordinal>            device to use (default 0)
- *    SMUDGEPLOT_SYMCHECK=exact|hash|none how table symmetry is proven (default exact)
+ *    SMUDGEPLOT_SYMCHECK=hash|exact|none how table symmetry is proven (default hash: 128-bit
+ *                                        multiset fingerprint of T against rc(T); exact looks up
+ *                                        the complement of every entry; the reference itself only
+ *                                        probes entry #1, PloidyPlot.c:1199-1229)
  *    under -v the engine adds one "[smg]" timing line to stderr
  *
  *  Deviations, deliberate:
@@ -246,8 +249,8 @@ int main(int argc, char *argv[])
     memset(&opts, 0, sizeof(opts));
     { const char *g = getenv("SMUDGEPLOT_GPU"), *s = getenv("SMUDGEPLOT_SYMCHECK");
       opts.device = g ? atoi(g) : 0;
-      opts.symcheck = SMG_SYM_EXACT;
-      if (s && strcasecmp(s, "hash") == 0) opts.symcheck = SMG_SYM_HASH;
+      opts.symcheck = SMG_SYM_HASH;
+      if (s && strcasecmp(s, "exact") == 0) opts.symcheck = SMG_SYM_EXACT;
       if (s && strcasecmp(s, "none") == 0) opts.symcheck = SMG_SYM_NONE;
       opts.verbose = VERBOSE;
     }

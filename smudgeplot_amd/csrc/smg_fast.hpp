@@ -362,13 +362,13 @@ kf_compact(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill,
 
 // self-check of a sort (debug / tests): order on the leading 32 bits + order-free checksums
 __global__ void __launch_bounds__(F_TPB)
-kf_check_sorted(const u64 *__restrict__ before, const u64 *__restrict__ after, int64_t n,
+kf_check_sorted(const u64 *__restrict__ before, const u64 *__restrict__ after, int64_t n, int lobit,
                 u64 *__restrict__ out /* [0]=violations [1]=sum before [2]=sum after [3]=xor both */)
 { const int64_t stride = (int64_t) gridDim.x * F_TPB;
   u64 bad = 0, sb = 0, sa = 0, x = 0;
   for (int64_t i = (int64_t) blockIdx.x * F_TPB + threadIdx.x; i < n; i += stride)
     { const u64 a = after[i], b = before[i];
-      if (i > 0 && (after[i - 1] >> 32) > (a >> 32)) bad++;
+      if (i > 0 && (after[i - 1] >> lobit) > (a >> lobit)) bad++;
       sb += mix64(b); sa += mix64(a); x ^= a ^ b;
     }
   bad = wave_sum_u64(bad); sb = wave_sum_u64(sb); sa = wave_sum_u64(sa);

@@ -714,10 +714,16 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
   g32.sbits = 2 * (e->kmer - e->kmer / 2);
   g32.smask = g32.sbits >= 32 ? 0xFFFFFFFFu : ((1u << g32.sbits) - 1u);
   g32.midbit = (e->kmer & 1) ? 1u << (g32.sbits - 2) : 0u;
-  int64_t want_rec = (emit_all ? e->n : e->n / 4) + (int64_t) (grid + 16 + 256) * F_CH;
+  // a chunk is closed as soon as the next tile's batch (<= one tile of records) does not fit, so
+  // chunks fill to >= 75 %: size the list for that, and never below what is already allocated
+  // (an engine that is reused on the same table must not redo pass 1 every time)
+  int64_t want_rec = (emit_all ? e->n + e->n / 24 : e->n / 4) + (int64_t) (grid + 16 + 256) * F_CH;
   int64_t big_cap = e->biglist_cap / 4 > (1 << 20) ? e->biglist_cap / 4 : (1 << 20);
   for (int attempt = 0; attempt < 3; attempt++)
-    { const unsigned maxc = (unsigned) ((want_rec + F_CH - 1) / F_CH);
+    { unsigned maxc = (unsigned) ((want_rec + F_CH - 1) / F_CH);
+      { const int64_t have = e->req_cap / ((int64_t) F_CH * (int64_t) sizeof(u64) * e->rw);
+        if (e->req && have > (int64_t) maxc && have < 0x7FFFFFFFll) maxc = (unsigned) have;
+      }
       if ((rc = grow(&e->req, &e->req_cap, (int64_t) maxc * F_CH * (int64_t) sizeof(u64) * e->rw, errbuf, errlen))) return rc;
       if ((rc = grow(&e->chunk_fill, &e->chunk_cap, (int64_t) maxc * 4 + 4, errbuf, errlen))) return rc;
       e->max_chunks = maxc;
@@ -811,17 +817,19 @@ static int apply_sorted(smg_engine *e, const u64 *keys_in, int64_t nsort, char *
   if (nsort >= SORT_MIN)
     { if ((rc = grow(&e->req2, &e->req2_cap, nsort * (int64_t) sizeof(u64), errbuf, errlen))) return rc;
       size_t tmp = 0;
+      unsigned lobit = 40;                   // tuning knob: sort on bits [lobit, 64) of the k-mer
+      { const char *lb = getenv("SMG_SORT_LOBIT"); if (lb) lobit = (unsigned) atoi(lb); if (lobit > 56) lobit = 56; }
       HIPCHK(rocprim::radix_sort_keys<smg_sort_config>(nullptr, tmp, (u64 *) keys_in, e->req2, (size_t) nsort,
-                                                       32u, 64u, e->stream));
+                                                       lobit, 64u, e->stream));
       if ((rc = grow((char **) &e->sort_tmp, &e->sort_tmp_cap, (int64_t) tmp + 16, errbuf, errlen))) return rc;
       HIPCHK(rocprim::radix_sort_keys<smg_sort_config>(e->sort_tmp, tmp, (u64 *) keys_in, e->req2, (size_t) nsort,
-                                                       32u, 64u, e->stream));
+                                                       lobit, 64u, e->stream));
       src = e->req2;
       if (getenv("SMG_VERIFY_SORT"))
         { u64 *d_chk = NULL, h[4];
           HIPCHK(hipMalloc(&d_chk, 32));
           HIPCHK(hipMemsetAsync(d_chk, 0, 32, e->stream));
-          hipLaunchKernelGGL(kf_check_sorted, dim3((unsigned) nb), dim3(F_TPB), 0, e->stream, keys_in, e->req2, nsort, d_chk);
+          hipLaunchKernelGGL(kf_check_sorted, dim3((unsigned) nb), dim3(F_TPB), 0, e->stream, keys_in, e->req2, nsort, (int) lobit, d_chk);
           HIPCHK(hipMemcpyAsync(h, d_chk, 32, hipMemcpyDeviceToHost, e->stream));
           HIPCHK(hipStreamSynchronize(e->stream));
           hipFree(d_chk);
