@@ -67,10 +67,17 @@ typedef struct smg_table_view
   const int64_t        *prefix_index;  /* [2^(8*ibyte)] cumulative END offsets                 */
 } smg_table_view;
 
+/* Table conditioning the reference delegates to FastK's Logex / Symmex
+   (PloidyPlot.c:1381-1414), done on the device instead.                                     */
+#define SMG_COND_TRIM  1     /* drop entries with count < ethresh          (Logex 'A[e-]')    */
+#define SMG_COND_SYMM  2     /* add the reverse complement of every entry  (Symmex)           */
+
 typedef struct smg_opts
 { int32_t device;        /* HIP device ordinal                                               */
   int32_t symcheck;      /* SMG_SYM_*                                                        */
   int32_t verbose;       /* >0: per-phase timing lines on stderr                             */
+  int32_t condition;     /* SMG_COND_* bits: condition the table before the scan             */
+  int32_t ethresh;       /* -e threshold for SMG_COND_TRIM                                   */
   int32_t reserved;
 } smg_opts;
 
@@ -121,6 +128,13 @@ int smg_engine_decode(smg_engine *e, int kmer, int ibyte, int64_t nels,
    d_counts= nels uint16.                                                                     */
 int smg_engine_bind(smg_engine *e, int kmer, int64_t nels, const uint64_t *d_keys,
                     const uint16_t *d_counts, char *errbuf, size_t errlen);
+
+/* Condition the engine's table in place (decoded or bound; the result is engine-owned):
+   trim to count >= ethresh and / or close it under reverse complement.  *new_nels (may be NULL)
+   receives the new number of entries.
+   Replaces the Logex / Symmex / Fastrm shell-outs, PloidyPlot.c:1381-1414, 1584-1592.        */
+int smg_engine_condition(smg_engine *e, int ethresh, int do_trim, int do_symm,
+                         int64_t *new_nels, char *errbuf, size_t errlen);
 
 /* Whole single-GPU computation on the bound/decoded table; d_plot = int64[SMG_PLOT_CELLS]
    in device memory, overwritten.  Asynchronous on the engine's stream except for the small

@@ -13,6 +13,8 @@
  *  Additions that do not touch the reference contract (all optional, environment only, so
  *  the Python CLI stays byte-for-byte unchanged):
  *    SMUDGEPLOT_GPU=<ordinal>            device to use (default 0)
+ *    SMUDGEPLOT_USE_FASTK_TOOLS=1        condition with Logex/Symmex/Fastrm like the reference
+ *                                        (default: trim + symmetrise on the device)
  *    SMUDGEPLOT_SYMCHECK=hash|exact|none how table symmetry is proven (default hash: 128-bit
  *                                        multiset fingerprint of T against rc(T); exact looks up
  *                                        the complement of every entry; the reference itself only
@@ -193,7 +195,7 @@ int main(int argc, char *argv[])
     smg_opts  opts;
     smg_stats stats;
     char errbuf[512];
-    int  rc;
+    int  rc, use_tools = 0, condition = 0;
 
     if (tname == NULL || command == NULL)
       { fprintf(stderr, "%s: Out of memory (Allocating strings)\n", Prog_Name); exit(1); }
@@ -211,29 +213,41 @@ int main(int argc, char *argv[])
 
     sprintf(tname, "%s", SRC);
 
-    /* Conditioning is still delegated to FastK's Logex / Symmex exactly as the reference does
-       (PloidyPlot.c:1381-1414); an on-device replacement is the next row of the scope table. */
+    /* Conditioning.  The reference delegates it to FastK's Logex / Symmex / Fastrm through system(3)
+       (PloidyPlot.c:1381-1414); those tools are not part of smudgeplot.  Here the same two steps run on
+       the device right after the table is decoded (smg_opts.condition), with the same progress lines
+       and no temporary tables.  SMUDGEPLOT_USE_FASTK_TOOLS=1 restores the reference's shell-outs
+       (identical command strings, temp tables ".trim" / ".symx" in the cwd).                      */
+    { const char *ft = getenv("SMUDGEPLOT_USE_FASTK_TOOLS");
+      use_tools = ft != NULL && atoi(ft) != 0;
+    }
     if (!trim)
       { if (VERBOSE)
           { fprintf(stderr, "\n  Trimming k-mers in table with count < %d\n", ETHRESH); fflush(stderr); }
-        sprintf(command, "Logex -T%d '%s.trim=A[%d-]' %s", NTHREADS, troot, ETHRESH, tname);
-        system_x(command);
-        sprintf(tname, "%s.trim", troot);
+        if (use_tools)
+          { sprintf(command, "Logex -T%d '%s.trim=A[%d-]' %s", NTHREADS, troot, ETHRESH, tname);
+            system_x(command);
+            sprintf(tname, "%s.trim", troot);
+          }
+        else condition |= SMG_COND_TRIM;
       }
     if (!symm)
       { if (VERBOSE)
           { fprintf(stderr, trim ? "\n  Making table symmetric\n" : "\n  Making trimmed table symmetric\n");
             fflush(stderr);
           }
-        sprintf(command, "Symmex -T%d -P%s %s %s.symx", NTHREADS, SORT_PATH, tname, troot);
-        system_x(command);
-        if (!trim)
-          { sprintf(command, "Fastrm %s.trim", troot);
+        if (use_tools)
+          { sprintf(command, "Symmex -T%d -P%s %s %s.symx", NTHREADS, SORT_PATH, tname, troot);
             system_x(command);
+            if (!trim)
+              { sprintf(command, "Fastrm %s.trim", troot);
+                system_x(command);
+              }
+            sprintf(tname, "%s.symx", troot);
           }
-        sprintf(tname, "%s.symx", troot);
+        else condition |= SMG_COND_SYMM;
       }
-    if (!(symm && trim))
+    if (use_tools && !(symm && trim))
       { input = tname;
         smg_ktab_free(&T);
         load_or_die(input, &T);
@@ -253,6 +267,8 @@ int main(int argc, char *argv[])
       if (s && strcasecmp(s, "exact") == 0) opts.symcheck = SMG_SYM_EXACT;
       if (s && strcasecmp(s, "none") == 0) opts.symcheck = SMG_SYM_NONE;
       opts.verbose = VERBOSE;
+      opts.condition = condition;
+      opts.ethresh = ETHRESH;
     }
     { smg_table_view tv;
       tv.kmer = T.kmer; tv.ibyte = T.ibyte; tv.nparts = T.nparts; tv.minval = T.minval;

@@ -129,20 +129,40 @@ template <int W> SMG_DEV int64_t lower_bound_key(const u64 *__restrict__ keys, i
   return lo;
 }
 
-// bucket directory over the first word: bstart[b] = first entry whose bucket is >= b
+// bucket directory over the leading 32 bits of the k-mer: bstart[b] = first entry whose bucket is >= b.
+// bucket(x) = (hi32(x) >> dsh) - b0: two 32-bit VALU operations (a 64-bit subtract + shift of the whole
+// word cost 65 instructions per entry in the first version of the pass-1 epilogue).  Tables whose k-mers
+// all share their first 16 bases fall into one bucket and are searched by plain bisection: correct,
+// only slower, and no real FastK table looks like that.
 struct Dir
 { const uint32_t *bstart;
-  u64      base;      // first word of the first entry
-  int      shift;
+  uint32_t b0;        // bucket value of the first entry before the offset
+  int      dsh;       // 0..31
   uint32_t nb;        // number of buckets; bstart has nb+1 entries
 };
 
+#define DIR_UNSET 0xFFFFFFFFu   // bstart of an empty bucket (the directory is memset to 0xFF before pass 1)
+
+// clamped into [0, nb): on a sorted table the clamp never acts; on garbage it keeps the writers in bounds
+SMG_DEV uint32_t dir_bucket(const Dir &d, u64 w0)
+{ const uint32_t b = ((uint32_t) (w0 >> 32) >> d.dsh) - d.b0;
+  return b < d.nb ? b : d.nb - 1;
+}
+
+// Writers store ONE word per non-empty bucket (bstart[bucket(i)] = i for the first entry i of the bucket)
+// plus bstart[nb] = n; empty buckets stay DIR_UNSET and are skipped here.  (Filling the empty buckets from
+// the writer side needs a loop per entry whose trip count is the length of the empty run: unbounded on
+// skewed tables.)
 template <int W> SMG_DEV int64_t find_key(const u64 *__restrict__ keys, const Dir &d,
                                           const Key<W> &t)
-{ if (t.w[0] < d.base) return -1;
-  const u64 b = (t.w[0] - d.base) >> d.shift;
+{ const uint32_t hb = (uint32_t) (t.w[0] >> 32) >> d.dsh;
+  if (hb < d.b0) return -1;
+  uint32_t b = hb - d.b0;
   if (b >= d.nb) return -1;
-  int64_t lo = d.bstart[b], hi = d.bstart[b + 1];
+  int64_t lo = d.bstart[b];
+  if (lo == (int64_t) DIR_UNSET) return -1;
+  int64_t hi = d.bstart[++b];
+  while (hi == (int64_t) DIR_UNSET) hi = d.bstart[++b];       // bstart[nb] is always set
   lo = lower_bound_key<W>(keys, lo, hi, t);
   if (lo < hi && key_eq<W>(load_key<W>(keys, lo), t)) return lo;
   return -1;

@@ -257,16 +257,15 @@ kf_pass1(FastArgs A, uint32_t *__restrict__ bstart, u64 *__restrict__ req,
           A.code[i] = (uint8_t) make_code(s_all, delta, w2);
 
           // bucket directory + strict order check (the predecessor is in the halo)
-          { const int64_t bcur = (int64_t) ((x.w[0] - A.dir.base) >> A.dir.shift);
-            int64_t bprev = -1;
+          { const uint32_t bcur = dir_bucket(A.dir, x.w[0]);
+            bool first = i == 0;
             if (i > 0)
               { const Key<W> pv = lds_key<W>(sk, idx - 1);
-                bprev = (int64_t) ((pv.w[0] - A.dir.base) >> A.dir.shift);
+                first = dir_bucket(A.dir, pv.w[0]) != bcur;
                 if (!key_lt<W>(pv, x)) ctl->unsorted = 1;
               }
-            for (int64_t b = bprev + 1; b <= bcur; b++) bstart[b] = (uint32_t) i;
-            if (i == n - 1)
-              for (int64_t b = bcur + 1; b <= (int64_t) A.dir.nb; b++) bstart[b] = (uint32_t) n;
+            if (first) bstart[bcur] = (uint32_t) i;
+            if (i == n - 1) bstart[A.dir.nb] = (uint32_t) n;
           }
 
           const bool emit = emit_all || s_hi > 0;
@@ -580,291 +579,9 @@ kf_route_scatter(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk
     }
 }
 
-// =================================================================================================
-//  kf_pass1_s : pass 1 specialised for k <= 32 (one 64-bit word per k-mer) -- the headline path.
-//
-//  Differences from the generic kf_pass1<W>:
-//   * the staged LDS entry is {prefix32 | suffix32}: the first p0 bases and the last k-p0 bases of
-//     the k-mer, so "same window block" is one 32-bit compare and the one-away test is 7 32-bit ops;
-//   * each pair is discovered ONCE, by its lower entry scanning forward in a wave-uniform loop
-//     (trip count = longest block run in the wave; rare work sits behind one branch); the upper
-//     entry is credited through a packed LDS atomic: count | hi<<8 | sum(delta)<<16;
-//   * a tile owns 992 entries and scans 1024 (its 32-entry left halo included), exactly 4 per thread;
-//   * the next tile's k-mers and counts are prefetched into registers while this one is scanned, and
-//     the workgroup barriers wait for LDS only (s_waitcnt lgkmcnt(0); s_barrier) -- __syncthreads()
-//     also drains every outstanding global store, which stalled v2 (profiles/r01_v2_pmc_*);
-//   * entries whose block reaches 32 entries to either side take the exact slow walk.
-// =================================================================================================
+#define S_OWN   992                    // owned entries per pass-1 tile of the k <= 32 kernel (smg_pass1.hpp)
 
-#define S_TPB   256
-#define S_OWN   992
-#define S_HALO  32
-#define S_SCAN  1024                   // left halo + owned
-#define S_SPAN  (S_SCAN + S_HALO)      // 1056 LDS slots
-
-struct Geo32
-{ int      k;
-  int      kshift;       // 64 - 2k
-  int      sbits;        // 2 * (k - p0)
-  unsigned smask;        // low sbits set
-  unsigned midbit;       // the `t` bit of a pair at the self-mirrored position (0 when k is even)
-};
-
-template <int RW> __global__ void __launch_bounds__(S_TPB)
-kf_pass1_s(FastArgs A, Geo32 G, uint32_t *__restrict__ bstart, u64 *__restrict__ req,
-           uint32_t *__restrict__ chunk_fill, unsigned max_chunks, uint32_t *__restrict__ biglist,
-           unsigned big_cap, int emit_all, int want_fp,
-           u64 *__restrict__ partials, FastCtl *__restrict__ ctl, int64_t ntiles)
-{ constexpr int rw = RW;               // 64-bit words per request record: k-mer [+ count|flag]
-  __shared__ u64      ent[S_SPAN];
-  __shared__ uint16_t scnt[S_SPAN];
-  __shared__ unsigned acc[S_SPAN];      // credits from lower entries: count | hi<<8 | sum(delta)<<16
-  __shared__ unsigned res[S_SCAN];      // own forward scan:           count | hi<<8 | delta<<16 | w2<<24
-  __shared__ u64      sq[S_OWN * RW];
-  __shared__ u64      sfp[S_TPB / 64][2];
-  __shared__ unsigned s_qn, s_chunk, s_used, s_nbig, s_bigbase;
-  __shared__ uint32_t sbig[S_OWN];      // entries whose window block outgrows the halo (rare)
-  __shared__ u64      s_base, s_total;
-
-  const int t = threadIdx.x;
-  const int64_t n = A.n;
-  u64 f0 = 0, f1 = 0;
-  if (t == 0) { s_chunk = F_NOCHUNK; s_used = 0; s_total = 0; s_qn = 0; s_nbig = 0; }
-
-  // Register prefetch of one tile: 528 key pairs (16 B) and 264 count quads (8 B) per workgroup.
-  // The loads are UNCONDITIONAL (addresses clamped into the table, n >= 8 guaranteed by the host):
-  // any branch around them makes the compiler serialise the five loads with s_waitcnt vmcnt(0),
-  // i.e. five memory round trips per tile instead of one (measured: r01 ISA dump).  Which slots are
-  // real is decided later from the slot index alone.
-  ulonglong2 kr[3];
-  ushort4    cr[2];
-  auto prefetch = [&](int64_t tile)
-  { const int64_t g0 = tile * S_OWN - S_HALO;
-#pragma unroll
-    for (int q = 0; q < 3; q++)
-      { int64_t gi = g0 + 2 * (t + q * S_TPB);
-        gi = gi < 0 ? 0 : (gi > n - 2 ? n - 2 : gi);
-        kr[q] = *reinterpret_cast<const ulonglong2 *>(A.keys + gi);
-      }
-#pragma unroll
-    for (int q = 0; q < 2; q++)
-      { int64_t gi = g0 + 4 * (t + q * S_TPB);
-        gi = gi < 0 ? 0 : (gi > n - 4 ? n - 4 : gi);
-        cr[q] = *reinterpret_cast<const ushort4 *>(A.cnt + gi);
-      }
-  };
-  // slot -> value, undoing the clamp: a pair / quad that straddles the table end was loaded from
-  // n-2 / n-4, so the wanted element sits further up in the registers
-  auto key_of = [&](const ulonglong2 &v, int64_t gpair, int which) -> u64
-  { const int64_t gi = gpair + which;
-    if (gi < 0 || gi >= n) return 0xFFFFFFFF00000000ull;       // never pairs, see below
-    const u64 x = (gpair > n - 2) ? v.y : (which ? v.y : v.x);   // gpair == n-1: element n-1 is .y
-    const u64 val = x >> G.kshift;
-    return ((val >> G.sbits) << 32) | (val & G.smask);
-  };
-  auto cnt_of = [&](const ushort4 &v, int64_t gquad, int which) -> unsigned
-  { const int64_t gi = gquad + which;
-    if (gi < 0 || gi >= n) return 0xFFFFu;
-    const int sh = gquad > n - 4 ? (int) (gquad - (n - 4)) : 0;   // loaded from n-4 instead of gquad
-    const int e = which + sh;                                     // 0..3
-    return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w;
-  };
-
-  int64_t tile = blockIdx.x;
-  if (tile < ntiles) prefetch(tile);
-
-  for (; tile < ntiles; tile += gridDim.x)
-    { const int64_t lo = tile * S_OWN;          // first owned entry
-      const int64_t g0 = lo - S_HALO;           // global index of LDS slot 0
-      // ---- phase 0: registers -> LDS ------------------------------------------------------------
-      // slots outside the table hold (0xFFFFFFFF, 0) with count 0xFFFF, which can never pair (the
-      // count sum exceeds SMAX) whatever prefix the neighbour has
-#pragma unroll
-      for (int q = 0; q < 3; q++)
-        { const int p = t + q * S_TPB;
-          if (p < S_SPAN / 2)
-            { ent[2 * p]     = key_of(kr[q], g0 + 2 * p, 0);
-              ent[2 * p + 1] = key_of(kr[q], g0 + 2 * p, 1);
-            }
-        }
-#pragma unroll
-      for (int q = 0; q < 2; q++)
-        { const int p = t + q * S_TPB;
-          if (p < S_SPAN / 4)
-            {
-#pragma unroll
-              for (int w = 0; w < 4; w++) scnt[4 * p + w] = (uint16_t) cnt_of(cr[q], g0 + 4 * p, w);
-            }
-        }
-      for (int idx = t; idx < S_SPAN; idx += S_TPB) acc[idx] = 0;
-      if (t == 0) s_qn = 0;
-      // the next tile's loads are in flight during all of this tile's work
-      if (tile + gridDim.x < ntiles) prefetch(tile + gridDim.x);
-      lds_barrier();
-
-      // ---- phase 1: forward scan with credits -----------------------------------------------------
-      { unsigned pre[4], suf[4], cc[4], sa[4], sh[4], dl[4];
-        bool alive[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-          { const int idx = t + r * S_TPB;
-            const u64 e = ent[idx];
-            pre[r] = (unsigned) (e >> 32); suf[r] = (unsigned) e; cc[r] = scnt[idx];
-            sa[r] = 0; sh[r] = 0; dl[r] = 0;
-            alive[r] = cc[r] != 0xFFFF;                     // slots outside the table never scan
-          }
-        for (int d = 1; d < S_HALO && !(A.dbg & 1); d++)
-          { bool any = false;
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-              { const int j = t + r * S_TPB + d;
-                const u64 y = ent[j];
-                alive[r] = alive[r] && ((unsigned) (y >> 32) == pre[r]);
-                unsigned tt = suf[r] ^ (unsigned) y;
-                tt = (tt | (tt >> 1)) & 0x55555555u;
-                const bool one = alive[r] && ((tt & (tt - 1)) == 0);
-                if (one)                                     // rare: a one-away neighbour
-                  { const unsigned cy = scnt[j];
-                    if (cc[r] + cy <= SMG_SMAX)
-                      { const unsigned hi = (tt != G.midbit);
-                        if (sa[r] == 0) dl[r] = ((unsigned) d << 16) | (hi << 24);
-                        sa[r]++; sh[r] += hi;
-                        atomicAdd(&acc[j], 1u | (hi << 8) | ((unsigned) d << 16));
-                      }
-                  }
-                any |= alive[r];
-              }
-            if (!__any(any)) break;
-          }
-#pragma unroll
-        for (int r = 0; r < 4; r++) res[t + r * S_TPB] = sa[r] | (sh[r] << 8) | dl[r];
-      }
-      lds_barrier();
-
-      // ---- phase 2: owned entries: combine, code, directory, complement, requests --------------
-#pragma unroll 1
-      for (int r = 0; r < 4; r++)
-        { const int idx = t + r * S_TPB;
-          const int64_t i = g0 + idx;
-          const bool own = idx >= S_HALO && i < n;
-          unsigned code = 0, s_hi = 0, bcur = 0, cnt_i = 0;
-          u64 x = 0;
-          if (own)
-            { const u64 e = ent[idx];
-              const unsigned pre_i = (unsigned) (e >> 32), suf_i = (unsigned) e;
-              const unsigned a = acc[idx], f = res[idx];
-              cnt_i = scnt[idx];
-              const unsigned fa = f & 0xFF;
-              unsigned s_all = fa + (a & 0xFF);
-              s_hi = ((f >> 8) & 0xFF) + ((a >> 8) & 0xFF);
-              int64_t delta = fa ? (int64_t) ((f >> 16) & 0xFF) : -(int64_t) (a >> 16);
-              unsigned w2 = fa ? (f >> 24) : ((a >> 8) & 0xFF);
-              // a block that reaches 32 entries to either side: exact slow walk
-              const bool big = (unsigned) (ent[idx - S_HALO] >> 32) == pre_i
-                            || (unsigned) (ent[idx + S_HALO] >> 32) == pre_i;
-              code = make_code(s_all, delta, w2);
-              if (big)
-                { // no global loads in this loop: they would be waited for with vmcnt(0), which also
-                  // drains the tile prefetch.  kf_bigfix redoes the entry exactly.
-                  sbig[atomicAdd(&s_nbig, 1u)] = (uint32_t) i;
-                  code = CODE_DEFER;
-                  s_hi = 0;
-                }
-              x = ((((u64) pre_i) << G.sbits) | suf_i) << G.kshift;
-              bcur = (unsigned) ((x - A.dir.base) >> A.dir.shift);
-              long long b = -1;
-              if (i > 0)
-                { const u64 pe = ent[idx - 1];
-                  if (!(pe < e)) ctl->unsorted = 1;
-                  const u64 px = ((((u64) (unsigned) (pe >> 32)) << G.sbits) | (unsigned) pe) << G.kshift;
-                  b = (long long) ((px - A.dir.base) >> A.dir.shift);
-                }
-              if (!(A.dbg & 8)) A.code[i] = (uint8_t) code;
-              // directory: buckets (bucket(i-1), bucket(i)] start at i
-              if (!(A.dbg & 2)) for (b = b + 1; b <= (long long) bcur; b++) bstart[b] = (uint32_t) i;
-              if (i == n - 1)
-                for (b = (long long) bcur + 1; b <= (long long) A.dir.nb; b++) bstart[b] = (uint32_t) n;
-            }
-          const bool emit = own && (emit_all || s_hi > 0);
-          if (!(A.dbg & 4) && __any(emit || (own && want_fp)))
-            { Key<1> kx, rc;
-              kx.w[0] = x;
-              rc = revcomp<1>(kx, G.k);
-              const u64 em = __ballot(emit);
-              if (em)
-                { const int lane = t & 63, lead = __ffsll((long long) em) - 1;
-                  unsigned qb = 0;
-                  if (lane == lead) qb = atomicAdd(&s_qn, (unsigned) __popcll(em));
-                  qb = __shfl(qb, lead, 64);
-                  if (emit)
-                    { const unsigned q = qb + __popcll(em & ((1ull << lane) - 1));
-                      if (rw == 1) sq[q] = rc.w[0];
-                      else
-                        { sq[2 * q] = rc.w[0];
-                          sq[2 * q + 1] = (u64) cnt_i | ((u64) (s_hi > 0) << 16);
-                        }
-                    }
-                }
-              if (own && want_fp) fp_accumulate<1>(kx, rc, cnt_i, f0, f1);
-            }
-        }
-      lds_barrier();
-
-      // ---- phase 3: flush the request queue into this workgroup's chunk --------------------------
-      // (a chunk that cannot take the batch is closed with its fill count; kf_compact squeezes the
-      //  holes out before the requests are sorted)
-      const unsigned qn = s_qn;
-      if (qn > 0)
-        { const unsigned old_chunk = s_chunk, old_used = s_used;
-          const bool fresh = old_chunk == F_NOCHUNK || old_used + qn > F_CH;
-          lds_barrier();
-          if (t == 0)
-            { if (fresh)
-                { if (old_chunk != F_NOCHUNK && old_chunk < max_chunks) chunk_fill[old_chunk] = old_used;
-                  s_chunk = atomicAdd(&ctl->n_chunks, 1u);
-                  s_used = 0;
-                }
-              s_base = (u64) s_chunk * F_CH + s_used;
-              s_used += qn;
-              s_total += qn;
-            }
-          lds_barrier();
-          if (s_chunk < max_chunks)
-            { u64 *o = req + s_base * rw;
-              for (unsigned e = t; e < qn * rw; e += S_TPB) o[e] = sq[e];
-            }
-          lds_barrier();
-        }
-      const unsigned nb = s_nbig;
-      if (nb > 0)                                   // rare
-        { lds_barrier();
-          if (t == 0) { s_bigbase = atomicAdd(&ctl->nbig, nb); s_nbig = 0; }
-          lds_barrier();
-          for (unsigned e = t; e < nb; e += S_TPB)
-            if (s_bigbase + e < big_cap) biglist[s_bigbase + e] = sbig[e];
-          lds_barrier();
-        }
-    }
-
-  if (t == 0)
-    { if (s_chunk != F_NOCHUNK && s_chunk < max_chunks) chunk_fill[s_chunk] = s_used;
-      if (s_total) atomicAdd(&ctl->nreq, s_total);
-    }
-  if (want_fp)
-    { f0 = wave_sum_u64(f0); f1 = wave_sum_u64(f1);
-      if ((t & 63) == 0) { sfp[t >> 6][0] = f0; sfp[t >> 6][1] = f1; }
-      lds_barrier();
-      if (t < 2)
-        { u64 s = 0;
-          for (int w = 0; w < S_TPB / 64; w++) s += sfp[w][t];
-          partials[(size_t) blockIdx.x * 4 + t] = s;
-          partials[(size_t) blockIdx.x * 4 + 2 + t] = 0;
-        }
-    }
-}
-
-
-// Entries deferred by kf_pass1_s (their window block is longer than the 32-entry halo): exact walk by
+// Entries deferred by kf_pass1_r (their window block is longer than the +-30 entry window): exact walk by
 // binary searches, final code byte, and -- for the ones that own a pair at p > k-1-p -- a request.
 // One chunk per workgroup iteration batch, same chunk list as pass 1.
 template <int RW> __global__ void __launch_bounds__(F_TPB)

@@ -35,6 +35,7 @@
 #include "smg_hetmers.h"
 #include "smg_device.hpp"
 #include "smg_fast.hpp"
+#include "smg_pass1.hpp"
 
 #define WIN_LIM   32          // window blocks up to this many entries are walked linearly
 #define TPB       256
@@ -98,15 +99,16 @@ template <int W> __global__ void __launch_bounds__(TPB)
 k_directory(Tab t, uint32_t *__restrict__ bstart, Ctrl *__restrict__ ctrl)
 { const int64_t i = (int64_t) blockIdx.x * TPB + threadIdx.x;
   if (i > t.n) return;
-  int64_t bprev = -1, bcur = t.dir.nb;
-  if (i > 0)
-    bprev = (int64_t) ((t.keys[(i - 1) * W] - t.dir.base) >> t.dir.shift);
   if (i < t.n)
-    { bcur = (int64_t) ((t.keys[i * W] - t.dir.base) >> t.dir.shift);
-      if (i > 0 && !key_lt<W>(load_key<W>(t.keys, i - 1), load_key<W>(t.keys, i)))
-        ctrl->unsorted = 1;
+    { const uint32_t bcur = dir_bucket(t.dir, t.keys[i * W]);
+      bool first = i == 0;
+      if (i > 0)
+        { first = dir_bucket(t.dir, t.keys[(i - 1) * W]) != bcur;
+          if (!key_lt<W>(load_key<W>(t.keys, i - 1), load_key<W>(t.keys, i))) ctrl->unsorted = 1;
+        }
+      if (first) bstart[bcur] = (uint32_t) i;
     }
-  for (int64_t b = bprev + 1; b <= bcur; b++) bstart[b] = (uint32_t) i;
+  else bstart[t.dir.nb] = (uint32_t) t.n;
 }
 
 // ---- pass 1 -------------------------------------------------------------------------------
@@ -323,7 +325,8 @@ k_pass2(Tab t, int64_t lo, int64_t hi, u64 *__restrict__ plot)
 // ------------------------------------------------------------------------------------------
 
 #define FAST_MAX_K   85        // above this a uint8 degree can wrap: counted path (v1 kernels)
-#define P1_GRID      1280      // persistent workgroups of kf_pass1 (5 per CU resident: LDS bound)
+#define P1_GRID      1280      // persistent workgroups of the generic kf_pass1<W> (5 per CU resident: LDS bound)
+#define P1_MAXGRID   4096      // upper bound of any pass-1 grid (partial fingerprint sums)
 #define P2_GRID      512       // persistent workgroups of kf_pass2 (2 per CU, 66 KB LDS each)
 
 struct smg_engine
@@ -349,7 +352,7 @@ struct smg_engine
   unsigned     max_chunks;
   uint32_t    *route_cnt;  int64_t route_cnt_cap;
   u64         *route_off;  int64_t route_off_cap;
-  u64         *partials;   // [P1_GRID][4]
+  u64         *partials;   // [P1_MAXGRID][4]
   u64         *d_split;
   Ctrl        *ctrl;
   Ctrl        *h_ctrl;        // pinned mirror
@@ -358,6 +361,7 @@ struct smg_engine
   Dir          dir;
   bool         prepared;      // pass 1 of the current table has run
   bool         fast;          // fast path in use
+  unsigned     p1_grid[2][2]; // resident workgroups of kf_pass1_r<RW, ODD> (0 = not asked yet)
   unsigned     n_chunks;
   u64          fp[4];
   smg_stats    st;
@@ -406,8 +410,8 @@ extern "C" smg_engine *smg_engine_create(int device, void *stream, char *errbuf,
   e->stream = (hipStream_t) stream;
   if (hipMalloc(&e->ctrl, sizeof(Ctrl)) != hipSuccess
       || hipHostMalloc(&e->h_ctrl, sizeof(Ctrl)) != hipSuccess
-      || hipMalloc(&e->partials, sizeof(u64) * 4 * P1_GRID) != hipSuccess
-      || hipHostMalloc(&e->h_partials, sizeof(u64) * 4 * P1_GRID) != hipSuccess
+      || hipMalloc(&e->partials, sizeof(u64) * 4 * P1_MAXGRID) != hipSuccess
+      || hipHostMalloc(&e->h_partials, sizeof(u64) * 4 * P1_MAXGRID) != hipSuccess
       || hipMalloc(&e->d_split, sizeof(u64) * 16 * 4) != hipSuccess)
     { fail(errbuf, errlen, SMG_ENOMEM, "cannot allocate the control block%s");
       delete e; return NULL;
@@ -526,12 +530,12 @@ static int dir_geometry(smg_engine *e, char *errbuf, size_t errlen)
   if (last < first) return fail(errbuf, errlen, SMG_EFORMAT, "table entries are not strictly increasing%s");
   int bits = 4;
   while (bits < 30 && (1ll << (bits + 1)) <= e->n / 8) bits++;
-  const u64 span = last - first;
-  int shift = 0;
-  while (shift < 63 && (span >> shift) >= (1ull << bits)) shift++;
-  e->dir.base = first;
-  e->dir.shift = shift;
-  e->dir.nb = (uint32_t) ((span >> shift) + 1);
+  const uint32_t hf = (uint32_t) (first >> 32), hl = (uint32_t) (last >> 32);
+  int dsh = 0;
+  while (dsh < 31 && ((hl >> dsh) - (hf >> dsh)) >= (1u << bits)) dsh++;
+  e->dir.b0 = hf >> dsh;
+  e->dir.dsh = dsh;
+  e->dir.nb = (hl >> dsh) - (hf >> dsh) + 1;
   int rc = grow(&e->bstart, &e->bstart_cap, (int64_t) sizeof(uint32_t) * ((int64_t) e->dir.nb + 2), errbuf, errlen);
   if (rc) return rc;
   e->dir.bstart = e->bstart;
@@ -554,6 +558,7 @@ static int counted_prepare(smg_engine *e, char *errbuf, size_t errlen)
   if (rc) return rc;
   HIPCHK(hipMemsetAsync(e->deg, 0, (size_t) dbytes, e->stream));
   if ((rc = dir_geometry(e, errbuf, errlen))) return rc;
+  HIPCHK(hipMemsetAsync(e->bstart, 0xFF, sizeof(uint32_t) * ((size_t) e->dir.nb + 2), e->stream));
   Tab t = make_tab(e);
   const unsigned nblk = (unsigned) ((e->n + 1 + TPB - 1) / TPB);
 #define CALL(WW) hipLaunchKernelGGL(k_directory<WW>, dim3(nblk), dim3(TPB), 0, e->stream, t, e->bstart, e->ctrl)
@@ -700,20 +705,44 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
   if ((rc = grow(&e->pflag, &e->pflag_cap, pbytes, errbuf, errlen))) return rc;
   HIPCHK(hipMemsetAsync(e->pflag, 0, (size_t) pbytes, e->stream));
   if ((rc = dir_geometry(e, errbuf, errlen))) return rc;
+  if (e->n > 0)
+    HIPCHK(hipMemsetAsync(e->bstart, 0xFF, sizeof(uint32_t) * ((size_t) e->dir.nb + 2), e->stream));
   if (e->n == 0)
     { HIPCHK(hipMemsetAsync(e->bstart, 0, sizeof(uint32_t) * ((size_t) e->dir.nb + 2), e->stream));
       e->n_chunks = 0; e->prepared = true;
       memset(e->fp, 0, sizeof(e->fp));
       return SMG_OK;
     }
-  const bool narrow = e->W == 1 && e->n >= 8;          // k <= 32: the specialised kernel
-  const int64_t ntiles = narrow ? (e->n + S_OWN - 1) / S_OWN : (e->n + F_TILE - 1) / F_TILE;
-  const unsigned grid = (unsigned) (ntiles < P1_GRID ? ntiles : P1_GRID);
-  Geo32 g32;
-  g32.k = e->kmer; g32.kshift = 64 - 2 * e->kmer;
-  g32.sbits = 2 * (e->kmer - e->kmer / 2);
-  g32.smask = g32.sbits >= 32 ? 0xFFFFFFFFu : ((1u << g32.sbits) - 1u);
-  g32.midbit = (e->kmer & 1) ? 1u << (g32.sbits - 2) : 0u;
+  const bool narrow = e->W == 1;                       // k <= 32: the specialised kernel
+  const int64_t ntiles = narrow ? (e->n + R_OWN - 1) / R_OWN : (e->n + F_TILE - 1) / F_TILE;
+  GeoR gr;
+  { const int p0 = e->kmer / 2, sbits = 2 * (e->kmer - p0);
+    gr.k = e->kmer; gr.kshift = 64 - 2 * e->kmer;
+    gr.pshift = 32 - 2 * p0;
+    gr.smask = sbits >= 32 ? 0xFFFFFFFFu : ((1u << sbits) - 1u);
+    gr.mshift = sbits - 2;
+  }
+  const bool odd = (e->kmer & 1) != 0;
+  unsigned grid = P1_GRID;
+  if (narrow)
+    { // persistent workgroups: exactly what is resident (a static tile stride must not have stragglers)
+      if (!e->p1_grid[e->rw - 1][odd])
+        { int nb = 0, cus = 0;
+          hipError_t he;
+          if (e->rw == 1) he = odd ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kf_pass1_r<1, true>, R_TPB, 0)
+                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kf_pass1_r<1, false>, R_TPB, 0);
+          else            he = odd ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kf_pass1_r<2, true>, R_TPB, 0)
+                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kf_pass1_r<2, false>, R_TPB, 0);
+          if (he != hipSuccess || nb < 1) nb = 4;
+          if (nb > 8) nb = 8;
+          if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || cus < 1) cus = 256;
+          { const char *g = getenv("SMG_P1_WGS_PER_CU"); if (g && atoi(g) > 0) nb = atoi(g); }
+          e->p1_grid[e->rw - 1][odd] = (unsigned) (nb * cus);
+        }
+      grid = e->p1_grid[e->rw - 1][odd];
+    }
+  if (grid > P1_MAXGRID) grid = P1_MAXGRID;
+  if ((int64_t) grid > ntiles) grid = (unsigned) ntiles;
   // a chunk is closed as soon as the next tile's batch (<= one tile of records) does not fit, so
   // chunks fill to >= 75 %: size the list for that, and never below what is already allocated
   // (an engine that is reused on the same table must not redo pass 1 every time)
@@ -731,14 +760,13 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
       FastArgs a = make_fast(e);
       hipEventRecord(e->ev[2], e->stream);
       if (narrow)
-        { if (e->rw == 1)
-            hipLaunchKernelGGL(kf_pass1_s<1>, dim3(grid), dim3(S_TPB), 0, e->stream, a, g32, e->bstart, e->req,
-                               e->chunk_fill, maxc, e->biglist, (unsigned) big_cap, emit_all, want_fp,
-                               e->partials, &e->ctrl->fast, ntiles);
-          else
-            hipLaunchKernelGGL(kf_pass1_s<2>, dim3(grid), dim3(S_TPB), 0, e->stream, a, g32, e->bstart, e->req,
-                               e->chunk_fill, maxc, e->biglist, (unsigned) big_cap, emit_all, want_fp,
-                               e->partials, &e->ctrl->fast, ntiles);
+        {
+#define LAUNCH_R(RW_, ODD_) hipLaunchKernelGGL((kf_pass1_r<RW_, ODD_>), dim3(grid), dim3(R_TPB), 0, e->stream, a, gr, \
+                              e->bstart, e->req, e->chunk_fill, maxc, e->biglist, (unsigned) big_cap, emit_all, want_fp, \
+                              e->partials, &e->ctrl->fast, ntiles)
+          if (e->rw == 1) { if (odd) LAUNCH_R(1, true); else LAUNCH_R(1, false); }
+          else            { if (odd) LAUNCH_R(2, true); else LAUNCH_R(2, false); }
+#undef LAUNCH_R
         }
       else
         {
@@ -1071,6 +1099,186 @@ extern "C" int smg_engine_run(smg_engine *e, int symcheck, int64_t *d_plot, smg_
   return SMG_OK;
 }
 
+// ---- table conditioning on device ----------------------------------------
+// The reference shells out to FastK's Logex / Symmex (PloidyPlot.c:1381-1414), which are neither vendored
+// nor pinned.  Restated semantics:
+//   trim        : keep the entries with count >= ethresh                    (Logex 'A[e-]')
+//   symmetrise  : add rc(x) with the count of x for every entry x, sort, keep one copy of a k-mer that
+//                 occurs twice (a self-complementary k-mer, or -- only on input that is neither canonical
+//                 nor symmetric -- a k-mer whose complement was already present: the original entry wins)
+// Sorting is an LSD radix sort over the 64-bit words of the k-mer (stable, rocPRIM Onesweep).
+
+typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                   rocprim::default_config, 0> smg_pair_sort_config;
+
+template <int W> __global__ void __launch_bounds__(TPB)
+kc_append_rc(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, int64_t n, int k,
+             u64 *__restrict__ okeys, uint16_t *__restrict__ ocnt)
+{ const int64_t i = (int64_t) blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const Key<W> x = load_key<W>(keys, i);
+  const Key<W> r = revcomp<W>(x, k);
+#pragma unroll
+  for (int w = 0; w < W; w++) { okeys[i * W + w] = x.w[w]; okeys[(n + i) * W + w] = r.w[w]; }
+  ocnt[i] = cnt[i]; ocnt[n + i] = cnt[i];
+}
+
+__global__ void __launch_bounds__(TPB) kc_iota(uint32_t *__restrict__ p, int64_t n)
+{ const int64_t i = (int64_t) blockIdx.x * TPB + threadIdx.x;
+  if (i < n) p[i] = (uint32_t) i;
+}
+
+__global__ void __launch_bounds__(TPB)
+kc_gather_word(const u64 *__restrict__ keys, const uint32_t *__restrict__ perm, int W, int w, int64_t n,
+               u64 *__restrict__ out)
+{ const int64_t i = (int64_t) blockIdx.x * TPB + threadIdx.x;
+  if (i < n) out[i] = keys[(int64_t) perm[i] * W + w];
+}
+
+// flag[i] = 1 when the i-th entry in sorted order survives (first of its k-mer)
+template <int W> __global__ void __launch_bounds__(TPB)
+kc_flag_first(const u64 *__restrict__ keys, const uint32_t *__restrict__ perm, int64_t n,
+              uint32_t *__restrict__ flag)
+{ const int64_t i = (int64_t) blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  bool first = i == 0;
+  if (i > 0) first = !key_eq<W>(load_key<W>(keys, perm[i]), load_key<W>(keys, perm[i - 1]));
+  flag[i] = first;
+}
+
+__global__ void __launch_bounds__(TPB)
+kc_flag_trim(const uint16_t *__restrict__ cnt, int64_t n, unsigned ethresh, uint32_t *__restrict__ flag)
+{ const int64_t i = (int64_t) blockIdx.x * TPB + threadIdx.x;
+  if (i < n) flag[i] = cnt[i] >= ethresh;
+}
+
+// out[pos[i]] = in[perm ? perm[i] : i] for the flagged i
+template <int W> __global__ void __launch_bounds__(TPB)
+kc_compact(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, const uint32_t *__restrict__ perm,
+           const uint32_t *__restrict__ flag, const uint32_t *__restrict__ pos, int64_t n,
+           u64 *__restrict__ okeys, uint16_t *__restrict__ ocnt)
+{ const int64_t i = (int64_t) blockIdx.x * TPB + threadIdx.x;
+  if (i >= n || !flag[i]) return;
+  const int64_t src = perm ? (int64_t) perm[i] : i;
+  const int64_t dst = pos[i];
+#pragma unroll
+  for (int w = 0; w < W; w++) okeys[dst * W + w] = keys[src * W + w];
+  ocnt[dst] = cnt[src];
+}
+
+// flag -> positions + survivor count (exclusive scan); tmp is engine scratch
+static int cond_scan(smg_engine *e, uint32_t *flag, uint32_t *pos, int64_t n, int64_t *kept,
+                     char *errbuf, size_t errlen)
+{ size_t tmp = 0;
+  int rc;
+  HIPCHK(rocprim::exclusive_scan(nullptr, tmp, flag, pos, 0u, (size_t) n, rocprim::plus<uint32_t>(), e->stream));
+  if ((rc = grow((char **) &e->sort_tmp, &e->sort_tmp_cap, (int64_t) tmp + 16, errbuf, errlen))) return rc;
+  HIPCHK(rocprim::exclusive_scan(e->sort_tmp, tmp, flag, pos, 0u, (size_t) n, rocprim::plus<uint32_t>(), e->stream));
+  uint32_t lastp = 0, lastf = 0;
+  HIPCHK(hipMemcpyAsync(&lastp, pos + (n - 1), 4, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(&lastf, flag + (n - 1), 4, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  *kept = (int64_t) lastp + lastf;
+  return SMG_OK;
+}
+
+extern "C" int smg_engine_condition(smg_engine *e, int ethresh, int do_trim, int do_symm,
+                                    int64_t *new_nels, char *errbuf, size_t errlen)
+{ if (!e) return fail(errbuf, errlen, SMG_EINVAL, "null engine%s");
+  if (!e->keys && e->n > 0) return fail(errbuf, errlen, SMG_EINVAL, "no table bound%s");
+  HIPCHK(hipSetDevice(e->device));
+  const int W = e->W;
+  int rc;
+  int64_t n = e->n;
+  hipEvent_t c0, c1;
+  hipEventCreate(&c0); hipEventCreate(&c1);
+  hipEventRecord(c0, e->stream);
+  uint32_t *flag = NULL, *pos = NULL, *perm = NULL, *perm2 = NULL;
+  u64 *k2 = NULL, *wk = NULL, *wk2 = NULL, *ko = NULL;
+  uint16_t *c2 = NULL, *co = NULL;
+#define CFREE() { hipFree(flag); hipFree(pos); hipFree(perm); hipFree(perm2); hipFree(k2); hipFree(wk); \
+                  hipFree(wk2); hipFree(c2); hipFree(ko); hipFree(co); hipEventDestroy(c0); hipEventDestroy(c1); }
+#define CCHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { CFREE(); \
+                     return fail(errbuf, errlen, _e == hipErrorOutOfMemory ? SMG_ENOMEM : SMG_ENODEV, \
+                                 "HIP error while conditioning: %s", hipGetErrorString(_e)); } } while (0)
+#define CRC(call) do { if ((rc = (call))) { CFREE(); return rc; } } while (0)
+
+  if (do_trim && n > 0)
+    { const unsigned nblk = (unsigned) ((n + TPB - 1) / TPB);
+      CCHK(hipMalloc(&flag, sizeof(uint32_t) * (size_t) n));
+      CCHK(hipMalloc(&pos, sizeof(uint32_t) * (size_t) n));
+      hipLaunchKernelGGL(kc_flag_trim, dim3(nblk), dim3(TPB), 0, e->stream, e->cnt, n, (unsigned) ethresh, flag);
+      int64_t kept = 0;
+      CRC(cond_scan(e, flag, pos, n, &kept, errbuf, errlen));
+      CCHK(hipMalloc(&ko, sizeof(u64) * (size_t) (kept > 0 ? kept : 1) * W));
+      CCHK(hipMalloc(&co, sizeof(uint16_t) * (size_t) (kept > 0 ? kept : 1) + 16));
+#define CALL(WW) hipLaunchKernelGGL(kc_compact<WW>, dim3(nblk), dim3(TPB), 0, e->stream, e->keys, e->cnt, \
+                   (const uint32_t *) NULL, flag, pos, n, ko, co)
+      DISPATCH_W(e, CALL)
+#undef CALL
+      CCHK(hipStreamSynchronize(e->stream));
+      hipFree(e->own_keys); hipFree(e->own_cnt);
+      e->own_keys = ko; e->own_cnt = co; ko = NULL; co = NULL;
+      e->keys = e->own_keys; e->cnt = e->own_cnt;
+      n = kept;
+      hipFree(flag); hipFree(pos); flag = pos = NULL;
+    }
+
+  if (do_symm && n > 0)
+    { const int64_t n2 = 2 * n;
+      if (n2 >= 0xFFFFFFF0ll) { CFREE(); return fail(errbuf, errlen, SMG_EINVAL, "table too large to symmetrise on one GPU%s"); }
+      const unsigned nblk = (unsigned) ((n + TPB - 1) / TPB), nblk2 = (unsigned) ((n2 + TPB - 1) / TPB);
+      CCHK(hipMalloc(&k2, sizeof(u64) * (size_t) n2 * W));
+      CCHK(hipMalloc(&c2, sizeof(uint16_t) * (size_t) n2));
+      CCHK(hipMalloc(&perm, sizeof(uint32_t) * (size_t) n2));
+      CCHK(hipMalloc(&perm2, sizeof(uint32_t) * (size_t) n2));
+      CCHK(hipMalloc(&wk, sizeof(u64) * (size_t) n2));
+      CCHK(hipMalloc(&wk2, sizeof(u64) * (size_t) n2));
+#define CALL(WW) hipLaunchKernelGGL(kc_append_rc<WW>, dim3(nblk), dim3(TPB), 0, e->stream, e->keys, e->cnt, n, e->kmer, k2, c2)
+      DISPATCH_W(e, CALL)
+#undef CALL
+      hipLaunchKernelGGL(kc_iota, dim3(nblk2), dim3(TPB), 0, e->stream, perm, n2);
+      for (int w = W - 1; w >= 0; w--)              // LSD over the words, stable
+        { hipLaunchKernelGGL(kc_gather_word, dim3(nblk2), dim3(TPB), 0, e->stream, k2, perm, W, w, n2, wk);
+          size_t tmp = 0;
+          CCHK(rocprim::radix_sort_pairs<smg_pair_sort_config>(nullptr, tmp, wk, wk2, perm, perm2, (size_t) n2, 0u, 64u, e->stream));
+          CRC(grow((char **) &e->sort_tmp, &e->sort_tmp_cap, (int64_t) tmp + 16, errbuf, errlen));
+          CCHK(rocprim::radix_sort_pairs<smg_pair_sort_config>(e->sort_tmp, tmp, wk, wk2, perm, perm2, (size_t) n2, 0u, 64u, e->stream));
+          uint32_t *sw = perm; perm = perm2; perm2 = sw;
+        }
+      CCHK(hipMalloc(&flag, sizeof(uint32_t) * (size_t) n2));
+      CCHK(hipMalloc(&pos, sizeof(uint32_t) * (size_t) n2));
+#define CALL(WW) hipLaunchKernelGGL(kc_flag_first<WW>, dim3(nblk2), dim3(TPB), 0, e->stream, k2, perm, n2, flag)
+      DISPATCH_W(e, CALL)
+#undef CALL
+      int64_t kept = 0;
+      CRC(cond_scan(e, flag, pos, n2, &kept, errbuf, errlen));
+      CCHK(hipMalloc(&ko, sizeof(u64) * (size_t) kept * W));
+      CCHK(hipMalloc(&co, sizeof(uint16_t) * (size_t) kept + 16));
+#define CALL(WW) hipLaunchKernelGGL(kc_compact<WW>, dim3(nblk2), dim3(TPB), 0, e->stream, k2, c2, perm, flag, pos, n2, ko, co)
+      DISPATCH_W(e, CALL)
+#undef CALL
+      CCHK(hipStreamSynchronize(e->stream));
+      hipFree(e->own_keys); hipFree(e->own_cnt);
+      e->own_keys = ko; e->own_cnt = co; ko = NULL; co = NULL;
+      e->keys = e->own_keys; e->cnt = e->own_cnt;
+      n = kept;
+    }
+  hipEventRecord(c1, e->stream);
+  CCHK(hipStreamSynchronize(e->stream));
+  float ms = 0; hipEventElapsedTime(&ms, c0, c1);
+  CFREE();
+#undef CFREE
+#undef CCHK
+#undef CRC
+  e->n = n;
+  e->prepared = false;
+  e->st.nels = n;
+  e->st.ms_decode += ms;
+  if (new_nels) *new_nels = n;
+  return SMG_OK;
+}
+
 // ---- one-shot host entry ----------------------------------------------------------------------
 
 extern "C" int smg_hetmers_run(const smg_table_view *tv, const smg_opts *opts, int64_t *plot,
@@ -1113,6 +1321,10 @@ extern "C" int smg_hetmers_run(const smg_table_view *tv, const smg_opts *opts, i
   hipEventSynchronize(h1);
   if ((rc = smg_engine_decode(e, tv->kmer, tv->ibyte, tv->nels, d_rec, d_index, errbuf, errlen))) goto done;
   hipFree(d_rec); d_rec = NULL;
+  if (opts && opts->condition)
+    { if ((rc = smg_engine_condition(e, opts->ethresh, opts->condition & SMG_COND_TRIM, opts->condition & SMG_COND_SYMM,
+                                     NULL, errbuf, errlen))) goto done;
+    }
   if ((rc = smg_engine_run(e, symcheck, d_plot, NULL, errbuf, errlen))) goto done;
   if (hipMemcpy(plot, d_plot, sizeof(int64_t) * SMG_PLOT_CELLS, hipMemcpyDeviceToHost) != hipSuccess)
     BAIL(SMG_ENODEV, "device to host copy failed")

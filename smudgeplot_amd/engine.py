@@ -24,7 +24,7 @@ SYM_EXACT, SYM_HASH, SYM_NONE = 0, 1, 2
 _SYM = {"exact": SYM_EXACT, "hash": SYM_HASH, "none": SYM_NONE}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsmg_hetmers.so")
+LIB_PATH = os.environ.get("SMG_LIB", os.path.join(_HERE, "libsmg_hetmers.so"))   # SMG_LIB: tuning builds only
 BIN_PATH = os.path.join(_HERE, "bin", "hetmers")
 
 
@@ -43,7 +43,7 @@ class TableView(C.Structure):
 
 class Opts(C.Structure):
     _fields_ = [("device", C.c_int32), ("symcheck", C.c_int32), ("verbose", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("condition", C.c_int32), ("ethresh", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -58,7 +58,7 @@ class Stats(C.Structure):
 
 EXPORTS = [
     "smg_hetmers_run", "smg_device_count", "smg_engine_create", "smg_engine_destroy",
-    "smg_engine_decode", "smg_engine_bind", "smg_engine_run", "smg_engine_pass1",
+    "smg_engine_decode", "smg_engine_bind", "smg_engine_condition", "smg_engine_run", "smg_engine_pass1",
     "smg_engine_nreq", "smg_engine_record_words", "smg_engine_route", "smg_engine_apply",
     "smg_engine_apply_own", "smg_engine_symhash", "smg_engine_pass2", "smg_engine_stats",
     "smg_version",
@@ -112,6 +112,7 @@ def load_library():
     lib.smg_engine_destroy.argtypes = [vp]
     lib.smg_engine_decode.argtypes = [vp, i32, i32, i64, vp, vp, *err]
     lib.smg_engine_bind.argtypes = [vp, i32, i64, vp, vp, *err]
+    lib.smg_engine_condition.argtypes = [vp, i32, i32, i32, C.POINTER(i64), *err]
     lib.smg_engine_run.argtypes = [vp, i32, vp, C.POINTER(Stats), *err]
     lib.smg_engine_pass1.argtypes = [vp, i32, *err]
     lib.smg_engine_nreq.restype = i64
@@ -136,8 +137,14 @@ def device_count() -> int:
     return int(load_library().smg_device_count())
 
 
-def hetmers_run(table, device: int = 0, symcheck: str = "exact", verbose: int = 0):
+COND_TRIM, COND_SYMM = 1, 2
+
+
+def hetmers_run(table, device: int = 0, symcheck: str = "exact", verbose: int = 0, condition: int = 0,
+                ethresh: int = 0):
     """Host FastK table (`ktab.KTable`) -> (plot int64[1001,501], stats dict).
+    condition: COND_TRIM | COND_SYMM to trim to count >= ethresh / symmetrise on the device first
+    (what the reference delegates to Logex / Symmex, PloidyPlot.c:1381-1414).
 
     In-process equivalent of running the `hetmers` executable on a conditioned table
     (reference: main(), src/lib/PloidyPlot.c:1433-1575).
@@ -160,7 +167,7 @@ def hetmers_run(table, device: int = 0, symcheck: str = "exact", verbose: int = 
                    C.cast(ptrs, C.POINTER(C.c_void_p)),
                    pn.ctypes.data_as(C.POINTER(C.c_int64)),
                    idx.ctypes.data_as(C.POINTER(C.c_int64)))
-    opts = Opts(device, _SYM[symcheck], verbose, 0)
+    opts = Opts(device, _SYM[symcheck], verbose, condition, ethresh, 0)
     plot = np.zeros(PLOT_CELLS, dtype=np.int64)
     st = Stats()
     buf = C.create_string_buffer(512)
@@ -209,6 +216,12 @@ class Engine:
     def decode(self, k: int, ibyte: int, nels: int, records_ptr: int, index_ptr: int):
         _check(self.lib.smg_engine_decode(self.h, k, ibyte, nels, records_ptr, index_ptr, self._buf, 512),
                self._buf)
+
+    def condition(self, ethresh: int, trim: bool, symm: bool) -> int:
+        n = C.c_int64(0)
+        _check(self.lib.smg_engine_condition(self.h, ethresh, int(trim), int(symm), C.byref(n), self._buf, 512),
+               self._buf)
+        return int(n.value)
 
     def run(self, plot_ptr: int, symcheck: str = "exact") -> dict:
         st = Stats()

@@ -237,3 +237,67 @@ def test_engine_object_with_torch_tensors_and_manual_two_shard_exchange():
         total += pl
     torch.cuda.synchronize()
     assert np.array_equal(total.cpu().numpy().reshape(1001, 501), want)
+
+
+# ---- table conditioning on the device (row A0: what the reference delegates to Logex / Symmex) -------------
+
+def _raw_table(k, seed, L):
+    """a RAW FastK-like table: canonical k-mers only, some of them below the -e threshold, plus the
+    conditioned (trimmed + symmetric) table a correct Logex + Symmex would make of it"""
+    packed, cnt = synth.adversarial_table(k, 2500, L, seed, low_complexity=120, dense=2)
+    rc = ktab.revcomp_packed(packed, k)
+    canon = np.array([bytes(a) <= bytes(b) for a, b in zip(packed, rc)])
+    rp, rcnt = packed[canon], cnt[canon].copy()
+    rng = np.random.default_rng(seed)
+    low = rng.random(len(rcnt)) < 0.2
+    rcnt[low] = rng.integers(1, L, size=int(low.sum()))           # erroneous k-mers
+    keep = rcnt >= L
+    cp, cc = ktab.symmetrize(rp[keep], rcnt[keep], k)
+    return (rp, rcnt), (cp, cc)
+
+
+@pytest.mark.parametrize("k,seed", [(31, 1), (32, 2), (21, 3), (40, 4), (65, 5), (100, 6)])
+def test_condition_on_device_matches_numpy_conditioning(k, seed):
+    L = 5
+    (rp, rcnt), (cp, cc) = _raw_table(k, seed, L)
+    want = brute.hetmers_plot(cp, cc, k)
+    assert want.sum() > 0
+    for mode in ("hash", "exact"):
+        plot, st = engine.hetmers_run(table_from(rp, rcnt, k), symcheck=mode,
+                                      condition=engine.COND_TRIM | engine.COND_SYMM, ethresh=L)
+        assert st["nels"] == len(cc)
+        assert st["path"] == 1, "the conditioned table must pass the symmetry proof"
+        assert np.array_equal(plot, want), (k, mode)
+    # trim only / symmetrise only
+    keep = rcnt >= L
+    plot, st = engine.hetmers_run(table_from(rp[keep], rcnt[keep], k), condition=engine.COND_SYMM, ethresh=L)
+    assert np.array_equal(plot, want) and st["nels"] == len(cc)
+    sp, sc = ktab.symmetrize(rp, rcnt, k)
+    plot, st = engine.hetmers_run(table_from(sp, sc, k), condition=engine.COND_TRIM, ethresh=L)
+    keep2 = sc >= L
+    assert np.array_equal(plot, brute.hetmers_plot(sp[keep2], sc[keep2], k)) and st["nels"] == int(keep2.sum())
+
+
+@pytest.mark.parametrize("k", [31, 51])
+def test_hetmers_on_raw_table_equals_reference_on_conditioned_table(k, tmp_path):
+    """condition-then-reference == ours-on-raw: the drop-in binary reads the RAW
+    canonical table; the reference binary (or, where it is absent, the C oracle) reads the table
+    conditioned by numpy."""
+    from conftest import REF_BIN
+    L = 6
+    (rp, rcnt), (cp, cc) = _raw_table(k, 40 + k, L)
+    ktab.write_ktab(str(tmp_path / "raw"), k, rp, rcnt, ibyte=1, nparts=2)
+    ktab.write_ktab(str(tmp_path / "cond"), k, cp, cc, ibyte=1, nparts=2)
+    r = subprocess.run([HETMERS_BIN, f"-e{L}", "-T4", "-v", "-ogpu", "raw"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "  The input table is untrimmed and not symmetric\n" in r.stderr
+    assert "  Trimming k-mers in table with count < 6\n" in r.stderr
+    assert "  Making trimmed table symmetric\n" in r.stderr
+    assert not (tmp_path / ".trim.ktab").exists() and not (tmp_path / ".symx.ktab").exists()
+    if os.path.exists(REF_BIN):
+        q = subprocess.run([REF_BIN, f"-e{L}", "-T4", "-oref", "cond"], cwd=tmp_path, capture_output=True, text=True)
+        assert q.returncode == 0, q.stderr
+    else:
+        subprocess.run([ORACLE_BIN, f"-e{L}", f"-o{tmp_path}/ref", str(tmp_path / "cond")], check=True)
+    assert (tmp_path / "gpu.smu").read_text() == (tmp_path / "ref.smu").read_text()
+    assert (tmp_path / "gpu.smu").read_text() != ""

@@ -120,11 +120,26 @@ def test_hetmers_conditioning_decision_and_no_cpu_fallback(tmp_path):
                                "\n  Starting to count covariant pairs\n")
     assert r.stderr.endswith("hetmers: no HIP device available (this engine has no CPU fallback)\n")
     assert not (tmp_path / "out.smu").exists()
-    # untrimmed table: same decision and same shell-out as the reference (Logex is not installed)
+    # untrimmed table: same decision as the reference; conditioning now happens on the device, so
+    # without a GPU the run fails there (loudly), not in a Logex shell-out
     r = run(["-e9", "-v", "-T3", "-oout", "t"], tmp_path)
     assert r.returncode == 1
     assert "  The input table is untrimmed yet symmetric\n" in r.stderr
     assert "  Trimming k-mers in table with count < 9\n" in r.stderr
+    assert r.stderr.endswith("hetmers: no HIP device available (this engine has no CPU fallback)\n")
+    # SMUDGEPLOT_USE_FASTK_TOOLS=1: the reference's shell-outs, same command strings (Logex is not installed)
+    r = subprocess.run([HETMERS_BIN, "-e9", "-v", "-T3", "-oout", "t"], cwd=tmp_path, capture_output=True, text=True,
+                       env=dict(os.environ, SMUDGEPLOT_USE_FASTK_TOOLS="1"))
+    assert r.returncode == 1
+    assert "  Trimming k-mers in table with count < 9\n" in r.stderr
     assert r.stderr.endswith("hetmers: Command 'Logex -T3 '.trim=A[9-]' t' failed\n")
+    # canonical-only table: not symmetric
+    rc = ktab.revcomp_packed(packed, 31)
+    canon = np.array([bytes(a) <= bytes(b) for a, b in zip(packed, rc)])
+    ktab.write_ktab(str(tmp_path / "c"), 31, packed[canon], cnt[canon], ibyte=1)
+    r = run(["-e6", "-v", "-oout", "c"], tmp_path)
+    assert r.returncode == 1
+    assert "  The input table is trimmed but not symmetric\n" in r.stderr
+    assert "  Making table symmetric\n" in r.stderr
     with pytest.raises(engine.EngineError):
         engine.Engine(0)
