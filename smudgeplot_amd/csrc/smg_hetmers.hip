@@ -68,30 +68,87 @@ struct Tab                     // kernel argument block (passed by value)
 
 // format F records -> interleaved left-aligned words + counts
 // (restates Current_Entry, libfastk.c:1230-1269: prefix from the index, suffix from the record)
+//
+// One workgroup decodes DEC_TILE consecutive entries:
+//   * their record bytes (DEC_TILE * pbyte, contiguous) are staged in LDS with coalesced dword loads
+//     (records are 3..33 bytes wide and unaligned: per-thread byte loads ran at ~4 G entries/s);
+//   * the prefix of an entry is the smallest p with index[p] > i.  Thread 0 bisects the index for the
+//     first and the last entry of the tile, the (few) index values in between are staged in LDS and
+//     every thread bisects there; a tile that spans more than DEC_IX buckets (sparse table) bisects
+//     the global index per entry as before.
+#define DEC_TILE  1024
+#define DEC_IX    2048
+#define DEC_MAXPB 34                      // pbyte <= ceil(128/4) + 2 - 1
+
+SMG_DEV int dec_bisect(const int64_t *__restrict__ index, int lo, int hi, int64_t i)
+{ while (lo < hi)                         // smallest p in [lo, hi] with index[p] > i  (index[hi] > i)
+    { const int m = (lo + hi) >> 1;
+      if (index[m] <= i) lo = m + 1; else hi = m;
+    }
+  return lo;
+}
+
 __global__ void __launch_bounds__(TPB)
 k_decode(const uint8_t *__restrict__ rec, const int64_t *__restrict__ index, int ixlen,
          int ibyte, int kbyte, int W, int64_t n, u64 *__restrict__ keys,
          uint16_t *__restrict__ cnt)
-{ const int64_t i = (int64_t) blockIdx.x * TPB + threadIdx.x;
-  if (i >= n) return;
-  // smallest p with index[p] > i
-  int lo = 0, hi = ixlen - 1;
-  while (lo < hi)
-    { const int m = (lo + hi) >> 1;
-      if (index[m] <= i) lo = m + 1; else hi = m;
+{ __shared__ unsigned sraw[(DEC_TILE * DEC_MAXPB + 3) / 4 + 2];
+  __shared__ int64_t  six[DEC_IX];
+  __shared__ int      s_lo, s_hi;
+  const int t = threadIdx.x;
+  const int hbyte = kbyte - ibyte, pbyte = hbyte + 2;
+  const int64_t i0 = (int64_t) blockIdx.x * DEC_TILE;
+  const int64_t i1 = i0 + DEC_TILE < n ? i0 + DEC_TILE : n;
+  // record bytes of [i0, i1): aligned dword loads around the (unaligned) byte range
+  const int64_t b0 = i0 * pbyte, b1 = i1 * pbyte;
+  const uintptr_t base = (uintptr_t) rec + (uintptr_t) b0;
+  const uintptr_t abase = base & ~(uintptr_t) 3;
+  const int skew = (int) (base - abase);
+  const int ndw = (int) ((b1 - b0 + skew + 3) >> 2);
+  const uintptr_t rbeg = (uintptr_t) rec, rend = (uintptr_t) rec + (uintptr_t) (n * pbyte);
+  for (int w = t; w < ndw; w += TPB)
+    { const uintptr_t a = abase + 4 * (uintptr_t) w;
+      unsigned v = 0;
+      if (a >= rbeg && a + 4 <= rend) v = *reinterpret_cast<const unsigned *>(a);
+      else                                  // first / last dword of the table: never touch bytes outside it
+        for (int q = 0; q < 4; q++)
+          if (a + q >= rbeg && a + q < rend) v |= (unsigned) *reinterpret_cast<const uint8_t *>(a + q) << (8 * q);
+      sraw[w] = v;
     }
-  const int hbyte = kbyte - ibyte;
-  const uint8_t *r = rec + i * (int64_t) (hbyte + 2);
-  u64 word = 0;
-  int w = 0;
-  for (int b = 0; b < 8 * W; b++)
-    { unsigned v = 0;
-      if (b < ibyte)      v = (lo >> (8 * (ibyte - 1 - b))) & 0xFF;
-      else if (b < kbyte) v = r[b - ibyte];
-      word = (word << 8) | v;
-      if ((b & 7) == 7) { keys[i * W + w] = word; w++; word = 0; }
+  if (t == 0)
+    { s_lo = dec_bisect(index, 0, ixlen - 1, i0);
+      s_hi = dec_bisect(index, 0, ixlen - 1, i1 - 1);
     }
-  cnt[i] = (uint16_t) (r[hbyte] | (r[hbyte + 1] << 8));
+  __syncthreads();
+  const int lo = s_lo, hi = s_hi;
+  const bool staged = hi - lo < DEC_IX;
+  if (staged)
+    for (int p = lo + t; p <= hi; p += TPB) six[p - lo] = index[p];
+  __syncthreads();
+  const uint8_t *sb = reinterpret_cast<const uint8_t *>(sraw) + skew;
+  for (int64_t i = i0 + t; i < i1; i += TPB)
+    { int p;
+      if (staged)
+        { int a = 0, b = hi - lo;
+          while (a < b)
+            { const int m = (a + b) >> 1;
+              if (six[m] <= i) a = m + 1; else b = m;
+            }
+          p = lo + a;
+        }
+      else p = dec_bisect(index, lo, hi, i);
+      const uint8_t *r = sb + (i - i0) * pbyte;
+      u64 word = 0;
+      int w = 0;
+      for (int bb = 0; bb < 8 * W; bb++)
+        { unsigned v = 0;
+          if (bb < ibyte)      v = (p >> (8 * (ibyte - 1 - bb))) & 0xFF;
+          else if (bb < kbyte) v = r[bb - ibyte];
+          word = (word << 8) | v;
+          if ((bb & 7) == 7) { keys[i * W + w] = word; w++; word = 0; }
+        }
+      cnt[i] = (uint16_t) (r[hbyte] | (r[hbyte + 1] << 8));
+    }
 }
 
 // bucket directory + strict-order validation
@@ -501,7 +558,7 @@ extern "C" int smg_engine_decode(smg_engine *e, int kmer, int ibyte, int64_t nel
   e->keys = e->own_keys; e->cnt = e->own_cnt;
   hipEventRecord(e->ev[0], e->stream);
   if (nels > 0)
-    { const unsigned nblk = (unsigned) ((nels + TPB - 1) / TPB);
+    { const unsigned nblk = (unsigned) ((nels + DEC_TILE - 1) / DEC_TILE);
       hipLaunchKernelGGL(k_decode, dim3(nblk), dim3(TPB), 0, e->stream, d_records,
                          d_prefix_index, 1 << (8 * ibyte), ibyte, kbyte, e->W, nels,
                          e->own_keys, e->own_cnt);
@@ -729,10 +786,9 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
       if (!e->p1_grid[e->rw - 1][odd])
         { int nb = 0, cus = 0;
           hipError_t he;
-          if (e->rw == 1) he = odd ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kf_pass1_r<1, true>, R_TPB, 0)
-                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kf_pass1_r<1, false>, R_TPB, 0);
-          else            he = odd ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kf_pass1_r<2, true>, R_TPB, 0)
-                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kf_pass1_r<2, false>, R_TPB, 0);
+          // (the four RW x ODD variants of one KF class use the same registers and LDS: ask for one of them)
+          if (e->rw == 1) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kf_pass1_r<1, true, true>, R_TPB, 0);
+          else            he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kf_pass1_r<2, true, true>, R_TPB, 0);
           if (he != hipSuccess || nb < 1) nb = 4;
           if (nb > 8) nb = 8;
           if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || cus < 1) cus = 256;
@@ -761,11 +817,14 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
       hipEventRecord(e->ev[2], e->stream);
       if (narrow)
         {
-#define LAUNCH_R(RW_, ODD_) hipLaunchKernelGGL((kf_pass1_r<RW_, ODD_>), dim3(grid), dim3(R_TPB), 0, e->stream, a, gr, \
+#define LAUNCH_R(RW_, ODD_, KF_) hipLaunchKernelGGL((kf_pass1_r<RW_, ODD_, KF_>), dim3(grid), dim3(R_TPB), 0, e->stream, a, gr, \
                               e->bstart, e->req, e->chunk_fill, maxc, e->biglist, (unsigned) big_cap, emit_all, want_fp, \
                               e->partials, &e->ctrl->fast, ntiles)
-          if (e->rw == 1) { if (odd) LAUNCH_R(1, true); else LAUNCH_R(1, false); }
-          else            { if (odd) LAUNCH_R(2, true); else LAUNCH_R(2, false); }
+#define LAUNCH_R2(RW_, ODD_) { if (kf) LAUNCH_R(RW_, ODD_, true); else LAUNCH_R(RW_, ODD_, false); }
+          const bool kf = gr.pshift < 32 && gr.kshift < 32;          // 17 <= k <= 32
+          if (e->rw == 1) { if (odd) LAUNCH_R2(1, true) else LAUNCH_R2(1, false) }
+          else            { if (odd) LAUNCH_R2(2, true) else LAUNCH_R2(2, false) }
+#undef LAUNCH_R2
 #undef LAUNCH_R
         }
       else

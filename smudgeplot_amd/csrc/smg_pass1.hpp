@@ -57,10 +57,17 @@ template <bool ODD> SMG_DEV unsigned r_val(unsigned dd, int d, const GeoR &G)
 }
 #define R_UP(v, d) ((v) - ((unsigned) (2 * (d)) << 8))
 
-SMG_DEV void r_unpack(u64 x, const GeoR &G, unsigned &pre, unsigned &suf)
+// KF: 17 <= k <= 32, the k-mer straddles both 32-bit halves (pshift and kshift below 32): no selects
+template <bool KF> SMG_DEV void r_unpack(u64 x, const GeoR &G, unsigned &pre, unsigned &suf)
 { const unsigned hi = (unsigned) (x >> 32), lo = (unsigned) x;
-  pre = G.pshift < 32 ? hi >> G.pshift : 0u;
-  suf = (G.kshift >= 32 ? hi >> (G.kshift - 32) : __builtin_amdgcn_alignbit(hi, lo, G.kshift)) & G.smask;
+  if (KF)
+    { pre = hi >> G.pshift;
+      suf = __builtin_amdgcn_alignbit(hi, lo, G.kshift) & G.smask;
+    }
+  else
+    { pre = G.pshift < 32 ? hi >> G.pshift : 0u;
+      suf = (G.kshift >= 32 ? hi >> (G.kshift - 32) : __builtin_amdgcn_alignbit(hi, lo, G.kshift)) & G.smask;
+    }
 }
 
 // the 12 register tests of one thread: entries 0..3 are its own, 4..6 its right neighbour's
@@ -92,7 +99,7 @@ struct RShared                            // the workgroup's LDS arrays (pointer
 
 // One tile: phases 1-3.  INNER tiles lie completely inside the table (all but the first and the last one):
 // vector loads, no bounds checks, no table-end cases in the directory code.
-template <int RW, bool ODD, bool INNER> SMG_DEV void
+template <int RW, bool ODD, bool KF, bool INNER> SMG_DEV void
 r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict__ bstart,
        FastCtl *__restrict__ ctl, int emit_all, int want_fp, int64_t g0, int t,
        u64 &fa, u64 &fb, unsigned &fneg)
@@ -135,7 +142,7 @@ r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict_
       }
     //@mark P1_UNPACK
 #pragma unroll
-    for (int e = 0; e < 8; e++) r_unpack(kk[e], G, pre[e], suf[e]);
+    for (int e = 0; e < 8; e++) r_unpack<KF>(kk[e], G, pre[e], suf[e]);
     // LDS copy for the tail loop and the epilogue
     { ulonglong2 w0, w1;
       w0.x = kk[0]; w0.y = kk[1]; w1.x = kk[2]; w1.y = kk[3];
@@ -156,8 +163,7 @@ r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict_
     //@mark P1_CREDIT
     // every result goes to the entry's credit word (own entries too: frees the registers)
 #pragma unroll
-    for (int e = 0; e < 7; e++)
-      if (acc[e]) atomicAdd(&S.cred[slot0 + e], acc[e]);
+    for (int e = 0; e < 7; e++) atomicAdd(&S.cred[slot0 + e], acc[e]);     // unconditional: no VALU spent on tests
     // entries whose block continues past distance 3
     unsigned alive = 0;
 #pragma unroll
@@ -169,23 +175,22 @@ r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict_
 
   //@mark P2_TAIL
   // ---- phase 2: tail, distances 4..30 from the LDS copy (global memory past the tile edge), rare --------
-  // one queue item per thread at most; items are dealt round-robin to the four waves
   { const unsigned tn = *S.s_tn;
-    const unsigned q = ((unsigned) (t & 63) << 2) | (unsigned) (t >> 6);
-    if (q < tn)
+    // items are dealt to waves 0 and 1 only: the other two skip the whole phase (the kernel is VALU bound)
+    for (unsigned q = ((unsigned) (t & 63) << 1) | (unsigned) (t >> 6); t < 128 && q < tn; q += 128)
       { const unsigned item = S.tailq[q];
         const int ts = 4 * (int) (item & 0xFF);
         for (unsigned m = item >> 8; m; m &= m - 1)
           { const int sa = ts + __ffs(m) - 1;
             unsigned pa, sfa, pb, sfb;
-            r_unpack(S.ent[sa], G, pa, sfa);
+            r_unpack<KF>(S.ent[sa], G, pa, sfa);
             const unsigned ca = S.lcn[sa];
             for (int d = 4; d <= R_WIN + 1; d++)
               { const int sb = sa + d;
                 unsigned cb;
                 if (!INNER && g0 + sb >= n) break;
-                if (sb < R_SCAN) { r_unpack(S.ent[sb], G, pb, sfb); cb = S.lcn[sb]; }
-                else             { r_unpack(keys[g0 + sb], G, pb, sfb); cb = cnts[g0 + sb]; }
+                if (sb < R_SCAN) { r_unpack<KF>(S.ent[sb], G, pb, sfb); cb = S.lcn[sb]; }
+                else             { r_unpack<KF>(keys[g0 + sb], G, pb, sfb); cb = cnts[g0 + sb]; }
                 if (pb != pa) break;
                 if (d > R_WIN) { atomicOr(&S.cred[sa], R_BIG); atomicOr(&S.cred[sb], R_BIG); break; }
                 const unsigned dd = sfa ^ sfb;
@@ -285,7 +290,7 @@ r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict_
 #define R_WAVES_PER_EU 5
 #endif
 
-template <int RW, bool ODD> __global__ void __launch_bounds__(R_TPB)
+template <int RW, bool ODD, bool KF> __global__ void __launch_bounds__(R_TPB)
 __attribute__((amdgpu_waves_per_eu(R_WAVES_PER_EU, R_WAVES_PER_EU)))
 kf_pass1_r(FastArgs A, GeoR G, uint32_t *__restrict__ bstart, u64 *__restrict__ req,
            uint32_t *__restrict__ chunk_fill, unsigned max_chunks, uint32_t *__restrict__ biglist,
@@ -316,9 +321,9 @@ kf_pass1_r(FastArgs A, GeoR G, uint32_t *__restrict__ bstart, u64 *__restrict__ 
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
     { const int64_t g0 = tile * R_OWN - R_HALO;
       if (g0 >= 0 && g0 + R_SCAN + 4 <= n)
-        r_tile<RW, ODD, true>(A, G, S, bstart, ctl, emit_all, want_fp, g0, t, fa, fb, fneg);
+        r_tile<RW, ODD, KF, true>(A, G, S, bstart, ctl, emit_all, want_fp, g0, t, fa, fb, fneg);
       else
-        r_tile<RW, ODD, false>(A, G, S, bstart, ctl, emit_all, want_fp, g0, t, fa, fb, fneg);
+        r_tile<RW, ODD, KF, false>(A, G, S, bstart, ctl, emit_all, want_fp, g0, t, fa, fb, fneg);
       lds_barrier();
       //@mark P4_FLUSH
       // zero the credit words for the next tile

@@ -101,3 +101,37 @@ def diploid_table(G: int, k: int = 31, het: float = 0.01, cov: float = 50.0, L: 
     del key_parts, cnt_parts
     keys <<= (64 - 2 * k)                      # left align: base 0 in bits 63..62
     return keys, cnt
+
+
+def polyploid_table(G: int, ploidy: int = 4, div: float = 0.01, cov_hap: float = 25.0, k: int = 31,
+                    L: int = 12, seed: int = 3265401, device="cuda"):
+    """Stand-in for a real polyploid FastK table (BASELINE configs 1/2/4: the yeast SRR3265401 and
+    strawberry data cannot be fetched offline): `ploidy` haplotypes, each the base genome with its own
+    SNPs at rate `div`; a k-mer carried by d haplotypes gets coverage ~ Normal(d*cov_hap), trimmed at L
+    (k-mers below L are DROPPED, like FastK -t / Logex would), both strands present.
+    -> (keys int64 left aligned sorted, counts int16), conditioned (trimmed + symmetric)."""
+    assert k <= 31 and 4 * ploidy * G < 1.2e9
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    base = torch.randint(0, 4, (G,), dtype=torch.uint8, device=device, generator=gen)
+    parts = []
+    for _ in range(ploidy):
+        snp = torch.rand(G, device=device, generator=gen) < div
+        delta = torch.randint(1, 4, (G,), dtype=torch.uint8, device=device, generator=gen)
+        h = torch.where(snp, (base + delta) & 3, base)
+        km = _kmers_of(h, k)
+        parts += [km, _revcomp_right(km, k)]
+        del snp, delta, h, km
+    keys, mult = torch.unique(torch.cat(parts), sorted=True, return_counts=True)
+    del parts
+    canon = torch.minimum(keys, _revcomp_right(keys, k))
+    u1 = (_mix(canon ^ 0x243F6A8885A308D3) >> 11).to(torch.float64) / float(1 << 53)
+    u2 = (_mix(canon ^ 0x13198A2E03707344) >> 11).to(torch.float64) / float(1 << 53)
+    u1 = u1 - torch.floor(u1); u2 = u2 - torch.floor(u2)
+    z = torch.sqrt(-2.0 * torch.log(u1.clamp_min(1e-300))) * torch.cos(2 * math.pi * u2)
+    mean = cov_hap * mult.clamp(max=ploidy).to(torch.float64)
+    cnt = torch.round(mean + torch.sqrt(mean) * z).clamp_(0, 32767).to(torch.int16)
+    keep = cnt >= L
+    keys, cnt = keys[keep], cnt[keep]
+    keys <<= (64 - 2 * k)
+    return keys, cnt
