@@ -393,6 +393,8 @@ kf_apply_sorted(FastArgs A, const u64 *__restrict__ keys_sorted, int64_t nreq, F
       A.pflag[j] = 1;
     }
 }
+// (Running 4 independent look-ups per thread in lockstep was tried and lost 1.1 ms of 8.1: the kernel streams
+// ~26 GB -- every k-mer line of the table is touched -- so it is bandwidth, not latency, that bounds it.)
 
 // exact symmetry proof of every local entry against the local table (single GPU)
 template <int W> __global__ void __launch_bounds__(F_TPB)

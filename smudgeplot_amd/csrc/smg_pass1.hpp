@@ -39,6 +39,10 @@
 #define R_WIN   30                       // partners are searched within +-30 entries
 #define R_CRED  (R_SCAN + 32)
 #define R_BIG   0x80000000u
+#ifndef R_D
+#define R_D     3                        // distances scanned in registers; farther partners: tail loop
+#endif
+#define R_QCAP  1536                     // LDS request queue (records); flushed when the next tile might not fit
 
 struct GeoR
 { int      k;
@@ -73,13 +77,13 @@ template <bool KF> SMG_DEV void r_unpack(u64 x, const GeoR &G, unsigned &pre, un
 // the 12 register tests of one thread: entries 0..3 are its own, 4..6 its right neighbour's
 template <bool ODD, bool CHECK> SMG_DEV void
 r_slots(const unsigned (&pre)[8], const unsigned (&suf)[8], const unsigned (&cn)[8], const GeoR &G,
-        unsigned (&acc)[7])
+        unsigned (&acc)[4 + R_D])
 {
 #pragma unroll
   for (int a = 0; a < 4; a++)
     {
 #pragma unroll
-      for (int d = 1; d <= 3; d++)
+      for (int d = 1; d <= R_D; d++)
         { const int b = a + d;
           const unsigned dd = suf[a] ^ suf[b];
           const unsigned tt = ((dd << 1) | dd) & 0xAAAAAAAAu;
@@ -153,22 +157,24 @@ r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict_
       if (t == R_TPB - 1) { S.ent[R_SCAN] = kk[4]; S.lcn[R_SCAN] = (uint16_t) cn[4]; }
     }
     //@mark P1_SLOTS
-    unsigned acc[7] = { 0, 0, 0, 0, 0, 0, 0 };
+    unsigned acc[4 + R_D];
+#pragma unroll
+    for (int e = 0; e < 4 + R_D; e++) acc[e] = 0;
     { unsigned mx = cn[0];
 #pragma unroll
-      for (int e = 1; e < 7; e++) mx = mx > cn[e] ? mx : cn[e];
+      for (int e = 1; e < 4 + R_D; e++) mx = mx > cn[e] ? mx : cn[e];
       if (__all(mx <= SMG_FMAX)) r_slots<ODD, false>(pre, suf, cn, G, acc);
       else                       r_slots<ODD, true>(pre, suf, cn, G, acc);
     }
     //@mark P1_CREDIT
     // every result goes to the entry's credit word (own entries too: frees the registers)
 #pragma unroll
-    for (int e = 0; e < 7; e++) atomicAdd(&S.cred[slot0 + e], acc[e]);     // unconditional: no VALU spent on tests
+    for (int e = 0; e < 4 + R_D; e++) atomicAdd(&S.cred[slot0 + e], acc[e]);     // unconditional: no VALU spent on tests
     // entries whose block continues past distance 3
     unsigned alive = 0;
 #pragma unroll
-    for (int r = 0; r < 4; r++) alive |= (unsigned) (pre[r] == pre[r + 4]) << r;
-    alive &= vmask & (vmask >> 4);
+    for (int r = 0; r < 4; r++) alive |= (unsigned) (pre[r] == pre[r + R_D + 1]) << r;
+    alive &= vmask & (vmask >> (R_D + 1));
     if (alive) S.tailq[atomicAdd(S.s_tn, 1u)] = (uint16_t) (t | (alive << 8));
   }
   lds_barrier();
@@ -185,7 +191,7 @@ r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict_
             unsigned pa, sfa, pb, sfb;
             r_unpack<KF>(S.ent[sa], G, pa, sfa);
             const unsigned ca = S.lcn[sa];
-            for (int d = 4; d <= R_WIN + 1; d++)
+            for (int d = R_D + 1; d <= R_WIN + 1; d++)
               { const int sb = sa + d;
                 unsigned cb;
                 if (!INNER && g0 + sb >= n) break;
@@ -300,7 +306,7 @@ kf_pass1_r(FastArgs A, GeoR G, uint32_t *__restrict__ bstart, u64 *__restrict__ 
   __shared__ uint16_t tailq[R_TPB];      // thread | alive mask << 8
   __shared__ u64      ent[R_SCAN + 4];   // the scanned k-mers (+ the first one of the next tile)
   __shared__ uint16_t lcn[R_SCAN + 4];
-  __shared__ u64      sq[R_OWN * RW];
+  __shared__ u64      sq[(RW == 1 ? R_QCAP : R_OWN) * RW];
   __shared__ uint32_t sbig[R_OWN];
   __shared__ u64      sfp[R_TPB / 64][2];
   __shared__ unsigned s_tn, s_qn, s_nbig, s_chunk, s_used, s_bigbase;
@@ -331,8 +337,11 @@ kf_pass1_r(FastArgs A, GeoR G, uint32_t *__restrict__ bstart, u64 *__restrict__ 
       if (t < (R_CRED - R_SCAN) / 4) *reinterpret_cast<uint4 *>(&cred[R_SCAN + slot0]) = make_uint4(0, 0, 0, 0);
 
       // ---- flush the request queue into this workgroup's chunk; publish deferred entries -----------------
+      // (RW == 1: only when the next tile might overflow the queue, or after this workgroup's last tile --
+      //  the barriers and the chunk bookkeeping of a flush cost as much as the copy itself)
       const unsigned qn = s_qn;
-      if (qn > 0)
+      const unsigned qcap = RW == 1 ? R_QCAP : R_OWN;
+      if (qn > 0 && (qn + R_OWN > qcap || tile + gridDim.x >= ntiles))
         { const unsigned old_chunk = s_chunk, old_used = s_used;
           const bool fresh = old_chunk == F_NOCHUNK || old_used + qn > F_CH;
           lds_barrier();

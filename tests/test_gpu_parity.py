@@ -301,3 +301,92 @@ def test_hetmers_on_raw_table_equals_reference_on_conditioned_table(k, tmp_path)
         subprocess.run([ORACLE_BIN, f"-e{L}", f"-o{tmp_path}/ref", str(tmp_path / "cond")], check=True)
     assert (tmp_path / "gpu.smu").read_text() == (tmp_path / "ref.smu").read_text()
     assert (tmp_path / "gpu.smu").read_text() != ""
+
+
+# ---- BASELINE config 3 at FULL size: size-independent properties (no CPU oracle finishes 2.5e9 entries) ----
+
+def _manual_sharded(k, tk, tc, cuts, dev, symcheck="hash"):
+    """the sharded protocol on ONE GPU: one engine per prefix shard, the request exchange done by hand"""
+    import torch
+    from smudgeplot_amd import sharded
+    world = len(cuts) - 1
+    keys_np = None
+    engs, sends, counts = [], [], []
+    firsts = [tk[c:c + 1].cpu().numpy().view(np.uint64) for c in cuts[1:-1]]
+    split = np.concatenate(firsts) if firsts else np.zeros(0, np.uint64)
+    for r in range(world):
+        en = sharded.TorchEngine(dev)
+        en.bind(k, tk[cuts[r]:cuts[r + 1]].clone(), tc[cuts[r]:cuts[r + 1]].clone())    # aligned copies
+        en.pass1(symcheck)
+        buf = torch.empty(max(en.nreq(), 1) * en.record_words(), dtype=torch.int64, device=dev)
+        counts.append(en.route(split, world, buf))
+        sends.append(buf); engs.append(en)
+    rw = engs[0].record_words()
+    fps = np.zeros(4, dtype=np.uint64)
+    for dst, en in enumerate(engs):
+        parts = []
+        for src in range(world):
+            off = sum(counts[src][:dst]) * rw
+            parts.append(sends[src][off: off + counts[src][dst] * rw])
+        recv = torch.cat(parts)
+        assert en.apply(recv, recv.numel() // rw) == 0
+        with np.errstate(over="ignore"):
+            fps = fps + np.array(en.symhash(), dtype=np.uint64)
+    assert fps[0] == fps[2] and fps[1] == fps[3]
+    total = torch.zeros(engine.PLOT_CELLS, dtype=torch.int64, device=dev)
+    for en in engs:
+        pl = torch.zeros(engine.PLOT_CELLS, dtype=torch.int64, device=dev)
+        en.pass2(pl)
+        total += pl
+    torch.cuda.synchronize()
+    return total, sum(sum(c) for c in counts)
+
+
+def test_full_size_config3_properties():
+    """Synthetic diploid 1 Gbp, 50x, k=31 (BASELINE configs[2], 2.5e9 entries, the bench workload):
+       idempotence, hash == exact symmetry proof, invariance under 3-way prefix sharding (uneven cuts),
+       and the mirror-image identity: on a symmetric table every pair has a distinct mirror image in the
+       same cell, except a pair {x, rc(x)} on the self-mirrored position, whose two counts are equal --
+       so every cell OFF the diagonal sum == 2*min holds an even number."""
+    import torch
+    from smudgeplot_amd import sharded, synth_device
+    k = 31
+    dev = torch.device("cuda:0")
+    free, _ = torch.cuda.mem_get_info()
+    G = 1_000_000_000 if free > 150e9 else 100_000_000
+    print(f"full-size property test: G={G}, free HBM {free / 1e9:.0f} GB")
+    tk, tc = synth_device.diploid_table(G, k=k, het=0.01, cov=50.0, L=10, seed=1, device=dev)
+    n = tc.numel()
+    assert n > 2.0 * G
+    torch.cuda.empty_cache()
+    plot = torch.zeros(engine.PLOT_CELLS, dtype=torch.int64, device=dev)
+    e = engine.Engine(0)
+    e.bind(k, n, tk.data_ptr(), tc.data_ptr())
+    st = e.run(plot.data_ptr(), "hash"); torch.cuda.synchronize()
+    assert st["path"] == 1
+    p_hash = plot.clone()
+    st = e.run(plot.data_ptr(), "hash"); torch.cuda.synchronize()
+    assert torch.equal(plot, p_hash), "idempotence"
+    st = e.run(plot.data_ptr(), "exact"); torch.cuda.synchronize()
+    assert st["path"] == 1 and torch.equal(plot, p_hash), "hash and exact proofs agree"
+    total = int(p_hash.sum().item())
+    assert total > n // 20
+    assert int(p_hash.view(1001, 501)[:, 500].sum().item()) >= 0
+    # sums above 1000 can never be counted; min <= sum / 2
+    pm = p_hash.view(1001, 501)
+    s_idx, m_idx = torch.nonzero(pm, as_tuple=True)
+    assert bool((2 * m_idx <= s_idx).all())
+    off_diag = pm[s_idx, m_idx][2 * m_idx != s_idx]
+    assert off_diag.numel() > 100 and bool((off_diag % 2 == 0).all()), "mirror-image identity"
+    del e
+    # 3 uneven prefix shards on one GPU
+    keys_first = tk
+    cuts = [0, n // 5, n // 5 + n // 2, n]
+    sh = 64 - 2 * (k // 2)
+    for i in (1, 2):
+        c = cuts[i]
+        while int(keys_first[c] >> sh) == int(keys_first[c - 1] >> sh):
+            c += 1
+        cuts[i] = c
+    tot, nsent = _manual_sharded(k, tk, tc, cuts, dev)
+    assert nsent > 0 and torch.equal(tot, p_hash), "prefix sharding does not change the plot"
