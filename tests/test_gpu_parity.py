@@ -390,3 +390,42 @@ def test_full_size_config3_properties():
         cuts[i] = c
     tot, nsent = _manual_sharded(k, tk, tc, cuts, dev)
     assert nsent > 0 and torch.equal(tot, p_hash), "prefix sharding does not change the plot"
+
+
+@pytest.mark.parametrize("k,m,seed", [(5, 25, 1), (5, 300, 11), (6, 80, 2), (6, 900, 12), (8, 600, 3), (8, 3000, 13), (9, 3000, 4), (12, 4000, 5),
+                                      (15, 4000, 6), (16, 4000, 7), (17, 4000, 8), (24, 3000, 9), (30, 3000, 10)])
+def test_small_and_even_k_vs_oracle(k, m, seed):
+    """k <= 16 (the k-mer lives in the upper 32-bit half only), dense tables with window blocks far longer
+    than the +-30 window (4^k possible k-mers), even k with self-complementary k-mers"""
+    packed, cnt = synth.adversarial_table(k, m, 4, seed, low_complexity=0, dense=0)
+    want = brute.hetmers_plot(packed, cnt, k)
+    assert want.sum() > 0 or m >= 300          # the dense small-k tables have no unique pair at all
+    for mode in ("hash", "exact", "none"):
+        plot, st = engine.hetmers_run(table_from(packed, cnt, k), symcheck=mode)
+        assert np.array_equal(plot, want), (k, mode)
+        assert st["path"] == (2 if mode == "none" else 1)
+
+
+@pytest.mark.parametrize("n_target", [991, 992, 993, 1023, 1024, 1025, 1983, 1984, 1985, 2976 + 32, 4 * 992 + 1])
+def test_table_sizes_around_the_pass1_tile(n_target):
+    """entry counts on and next to the tile edges of kf_pass1_r (992 owned + 32 halo entries)"""
+    k = 31
+    keys, cnt = synth.diploid_table_u64(1500, k=k, seed=n_target, het_frac=0.5, cov=30, L=5)
+    assert len(cnt) > n_target
+    # cut to the wanted size while keeping the table closed under reverse complement
+    rc = ktab.revcomp_u64(keys, k)
+    canon = np.minimum(keys, rc)
+    order = np.argsort(canon, kind="stable")
+    keep = np.zeros(len(keys), bool)
+    keep[order[: (n_target // 2) * 2]] = True              # whole {x, rc(x)} classes (odd k: always 2 members)
+    kk, cc = keys[keep], cnt[keep]
+    if n_target % 2:                                        # odd size: one extra entry breaks the symmetry
+        extra = order[(n_target // 2) * 2]
+        keep[extra] = True
+        kk, cc = keys[keep], cnt[keep]
+    assert len(cc) == n_target
+    packed = ktab.u64_to_packed(kk, k)
+    want = brute.hetmers_plot(packed, cc, k)
+    plot, st = engine.hetmers_run(table_from(packed, cc, k), symcheck="hash")
+    assert np.array_equal(plot, want)
+    assert st["path"] == (2 if n_target % 2 else 1)
