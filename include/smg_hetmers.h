@@ -102,6 +102,22 @@ typedef struct smg_stats
 int smg_hetmers_run(const smg_table_view *table, const smg_opts *opts, int64_t *plot,
                     smg_stats *stats, char *errbuf, size_t errlen);
 
+/* ---- extract: the pairs behind the labelled pixels ----------------------------------------
+   Replaces the compute section of extract_kmer_pairs, src/lib/PloidyList.c:1207-1583 (same two
+   passes as hetmers; the pass-2 sink prints the pair instead of counting it, PloidyList.c:424-448).
+   labels: host uint16[SMG_PLOT_CELLS], labels[sum*501+min] = 1-based smudge number of the pixel, 0 =
+   not annotated (PloidyList.c:1312-1346 PLOT[i+j][i] = s+1).
+   *records: malloc'ed by the library (release with smg_free), *nrec records of *rec_words uint64:
+     words 0 .. rec_words-2 : the k-mer to print, left aligned (base 0 in bits 63..62 of word 0)
+     last word              : variant position | alt base (0..3 = acgt) << 8 | label << 16
+   One record per printed line of the reference (print_het, PloidyList.c:128-165); the order of the
+   records is unspecified (so is the order of the reference's lines: mutex-guarded fprintf from threads).
+   plot receives the same histogram smg_hetmers_run computes.  Needs k <= 85.                   */
+int smg_hetmers_extract(const smg_table_view *table, const smg_opts *opts, const uint16_t *labels,
+                        int64_t *plot, uint64_t **records, int64_t *nrec, int *rec_words,
+                        smg_stats *stats, char *errbuf, size_t errlen);
+void smg_free(void *p);
+
 /* number of usable HIP devices (0 when there is none or the runtime is missing)             */
 int smg_device_count(void);
 
@@ -171,6 +187,12 @@ int     smg_engine_apply_own(smg_engine *e, int64_t *missing, char *errbuf, size
 int     smg_engine_symhash(smg_engine *e, uint64_t out[4], char *errbuf, size_t errlen);
 int     smg_engine_pass2(smg_engine *e, int64_t *d_plot, char *errbuf, size_t errlen);
 int     smg_engine_stats(smg_engine *e, smg_stats *stats);
+
+/* extract leg on an engine whose run has completed on the symmetric path: d_labels = device
+   uint16[SMG_PLOT_CELLS]; d_out = device buffer of `capacity` records (may be NULL with capacity 0
+   to count only); *nrec = records produced (compare with capacity).                            */
+int     smg_engine_extract(smg_engine *e, const uint16_t *d_labels, uint64_t *d_out, int64_t capacity,
+                           int64_t *nrec, char *errbuf, size_t errlen);
 
 /* library / build identification, e.g. "smudgeplot_amd 0.1 gfx950" */
 const char *smg_version(void);

@@ -518,6 +518,99 @@ kf_pass2(FastArgs A, u64 *__restrict__ plot)
     }
 }
 
+// ---- extract: pass 2 with another sink (reference: extract_kmer_pairs, src/lib/PloidyList.c) ------------
+// Every pair that enters the plot at a LABELLED pixel (labels[sum*501+min] > 0, from the .sma file,
+// PloidyList.c:1312-1346) yields one record per represented pair: the k-mer to print (the member with the
+// larger count; ties: the one with the smaller base at the variant position, PloidyList.c:430-446),
+// then  position | alt base << 8 | label << 16.  A pair found at p != k-1-p also stands for its mirror
+// image (rc of both members at k-1-p), which the reference finds and prints separately.
+// Records are staged in LDS and appended with one global atomic per flush.
+#define EX_STAGE 1024                   // records per workgroup staging buffer
+
+template <int W> SMG_DEV unsigned base_at(const Key<W> &x, int p)
+{ unsigned b = 0;
+#pragma unroll
+  for (int w = 0; w < W; w++)
+    if (w == (p >> 5)) b = (unsigned) (x.w[w] >> (62 - 2 * (p & 31))) & 3u;
+  return b;
+}
+
+template <int W> __global__ void __launch_bounds__(F_TPB)
+kf_extract(FastArgs A, const uint16_t *__restrict__ labels, u64 *__restrict__ out, u64 capacity,
+           u64 *__restrict__ total)
+{ __shared__ u64      stage[EX_STAGE * (W + 1)];
+  __shared__ unsigned s_n;
+  __shared__ u64      s_base;
+  const int t = threadIdx.x;
+  const int k = A.g.k;
+  if (t == 0) s_n = 0;
+  __syncthreads();
+  const int64_t step = (int64_t) gridDim.x * F_TPB;
+  const int64_t rounds = (A.n + step - 1) / step;
+  for (int64_t rd = 0; rd < rounds; rd++)
+    { const int64_t i = rd * step + (int64_t) blockIdx.x * F_TPB + t;
+      if (i < A.n)
+        { const unsigned ci = A.code[i], lo6 = ci & 63;
+          if (lo6 >= 32 && lo6 != CODE_MULTI)                     // unique pair, partner above
+            { int64_t j;
+              unsigned w2 = (ci & CODE_W2) != 0;
+              bool ok = true;
+              if (lo6 == CODE_FAR) { far_partner<W>(A, i, j, w2); ok = j > i; }
+              else j = i + (int) lo6 - 31;
+              if (ok)
+                { const unsigned lj = A.code[j] & 63;
+                  ok = lj != CODE_NONE && lj != CODE_MULTI && !(A.pflag[i] | A.pflag[j]);
+                }
+              if (ok)
+                { const unsigned ni = A.cnt[i], nj = A.cnt[j];
+                  const unsigned s = ni + nj, m = ni < nj ? ni : nj;
+                  const unsigned lab = labels[(size_t) s * SMG_PLOT_COLS + m];
+                  if (lab)
+                    { const Key<W> xi = load_key<W>(A.keys, i), xj = load_key<W>(A.keys, j);
+                      const int p = pair_pos<W>(xi, xj);
+                      const unsigned bi = base_at<W>(xi, p), bj = base_at<W>(xj, p);     // bi < bj (i < j)
+                      const unsigned nrec = w2 ? 2u : 1u;
+                      const unsigned q = atomicAdd(&s_n, nrec);
+                      // the pair itself: a = i (smaller base); cnt[a] < cnt[b] prints b with alt base of a
+                      { const bool pj = ni < nj;
+                        const Key<W> &who = pj ? xj : xi;
+                        u64 *o = stage + (size_t) q * (W + 1);
+#pragma unroll
+                        for (int w = 0; w < W; w++) o[w] = who.w[w];
+                        o[W] = (u64) p | ((u64) (pj ? bi : bj) << 8) | ((u64) lab << 16);
+                      }
+                      if (w2)
+                        { // mirror image at k-1-p: a = rc(xj) (base 3-bj is the smaller one), b = rc(xi)
+                          const bool pb = nj < ni;                  // cnt[a] < cnt[b]: print b = rc(xi)
+                          const Key<W> who = revcomp<W>(pb ? xi : xj, k);
+                          u64 *o = stage + (size_t) (q + 1) * (W + 1);
+#pragma unroll
+                          for (int w = 0; w < W; w++) o[w] = who.w[w];
+                          o[W] = (u64) (k - 1 - p) | ((u64) (pb ? 3u - bj : 3u - bi) << 8) | ((u64) lab << 16);
+                        }
+                    }
+                }
+            }
+        }
+      __syncthreads();
+      // flush when the next round might not fit (a round adds at most 2 records per thread)
+      const unsigned have = s_n;
+      __syncthreads();                       // everybody has read s_n before thread 0 resets it
+      if (have + 2 * F_TPB > EX_STAGE || rd + 1 == rounds)
+        { if (have)
+            { if (t == 0) { s_base = atomicAdd(total, (u64) have); s_n = 0; }
+              __syncthreads();
+              const u64 base = s_base;
+              for (unsigned e = t; e < have * (W + 1); e += F_TPB)
+                { const u64 r = base + e / (W + 1);
+                  if (r < capacity) out[r * (W + 1) + e % (W + 1)] = stage[e];
+                }
+            }
+          __syncthreads();
+        }
+    }
+}
+
 // total weight in the plot (stat only)
 __global__ void __launch_bounds__(1024) kf_plot_sum(const u64 *__restrict__ plot, u64 *__restrict__ out)
 { __shared__ u64 part[16];

@@ -1338,10 +1338,40 @@ extern "C" int smg_engine_condition(smg_engine *e, int ethresh, int do_trim, int
   return SMG_OK;
 }
 
+// ---- extract: the unique pairs of the labelled pixels (next row of the scope table: extract_kmer_pairs) ------
+
+extern "C" int smg_engine_extract(smg_engine *e, const uint16_t *d_labels, uint64_t *d_out, int64_t capacity,
+                                  int64_t *nrec, char *errbuf, size_t errlen)
+{ if (!e || !d_labels || !nrec) return fail(errbuf, errlen, SMG_EINVAL, "null argument%s");
+  if (!e->prepared || !e->fast || e->st.path != 1)
+    return fail(errbuf, errlen, SMG_EINVAL,
+                "extract needs a completed run on a conditioned (reverse-complement closed) table with k <= 85%s");
+  HIPCHK(hipSetDevice(e->device));
+  u64 *d_total = &e->ctrl->plot_sum;
+  HIPCHK(hipMemsetAsync(d_total, 0, sizeof(u64), e->stream));
+  if (e->n > 0)
+    { FastArgs a = make_fast(e);
+      int64_t nb = (e->n + F_TPB - 1) / F_TPB;
+      if (nb > 2048) nb = 2048;
+#define CALL(WW) hipLaunchKernelGGL(kf_extract<WW>, dim3((unsigned) nb), dim3(F_TPB), 0, e->stream, a, d_labels, \
+                   (u64 *) d_out, (u64) (d_out ? capacity : 0), d_total)
+      DISPATCH_W3(e, CALL)
+#undef CALL
+    }
+  HIPCHK(hipGetLastError());
+  int rc = read_ctrl(e, errbuf, errlen);
+  if (rc) return rc;
+  *nrec = (int64_t) e->h_ctrl->plot_sum;
+  return SMG_OK;
+}
+
 // ---- one-shot host entry ----------------------------------------------------------------------
 
-extern "C" int smg_hetmers_run(const smg_table_view *tv, const smg_opts *opts, int64_t *plot,
-                               smg_stats *stats, char *errbuf, size_t errlen)
+// labels == NULL: hetmers.  labels != NULL: additionally the extract leg; *records receives a malloc'ed
+// array of *nrec records of (words + 1) uint64 each.
+static int host_run(const smg_table_view *tv, const smg_opts *opts, int64_t *plot, smg_stats *stats,
+                    const uint16_t *labels, uint64_t **records, int64_t *nrec, int *rec_words,
+                    char *errbuf, size_t errlen)
 { if (!tv || !plot) return fail(errbuf, errlen, SMG_EINVAL, "null argument%s");
   const int device = opts ? opts->device : 0;
   const int symcheck = opts ? opts->symcheck : SMG_SYM_EXACT;
@@ -1357,6 +1387,7 @@ extern "C" int smg_hetmers_run(const smg_table_view *tv, const smg_opts *opts, i
   if (!e) return SMG_ENODEV;
   int rc = SMG_OK;
   uint8_t *d_rec = NULL; int64_t *d_index = NULL, *d_plot = NULL;
+  uint16_t *d_labels = NULL; uint64_t *d_out = NULL;
   const size_t ixbytes = sizeof(int64_t) << (8 * tv->ibyte);
   hipEvent_t h0, h1;
   hipEventCreate(&h0); hipEventCreate(&h1);
@@ -1387,6 +1418,26 @@ extern "C" int smg_hetmers_run(const smg_table_view *tv, const smg_opts *opts, i
   if ((rc = smg_engine_run(e, symcheck, d_plot, NULL, errbuf, errlen))) goto done;
   if (hipMemcpy(plot, d_plot, sizeof(int64_t) * SMG_PLOT_CELLS, hipMemcpyDeviceToHost) != hipSuccess)
     BAIL(SMG_ENODEV, "device to host copy failed")
+  if (labels)
+    { // exact record count = plot weight on the labelled pixels (the plot counts a mirrored pair twice)
+      if (e->st.path != 1)
+        BAIL(SMG_EINVAL, "extract needs a trimmed, reverse-complement closed table with k <= 85")
+      int64_t want = 0, got = 0;
+      for (int c = 0; c < SMG_PLOT_CELLS; c++) if (labels[c]) want += plot[c];
+      const int rw = e->W + 1;
+      if (hipMalloc(&d_labels, sizeof(uint16_t) * SMG_PLOT_CELLS) != hipSuccess
+          || hipMalloc(&d_out, sizeof(uint64_t) * (size_t) (want > 0 ? want : 1) * rw) != hipSuccess)
+        BAIL(SMG_ENOMEM, "out of device memory for the pair list")
+      if (hipMemcpy(d_labels, labels, sizeof(uint16_t) * SMG_PLOT_CELLS, hipMemcpyHostToDevice) != hipSuccess)
+        BAIL(SMG_ENODEV, "host to device copy failed")
+      if ((rc = smg_engine_extract(e, d_labels, d_out, want, &got, errbuf, errlen))) goto done;
+      if (got != want) BAIL(SMG_ENODEV, "internal error: pair list and plot disagree")
+      uint64_t *h = (uint64_t *) malloc(sizeof(uint64_t) * (size_t) (want > 0 ? want : 1) * rw);
+      if (!h) BAIL(SMG_ENOMEM, "out of host memory for the pair list")
+      if (want && hipMemcpy(h, d_out, sizeof(uint64_t) * (size_t) want * rw, hipMemcpyDeviceToHost) != hipSuccess)
+        { free(h); BAIL(SMG_ENODEV, "device to host copy failed") }
+      *records = h; *nrec = want; *rec_words = rw;
+    }
   { float ms = 0; hipEventElapsedTime(&ms, h0, h1); e->st.ms_h2d = ms; }
   if (stats) *stats = e->st;
   if (verbose)
@@ -1401,6 +1452,22 @@ done:
   if (d_rec) hipFree(d_rec);
   if (d_index) hipFree(d_index);
   if (d_plot) hipFree(d_plot);
+  if (d_labels) hipFree(d_labels);
+  if (d_out) hipFree(d_out);
   smg_engine_destroy(e);
   return rc;
 }
+
+extern "C" int smg_hetmers_run(const smg_table_view *tv, const smg_opts *opts, int64_t *plot,
+                               smg_stats *stats, char *errbuf, size_t errlen)
+{ return host_run(tv, opts, plot, stats, NULL, NULL, NULL, NULL, errbuf, errlen); }
+
+extern "C" int smg_hetmers_extract(const smg_table_view *tv, const smg_opts *opts, const uint16_t *labels,
+                                   int64_t *plot, uint64_t **records, int64_t *nrec, int *rec_words,
+                                   smg_stats *stats, char *errbuf, size_t errlen)
+{ if (!labels || !records || !nrec || !rec_words) return fail(errbuf, errlen, SMG_EINVAL, "null argument%s");
+  *records = NULL; *nrec = 0; *rec_words = 0;
+  return host_run(tv, opts, plot, stats, labels, records, nrec, rec_words, errbuf, errlen);
+}
+
+extern "C" void smg_free(void *p) { free(p); }

@@ -61,7 +61,7 @@ EXPORTS = [
     "smg_engine_decode", "smg_engine_bind", "smg_engine_condition", "smg_engine_run", "smg_engine_pass1",
     "smg_engine_nreq", "smg_engine_record_words", "smg_engine_route", "smg_engine_apply",
     "smg_engine_apply_own", "smg_engine_symhash", "smg_engine_pass2", "smg_engine_stats",
-    "smg_version",
+    "smg_engine_extract", "smg_hetmers_extract", "smg_free", "smg_version",
 ]
 
 _lib = None
@@ -124,6 +124,10 @@ def load_library():
     lib.smg_engine_symhash.argtypes = [vp, C.POINTER(C.c_uint64), *err]
     lib.smg_engine_pass2.argtypes = [vp, vp, *err]
     lib.smg_engine_stats.argtypes = [vp, C.POINTER(Stats)]
+    lib.smg_engine_extract.argtypes = [vp, vp, vp, i64, C.POINTER(i64), *err]
+    lib.smg_hetmers_extract.argtypes = [C.POINTER(TableView), C.POINTER(Opts), vp, vp, C.POINTER(vp),
+                                        C.POINTER(i64), C.POINTER(i32), C.POINTER(Stats), *err]
+    lib.smg_free.argtypes = [vp]
     _lib = lib
     return lib
 
@@ -150,6 +154,18 @@ def hetmers_run(table, device: int = 0, symcheck: str = "exact", verbose: int = 
     (reference: main(), src/lib/PloidyPlot.c:1433-1575).
     """
     lib = load_library()
+    tv, keep = _table_view(table)
+    opts = Opts(device, _SYM[symcheck], verbose, condition, ethresh, 0)
+    plot = np.zeros(PLOT_CELLS, dtype=np.int64)
+    st = Stats()
+    buf = C.create_string_buffer(512)
+    rc = lib.smg_hetmers_run(C.byref(tv), C.byref(opts), plot.ctypes.data, C.byref(st), buf, 512)
+    _check(rc, buf)
+    return plot.reshape(PLOT_ROWS, PLOT_COLS), st.asdict()
+
+
+def _table_view(table):
+    """`ktab.KTable` -> (TableView, objects that must stay alive while it is used)"""
     kb = (table.k + 3) >> 2
     pb = kb + 2 - table.ibyte
     n = table.nels
@@ -167,13 +183,42 @@ def hetmers_run(table, device: int = 0, symcheck: str = "exact", verbose: int = 
                    C.cast(ptrs, C.POINTER(C.c_void_p)),
                    pn.ctypes.data_as(C.POINTER(C.c_int64)),
                    idx.ctypes.data_as(C.POINTER(C.c_int64)))
-    opts = Opts(device, _SYM[symcheck], verbose, condition, ethresh, 0)
+    return tv, (parts, ptrs, pn, idx)
+
+
+def hetmers_extract(table, labels: dict, device: int = 0, symcheck: str = "hash", condition: int = 0,
+                    ethresh: int = 0):
+    """In-process equivalent of `extract_kmer_pairs` (reference: src/lib/PloidyList.c).
+    labels: {(covB, covA): "<a>A<b>B"} as read from a .sma file.
+    -> (plot, {smudge name: list of text lines as the reference prints them (order unspecified)})"""
+    lib = load_library()
+    tv, keep = _table_view(table)
+    names = sorted(set(labels.values()))
+    lab = np.zeros(PLOT_CELLS, dtype=np.uint16)
+    for (cb, ca), name in labels.items():
+        lab[(ca + cb) * PLOT_COLS + cb] = names.index(name) + 1
+    opts = Opts(device, _SYM[symcheck], 0, condition, ethresh, 0)
     plot = np.zeros(PLOT_CELLS, dtype=np.int64)
     st = Stats()
     buf = C.create_string_buffer(512)
-    rc = lib.smg_hetmers_run(C.byref(tv), C.byref(opts), plot.ctypes.data, C.byref(st), buf, 512)
+    recs, nrec, rw = C.c_void_p(), C.c_int64(0), C.c_int(0)
+    rc = lib.smg_hetmers_extract(C.byref(tv), C.byref(opts), lab.ctypes.data, plot.ctypes.data, C.byref(recs),
+                                 C.byref(nrec), C.byref(rw), C.byref(st), buf, 512)
     _check(rc, buf)
-    return plot.reshape(PLOT_ROWS, PLOT_COLS), st.asdict()
+    n, w = int(nrec.value), int(rw.value)
+    arr = np.ctypeslib.as_array(C.cast(recs, C.POINTER(C.c_uint64)), shape=(max(n, 1) * w,))[: n * w].copy().reshape(n, w)
+    lib.smg_free(recs)
+    out = {name: [] for name in names}
+    dna = "acgt"
+    for row in arr:
+        meta = int(row[w - 1])
+        pos, alt, label = meta & 0xFF, (meta >> 8) & 3, meta >> 16
+        bases = []
+        for q in range(table.k):
+            bases.append((int(row[q >> 5]) >> (62 - 2 * (q & 31))) & 3)
+        out[names[label - 1]].append("".join(dna[b] for b in bases[:pos]) + f"({dna[bases[pos]]}/{dna[alt]})"
+                                     + "".join(dna[b] for b in bases[pos + 1:]) + "\n")
+    return plot.reshape(PLOT_ROWS, PLOT_COLS), out
 
 
 def smu_text(plot: np.ndarray) -> str:
