@@ -47,9 +47,11 @@ static void system_x(const char *command)       /* SystemX, gene_core.c:19-24 */
     }
 }
 
+static int Load_Threads = 1;           /* -T: host threads that read the part files */
+
 static void load_or_die(const char *name, smg_ktab *T)
 { char what[4096];
-  switch (smg_ktab_load(name, T, what))
+  switch (smg_ktab_load_mt(name, T, what, Load_Threads))
   { case SMG_KTAB_OK:
       return;
     case SMG_KTAB_NOSTUB:
@@ -149,6 +151,7 @@ static char *smg_cli_open_table(const smg_cli *c, const char *SRC, smg_ktab *T, 
   if (tname == NULL || command == NULL)
     { fprintf(stderr, "%s: Out of memory (Allocating strings)\n", Prog_Name); exit(1); }
 
+  Load_Threads = c->nthreads;
   load_or_die(SRC, T);
   smg_ktab_examine(T, c->ethresh, &trim, &symm);
 

@@ -43,8 +43,8 @@
 #define CODE_DEFER  0xFF                  // placeholder until kf_bigfix has redone the entry
 
 #define P2_TPB   1024
-#define P2_SMAX  256                  // LDS plot tile covers sums < P2_SMAX
-#define P2_CELLS ((P2_SMAX / 2) * (P2_SMAX / 2 + 1))     // 16512
+#define P2_SMAX  208                  // LDS plot tile covers sums < P2_SMAX (43.7 KB; with the 32 KB queue: 2 WGs/CU)
+#define P2_CELLS ((P2_SMAX / 2) * (P2_SMAX / 2 + 1))     // 10920
 
 struct FastArgs
 { const u64      *keys;
@@ -430,13 +430,32 @@ far_partner(const FastArgs &A, int64_t i, int64_t &partner, unsigned &w2)
 
 #define P2_VEC   16                       // consecutive entries per thread: one 16-byte code load
 #define P2_TILE  (P2_TPB * P2_VEC)        // 16384 entries per workgroup iteration
-#define P2_QCAP  P2_TILE                  // "far" codes can make every entry a candidate
+#define P2_QCAP  (P2_TILE / 2)            // candidates beyond half of a tile are handled where they are found (rare)
 
 // Phase A: every thread inspects 16 code bytes and pushes its "unique pair, partner above"
 //          candidates into an LDS queue (wave-aggregated slot allocation).
 // Phase B: the queue is drained densely, one candidate per lane: the five dependent-free loads
 //          (partner code, two P flags, two counts) are issued together -- walking the candidates
 //          inside the 16-entry loop serialised one memory round trip per entry (r01_v2 profile).
+template <int W> SMG_DEV void
+p2_candidate(const FastArgs &A, unsigned *tile, u64 *__restrict__ plot, int64_t i, unsigned ci)
+{ const unsigned lo6 = ci & 63;
+  int64_t j;
+  unsigned w2 = (ci & CODE_W2) != 0;
+  if (lo6 == CODE_FAR)
+    { far_partner<W>(A, i, j, w2);
+      if (j <= i) return;
+    }
+  else
+    j = i + (int) lo6 - 31;
+  const unsigned cj = A.code[j], pi = A.pflag[i], pj = A.pflag[j];
+  const unsigned ni = A.cnt[i], nj = A.cnt[j];
+  const unsigned lj = cj & 63;
+  if (lj == CODE_NONE || lj == CODE_MULTI) return;    // partner has several pairs
+  if (pi | pj) return;                                // a prefix-side pair exists too
+  plot_bump(tile, plot, ni, nj, w2 ? 2u : 1u);
+}
+
 template <int W> __global__ void __launch_bounds__(P2_TPB)
 kf_pass2(FastArgs A, u64 *__restrict__ plot)
 { __shared__ unsigned tile[P2_CELLS];
@@ -469,7 +488,11 @@ kf_pass2(FastArgs A, u64 *__restrict__ plot)
                   unsigned qb = 0;
                   if (lane == lead) qb = atomicAdd(&s_qn, (unsigned) __popcll(m));
                   qb = __shfl(qb, lead, 64);
-                  if (cand) queue[qb + __popcll(m & ((1ull << lane) - 1))] = (unsigned) li | (ci << 16);
+                  if (cand)
+                    { const unsigned slot = qb + __popcll(m & ((1ull << lane) - 1));
+                      if (slot < P2_QCAP) queue[slot] = (unsigned) li | (ci << 16);
+                      else p2_candidate<W>(A, tile, plot, c0 + li, ci);      // queue full: rare, done in place
+                    }
                 }
             }
         }
@@ -479,25 +502,10 @@ kf_pass2(FastArgs A, u64 *__restrict__ plot)
       if (nx < A.n) cv = *reinterpret_cast<const uint4 *>(A.code + nx);
       lds_barrier();
       // ---- phase B ----
-      const unsigned qn = s_qn;
+      const unsigned qn = s_qn < P2_QCAP ? s_qn : P2_QCAP;
       for (unsigned q = t; q < qn; q += P2_TPB)
         { const unsigned e = queue[q];
-          const unsigned ci = e >> 16, lo6 = ci & 63;
-          const int64_t i = c0 + (e & 0xFFFF);
-          int64_t j;
-          unsigned w2 = (ci & CODE_W2) != 0;
-          if (lo6 == CODE_FAR)
-            { far_partner<W>(A, i, j, w2);
-              if (j <= i) continue;
-            }
-          else
-            j = i + (int) lo6 - 31;
-          const unsigned cj = A.code[j], pi = A.pflag[i], pj = A.pflag[j];
-          const unsigned ni = A.cnt[i], nj = A.cnt[j];
-          const unsigned lj = cj & 63;
-          if (lj == CODE_NONE || lj == CODE_MULTI) continue;  // partner has several pairs
-          if (pi | pj) continue;                              // a prefix-side pair exists too
-          plot_bump(tile, plot, ni, nj, w2 ? 2u : 1u);
+          p2_candidate<W>(A, tile, plot, c0 + (e & 0xFFFF), e >> 16);
         }
       lds_barrier();
       if (t == 0) s_qn = 0;

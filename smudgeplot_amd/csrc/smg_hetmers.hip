@@ -384,7 +384,7 @@ k_pass2(Tab t, int64_t lo, int64_t hi, u64 *__restrict__ plot)
 #define FAST_MAX_K   85        // above this a uint8 degree can wrap: counted path (v1 kernels)
 #define P1_GRID      1280      // persistent workgroups of the generic kf_pass1<W> (5 per CU resident: LDS bound)
 #define P1_MAXGRID   4096      // upper bound of any pass-1 grid (partial fingerprint sums)
-#define P2_GRID      512       // persistent workgroups of kf_pass2 (2 per CU, 66 KB LDS each)
+#define P2_GRID      512       // persistent workgroups of kf_pass2 (2 per CU: 43.7 KB plot tile + 32 KB queue each)
 
 struct smg_engine
 { int          device;

@@ -7,6 +7,7 @@
 #include <fcntl.h>
 #include <unistd.h>
 #include <sys/stat.h>
+#include <pthread.h>
 
 #include "smg_ktab.h"
 
@@ -20,7 +21,38 @@ static int read_full(int fd, void *buf, size_t n)
   return 0;
 }
 
+/* ---- parallel part reader: the -T threads of the command line pread 32 MB chunks (the reference streams
+        the parts through per-thread Kmer_Stream clones, PloidyPlot.c:1476-1479; here the whole table goes to
+        the GPU, so host threads are only useful for getting it off the disk / out of the page cache) ---- */
+#define SMG_CHUNK ((size_t) 32 << 20)
+
+typedef struct { int fd; off_t off; uint8_t *dst; size_t len; } smg_chunk;
+typedef struct { smg_chunk *ch; long n; long next; int failed; pthread_mutex_t mu; } smg_chunkq;
+
+static void *chunk_worker(void *arg)
+{ smg_chunkq *q = (smg_chunkq *) arg;
+  for (;;)
+    { long i;
+      pthread_mutex_lock(&q->mu);
+      i = q->next++;
+      pthread_mutex_unlock(&q->mu);
+      if (i >= q->n) break;
+      { smg_chunk *c = q->ch + i;
+        size_t done = 0;
+        while (done < c->len)
+          { ssize_t r = pread(c->fd, c->dst + done, c->len - done, c->off + (off_t) done);
+            if (r <= 0) { q->failed = 1; break; }
+            done += (size_t) r;
+          }
+      }
+    }
+  return NULL;
+}
+
 int smg_ktab_load(const char *name, smg_ktab *t, char *what)
+{ return smg_ktab_load_mt(name, t, what, 1); }
+
+int smg_ktab_load_mt(const char *name, smg_ktab *t, char *what, int nthreads)
 { const char *slash = strrchr(name, '/');
   char  *dir, *root, *path;
   size_t len;
@@ -58,24 +90,57 @@ int smg_ktab_load(const char *name, smg_ktab *t, char *what)
     { close(fd); rc = SMG_KTAB_SHORT; goto out; }
   close(fd);
 
-  for (p = 1; p <= t->nparts; p++)
-    { int32_t km; int64_t n;
-      sprintf(path, "%s/.%s.ktab.%d", dir, root, p);
-      if (what) snprintf(what, 4096, "%s", path);
-      fd = open(path, O_RDONLY);
-      if (fd < 0) { rc = SMG_KTAB_NOPART; goto out; }
-      if (read_full(fd, &km, 4) || read_full(fd, &n, 8)) { close(fd); rc = SMG_KTAB_SHORT; goto out; }
-      if (km != t->kmer) { close(fd); rc = SMG_KTAB_KMISMATCH; goto out; }
-      if (n < 0) { close(fd); rc = SMG_KTAB_SHORT; goto out; }
-      t->part[p - 1] = (uint8_t *) malloc((size_t) (n > 0 ? n : 1) * (size_t) t->pbyte);
-      if (!t->part[p - 1]) { close(fd); rc = SMG_KTAB_NOMEM; goto out; }
-      if (n > 0 && read_full(fd, t->part[p - 1], (size_t) n * (size_t) t->pbyte))
-        { close(fd); rc = SMG_KTAB_SHORT; goto out; }
-      close(fd);
-      t->part_nels[p - 1] = n;
-      t->nels += n;
-      t->part_end[p - 1] = t->nels;
-    }
+  { int *fds = (int *) malloc(sizeof(int) * (size_t) (t->nparts > 0 ? t->nparts : 1));
+    smg_chunkq q;
+    long cap = 0;
+    int  opened = 0;
+    memset(&q, 0, sizeof(q));
+    if (!fds) { rc = SMG_KTAB_NOMEM; goto out; }
+    for (p = 1; p <= t->nparts && rc == SMG_KTAB_OK; p++)
+      { int32_t km; int64_t n;
+        struct stat sb;
+        sprintf(path, "%s/.%s.ktab.%d", dir, root, p);
+        if (what) snprintf(what, 4096, "%s", path);
+        fd = open(path, O_RDONLY);
+        if (fd < 0) { rc = SMG_KTAB_NOPART; break; }
+        fds[opened++] = fd;
+        if (read_full(fd, &km, 4) || read_full(fd, &n, 8)) { rc = SMG_KTAB_SHORT; break; }
+        if (km != t->kmer) { rc = SMG_KTAB_KMISMATCH; break; }
+        if (n < 0 || fstat(fd, &sb) != 0 || (int64_t) sb.st_size < 12 + n * (int64_t) t->pbyte)
+          { rc = SMG_KTAB_SHORT; break; }
+        t->part[p - 1] = (uint8_t *) malloc((size_t) (n > 0 ? n : 1) * (size_t) t->pbyte);
+        if (!t->part[p - 1]) { rc = SMG_KTAB_NOMEM; break; }
+        t->part_nels[p - 1] = n;
+        t->nels += n;
+        t->part_end[p - 1] = t->nels;
+        { size_t bytes = (size_t) n * (size_t) t->pbyte, o;
+          for (o = 0; o < bytes; o += SMG_CHUNK)
+            { if (q.n >= cap)
+                { cap = cap ? 2 * cap : 256;
+                  q.ch = (smg_chunk *) realloc(q.ch, sizeof(smg_chunk) * (size_t) cap);
+                  if (!q.ch) { rc = SMG_KTAB_NOMEM; break; }
+                }
+              q.ch[q.n].fd = fd; q.ch[q.n].off = (off_t) (12 + o); q.ch[q.n].dst = t->part[p - 1] + o;
+              q.ch[q.n].len = bytes - o < SMG_CHUNK ? bytes - o : SMG_CHUNK;
+              q.n++;
+            }
+        }
+      }
+    if (rc == SMG_KTAB_OK && q.n > 0)
+      { pthread_t th[64];
+        int nt = nthreads < 1 ? 1 : (nthreads > 64 ? 64 : nthreads), i, started = 0;
+        if ((long) nt > q.n) nt = (int) q.n;
+        pthread_mutex_init(&q.mu, NULL);
+        for (i = 1; i < nt; i++)
+          if (pthread_create(&th[started], NULL, chunk_worker, &q) == 0) started++;
+        chunk_worker(&q);
+        for (i = 0; i < started; i++) pthread_join(th[i], NULL);
+        pthread_mutex_destroy(&q.mu);
+        if (q.failed) rc = SMG_KTAB_SHORT;
+      }
+    while (opened > 0) close(fds[--opened]);
+    free(fds); free(q.ch);
+  }
 out:
   free(dir); free(root); free(path);
   if (rc != SMG_KTAB_OK) smg_ktab_free(t);

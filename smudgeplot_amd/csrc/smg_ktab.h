@@ -31,6 +31,8 @@ typedef struct smg_ktab
 
 /* name: "<path>[.ktab]".  On failure `what` (>= 4096 bytes) receives the offending file name. */
 int  smg_ktab_load(const char *name, smg_ktab *t, char *what);
+/* same, the part files read by `nthreads` threads (the -T of the command line, <= 64)           */
+int  smg_ktab_load_mt(const char *name, smg_ktab *t, char *what, int nthreads);
 void smg_ktab_free(smg_ktab *t);
 
 /* expand entry i into kbyte packed bytes (Current_Entry, libfastk.c:1230-1269) + its count     */

@@ -13,13 +13,20 @@ sys.path.insert(0, ROOT)
 from smudgeplot_amd import ktab, synth, synth_device
 
 G = int(float(sys.argv[1])) if len(sys.argv) > 1 else 12_000_000
-k, L = 31, 12
+KIND = sys.argv[2] if len(sys.argv) > 2 else "tetraploid"      # or "diploid" (BASELINE configs[2] generator)
+SKIP_T1 = len(sys.argv) > 3 and sys.argv[3] in ("skipT1", "oursOnly")
+OURS_ONLY = len(sys.argv) > 3 and sys.argv[3] == "oursOnly"
+k, L = 31, (12 if KIND == "tetraploid" else 10)
 dev = torch.device("cuda:0")
-tk, tc = synth_device.polyploid_table(G, ploidy=4, div=0.01, cov_hap=25.0, k=k, L=L, seed=3265401, device=dev)
+if KIND == "tetraploid":
+    tk, tc = synth_device.polyploid_table(G, ploidy=4, div=0.01, cov_hap=25.0, k=k, L=L, seed=3265401, device=dev)
+else:
+    tk, tc = synth_device.diploid_table(G, k=k, het=0.01, cov=50.0, L=L, seed=1, device=dev)
 keys = tk.cpu().numpy().view(np.uint64); cnt = tc.cpu().numpy().view(np.uint16)
 ref = os.path.join(ROOT, "oracle", "_ref", "hetmers_ref")
 ours = os.path.join(ROOT, "smudgeplot_amd", "bin", "hetmers")
-out = {"workload": f"synthetic tetraploid {G} bp, 1% divergence, 25x per haplotype, k={k}, L={L}", "entries": int(len(cnt)),
+out = {"workload": (f"synthetic tetraploid {G} bp, 1% divergence, 25x per haplotype, k={k}, L={L}" if KIND == "tetraploid"
+                    else f"synthetic diploid {G} bp, 50x, 1% het, k={k}, L={L}"), "entries": int(len(cnt)),
        "host_cores": os.cpu_count()}
 with tempfile.TemporaryDirectory(prefix="smg_e2e") as d:
     t0 = time.time()
@@ -38,20 +45,27 @@ with tempfile.TemporaryDirectory(prefix="smg_e2e") as d:
         return dt, r.stderr
 
     cores = min(64, os.cpu_count() or 1)
-    run([ref, f"-e{L}", f"-T{cores}", "-owarm", "t.ktab"], "warm")          # page cache
-    dt, _ = run([ref, f"-e{L}", "-T1", "-oref1", "t.ktab"], "ref1")
-    out["reference_T1"] = {"wall_s": round(dt, 3), "kmers_per_s": len(cnt) / dt}
-    dt, _ = run([ref, f"-e{L}", f"-T{cores}", "-orefN", "t.ktab"], "refN")
-    out[f"reference_T{cores}"] = {"wall_s": round(dt, 3), "kmers_per_s": len(cnt) / dt}
-    best = None
-    for _ in range(3):
-        dt, err = run([ours, f"-e{L}", "-T4", "-v", "-ogpu", "t.ktab"], "gpu")
-        if best is None or dt < best[0]:
-            best = (dt, err)
-    out["mi355x_hetmers_end_to_end"] = {"wall_s": round(best[0], 3), "kmers_per_s": len(cnt) / best[0],
-                                        "engine_line": [l.strip() for l in best[1].splitlines() if "[smg]" in l]}
+    if not OURS_ONLY:
+        run([ref, f"-e{L}", f"-T{cores}", "-owarm", "t.ktab"], "warm")          # page cache
+    if not SKIP_T1:
+        dt, _ = run([ref, f"-e{L}", "-T1", "-oref1", "t.ktab"], "ref1")
+        out["reference_T1"] = {"wall_s": round(dt, 3), "kmers_per_s": len(cnt) / dt}
+    if not OURS_ONLY:
+        dt, _ = run([ref, f"-e{L}", f"-T{cores}", "-orefN", "t.ktab"], "refN")
+        out[f"reference_T{cores}"] = {"wall_s": round(dt, 3), "kmers_per_s": len(cnt) / dt}
+    for T in (4, 32):                      # -T = host threads that read the part files (CLI default: 4)
+        best = None
+        for _ in range(3):
+            dt, err = run([ours, f"-e{L}", f"-T{T}", "-v", "-ogpu", "t.ktab"], "gpu")
+            if best is None or dt < best[0]:
+                best = (dt, err)
+        out[f"mi355x_hetmers_end_to_end_T{T}"] = {"wall_s": round(best[0], 3), "kmers_per_s": len(cnt) / best[0],
+                                                  "engine_line": [l.strip() for l in best[1].splitlines() if "[smg]" in l]}
     a = open(os.path.join(d, "gpu.smu"), "rb").read()
     out["smu_bytes"] = len(a)
-    out["byte_identical_vs_reference_T1"] = a == open(os.path.join(d, "ref1.smu"), "rb").read()
+    if OURS_ONLY:
+        print(json.dumps(out, indent=1)); sys.exit(0)
+    if not SKIP_T1:
+        out["byte_identical_vs_reference_T1"] = a == open(os.path.join(d, "ref1.smu"), "rb").read()
     out["byte_identical_vs_reference_TN"] = a == open(os.path.join(d, "refN.smu"), "rb").read()
 print(json.dumps(out, indent=1))
