@@ -32,8 +32,10 @@ sys.path.insert(0, ROOT)
 from smudgeplot_amd import engine, ktab, sharded, synth, synth_device  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-ALG_BYTES_PER_KMER_PASS = 11   # k=31: TBYTE (8+2) read per pass + 1 degree byte written/read
-                               # => 22 B/k-mer over both passes
+def alg_bytes_per_kmer_pass(k):
+    """TBYTE = ceil(k/4)+2 read per pass + 1 degree byte written/read: 11 B at k=31 (22 B/k-mer over both
+    passes), 16 B at k=51"""
+    return (k + 3) // 4 + 2 + 1
 
 
 def cpu_baseline(sample_n0: int, k: int, L: int):
@@ -85,16 +87,19 @@ def main():
 
     # ---- workload: identical table on every rank, then keep this rank's prefix shard ----------
     G = int(args.genome)
-    keys, cnt = synth_device.diploid_table(G, k=args.k, het=0.01, cov=50.0, L=args.L, seed=1, device=dev)
+    if args.k <= 31:
+        keys, cnt = synth_device.diploid_table(G, k=args.k, het=0.01, cov=50.0, L=args.L, seed=1, device=dev)
+    else:                                  # two-word k-mers (BASELINE configs[4] is k=51); keys is [n, 2]
+        keys, cnt = synth_device.diploid_table_wide(G, k=args.k, het=0.01, cov=50.0, L=args.L, seed=1, device=dev)
     n_total = cnt.numel()
+    kw0 = keys if keys.dim() == 1 else keys[:, 0]          # the word that holds the window-block prefix
     if world > 1:
         cuts = [0]
-        kcpu = None
+        sh = 64 - 2 * min(32, args.k // 2)
+        pref = kw0 >> sh
         for r in range(1, world):
             c = (n_total * r) // world
             # move the cut to a window-block boundary (first k//2 bases differ)
-            sh = 64 - 2 * (args.k // 2)
-            pref = keys >> sh
             while c < n_total and int(pref[c]) == int(pref[c - 1]):
                 c += 1
             cuts.append(c)
@@ -102,7 +107,9 @@ def main():
         lo, hi = cuts[rank], cuts[rank + 1]
         keys = keys[lo:hi].clone()
         cnt = cnt[lo:hi].clone()
-        del kcpu
+        del pref
+    del kw0
+    keys = keys.reshape(-1)
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
 
@@ -140,8 +147,8 @@ def main():
     # Algorithmic bytes per launch: the two scan kernels move B_alg/2 = 11 B per
     # entry each (10 B record + 1 B degree/code); the look-up phase moves one 8-byte k-mer + 2-byte
     # count per request (per entry in exact mode, where every complement is looked up).
-    alg = {"ms_pass1": n_local * float(ALG_BYTES_PER_KMER_PASS),
-           "ms_pass2": n_local * float(ALG_BYTES_PER_KMER_PASS),
+    alg = {"ms_pass1": n_local * float(alg_bytes_per_kmer_pass(args.k)),
+           "ms_pass2": n_local * float(alg_bytes_per_kmer_pass(args.k)),
            "ms_rclookup": (nreq if args.symcheck == "hash" else n_local) * 10.0}
     # the dominant KERNEL: pass 1 and pass 2 are one launch each; the look-up phase is a chain of
     # short launches (compact, 4 radix passes, in-order look-ups), each well below pass 1
@@ -163,10 +170,10 @@ def main():
         cpu = None if args.no_cpu else cpu_baseline(args.cpu_sample, args.k, args.L)
         value = n_total * args.steps / dt
         out = {
-            "metric": "k-mers/sec through hetmers (k=31)",
+            "metric": "k-mers/sec through hetmers (k=%d)" % args.k,
             "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "u64" if args.k <= 32 else "u64x%d" % ((args.k + 31) // 32), "data": "synthetic",
             "config": {"workload": f"synthetic diploid {G:.3g} bp, 50x, 1% het, k={args.k}, L={args.L}: "
                                    f"{n_total} table entries (conditioned, rc-closed)",
                        "symcheck": args.symcheck, "sharding": f"prefix x{world}"},
@@ -177,7 +184,7 @@ def main():
                          "lookup_phase_GBps": alg["ms_rclookup"] / (ms["ms_rclookup"] * 1e-3) / 1e9
                          if ms["ms_rclookup"] > 0 else 0.0,
                          "whole_job_frac_of_22B_roofline":
-                             (n_total * 22.0 / (dt / args.steps)) / 1e9 / (HBM_PEAK_GBS * world)},
+                             (n_total * 2.0 * alg_bytes_per_kmer_pass(args.k) / (dt / args.steps)) / 1e9 / (HBM_PEAK_GBS * world)},
             "cpu_baseline": cpu,
             "pairs_in_plot": int(plot.sum().item()),
         }

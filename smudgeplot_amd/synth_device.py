@@ -135,3 +135,88 @@ def polyploid_table(G: int, ploidy: int = 4, div: float = 0.01, cov_hap: float =
     keys, cnt = keys[keep], cnt[keep]
     keys <<= (64 - 2 * k)
     return keys, cnt
+
+
+def diploid_table_wide(G: int, k: int = 51, het: float = 0.01, cov: float = 50.0, L: int = 10, seed: int = 1,
+                       device="cuda"):
+    """The diploid model of `diploid_table` for 33 <= k <= 64 (two 64-bit words per k-mer): BASELINE
+    configs[4] is a k=51 table.  -> (keys int64 [n, 2] viewing left-aligned uint64 words, sorted as
+    unsigned pairs; counts int16), trimmed at L and closed under reverse complement with equal counts.
+
+    The reverse complements are taken as the k-mers of the reverse-complemented haplotypes; every
+    occurrence carries a per-position normal deviate, a table entry takes the MINIMUM over its
+    occurrences (the occurrence sets of x and rc(x) mirror each other, so the two get the same count)."""
+    assert 33 <= k <= 64
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    h1 = torch.randint(0, 4, (G,), dtype=torch.uint8, device=device, generator=gen)
+    snp = torch.rand(G, device=device, generator=gen) < het
+    delta = torch.randint(1, 4, (G,), dtype=torch.uint8, device=device, generator=gen)
+    h2 = torch.where(snp, (h1 + delta) & 3, h1)
+    z = torch.randn(G - k + 1, device=device, generator=gen, dtype=torch.float32)
+    del snp, delta
+    SIGN = -(1 << 63)
+
+    def words(h):
+        g = h.numel()
+        m = g - k + 1
+        w0 = torch.zeros(m, dtype=torch.int64, device=device)
+        for j in range(32):
+            w0 <<= 2
+            w0 |= h[j: m + j].to(torch.int64)
+        w1 = torch.zeros(m, dtype=torch.int64, device=device)
+        for j in range(32, k):
+            w1 <<= 2
+            w1 |= h[j: m + j].to(torch.int64)
+        w1 <<= 2 * (64 - k)
+        return w0 ^ SIGN, w1 ^ SIGN            # biased: signed order == unsigned order
+
+    W0, W1, Z = [], [], []
+    for h in (h1, h2):
+        a0, a1 = words(h)
+        b0, b1 = words((3 - h).flip(0))        # occurrence i of h mirrors occurrence m-1-i of rc(h)
+        W0 += [a0, b0]; W1 += [a1, b1]; Z += [z, z.flip(0)]
+    del h1, h2
+    w0 = torch.cat(W0); w1 = torch.cat(W1); zz = torch.cat(Z)
+    del W0, W1, Z
+    # order by (w0, w1): one sort on w0, then odd-even transposition inside the (tiny) runs of equal w0
+    # (two stable sorts in a row came back unsorted for > 1e8 elements with this torch/ROCm build)
+    w0, o = torch.sort(w0)
+    w1, zz = w1[o], zz[o]
+    del o
+    for rnd in range(64):
+        swapped = 0
+        for parity in (0, 1):
+            a = slice(parity, w0.numel() - 1, 2)
+            b = slice(parity + 1, w0.numel(), 2)
+            n2 = min(w0[a].numel(), w0[b].numel())
+            ia = torch.arange(parity, parity + 2 * n2, 2, device=device)
+            bad = (w0[ia] == w0[ia + 1]) & (w1[ia] > w1[ia + 1])
+            idx = ia[bad]
+            swapped += int(idx.numel())
+            if idx.numel():
+                t1, tz = w1[idx].clone(), zz[idx].clone()
+                w1[idx], zz[idx] = w1[idx + 1], zz[idx + 1]
+                w1[idx + 1], zz[idx + 1] = t1, tz
+            del ia, bad, idx
+        if swapped == 0:
+            break
+    assert bool(((w0[1:] > w0[:-1]) | ((w0[1:] == w0[:-1]) & (w1[1:] >= w1[:-1]))).all()), "generator: not sorted"
+    first = torch.ones(w0.numel(), dtype=torch.bool, device=device)
+    first[1:] = (w0[1:] != w0[:-1]) | (w1[1:] != w1[:-1])
+    run = torch.cumsum(first, 0) - 1
+    nrun = int(run[-1].item()) + 1
+    zmin = torch.full((nrun,), float("inf"), device=device, dtype=torch.float32)
+    zmin.scatter_reduce_(0, run, zz, reduce="amin")
+    mult = torch.zeros(nrun, dtype=torch.int64, device=device)
+    mult.scatter_add_(0, run, torch.ones_like(run))
+    u0, u1 = w0[first] ^ SIGN, w1[first] ^ SIGN
+    del w0, w1, zz, run, first
+    mean = torch.where(mult >= 2, float(cov), float(cov) / 2)
+    cnt = torch.round(mean + torch.sqrt(mean) * zmin).clamp_(0, 32767).to(torch.int16)
+    keep = cnt >= L                            # x and rc(x) carry the same count: trimming keeps the closure
+    u0, u1, cnt = u0[keep], u1[keep], cnt[keep].contiguous()
+    keys = torch.empty((u0.numel(), 2), dtype=torch.int64, device=device)
+    keys[:, 0] = u0                            # (torch.stack / 2-D boolean indexing came back scrambled
+    keys[:, 1] = u1                            #  beyond ~1e8 rows with this torch/ROCm build)
+    return keys, cnt
