@@ -78,7 +78,9 @@ typedef struct smg_opts
   int32_t verbose;       /* >0: per-phase timing lines on stderr                             */
   int32_t condition;     /* SMG_COND_* bits: condition the table before the scan             */
   int32_t ethresh;       /* -e threshold for SMG_COND_TRIM                                   */
-  int32_t reserved;
+  int32_t ngpus;         /* > 1: smg_hetmers_run shards the table by k-mer prefix over the HIP    */
+                         /* devices device .. device+ngpus-1 (one host thread each, RCCL request  */
+                         /* exchange + histogram all-reduce); 0 / 1: one GPU                      */
 } smg_opts;
 
 typedef struct smg_stats

@@ -208,8 +208,9 @@ static char *smg_cli_open_table(const smg_cli *c, const char *SRC, smg_ktab *T, 
   free(tname);
 
   memset(opts, 0, sizeof(*opts));
-  { const char *g = getenv("SMUDGEPLOT_GPU"), *s = getenv("SMUDGEPLOT_SYMCHECK");
+  { const char *g = getenv("SMUDGEPLOT_GPU"), *s = getenv("SMUDGEPLOT_SYMCHECK"), *ng = getenv("SMUDGEPLOT_GPUS");
     opts->device = g ? atoi(g) : 0;
+    opts->ngpus = ng ? atoi(ng) : 0;          /* > 1: prefix-shard the table over that many GPUs of the node */
     opts->symcheck = SMG_SYM_HASH;
     if (s && strcasecmp(s, "exact") == 0) opts->symcheck = SMG_SYM_EXACT;
     if (s && strcasecmp(s, "none") == 0) opts->symcheck = SMG_SYM_NONE;

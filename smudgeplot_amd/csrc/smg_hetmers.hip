@@ -90,9 +90,11 @@ SMG_DEV int dec_bisect(const int64_t *__restrict__ index, int lo, int hi, int64_
 
 __global__ void __launch_bounds__(TPB)
 k_decode(const uint8_t *__restrict__ rec, const int64_t *__restrict__ index, int ixlen,
-         int ibyte, int kbyte, int W, int64_t n, u64 *__restrict__ keys,
+         int ibyte, int kbyte, int W, int64_t n, int64_t ibase, u64 *__restrict__ keys,
          uint16_t *__restrict__ cnt)
-{ __shared__ unsigned sraw[(DEC_TILE * DEC_MAXPB + 3) / 4 + 2];
+{ // rec / keys / cnt are indexed by the LOCAL entry number 0..n-1; the prefix index by ibase + local
+  // (a shard of a table that was cut for several GPUs starts at entry ibase of the whole table)
+  __shared__ unsigned sraw[(DEC_TILE * DEC_MAXPB + 3) / 4 + 2];
   __shared__ int64_t  six[DEC_IX];
   __shared__ int      s_lo, s_hi;
   const int t = threadIdx.x;
@@ -116,8 +118,8 @@ k_decode(const uint8_t *__restrict__ rec, const int64_t *__restrict__ index, int
       sraw[w] = v;
     }
   if (t == 0)
-    { s_lo = dec_bisect(index, 0, ixlen - 1, i0);
-      s_hi = dec_bisect(index, 0, ixlen - 1, i1 - 1);
+    { s_lo = dec_bisect(index, 0, ixlen - 1, ibase + i0);
+      s_hi = dec_bisect(index, 0, ixlen - 1, ibase + i1 - 1);
     }
   __syncthreads();
   const int lo = s_lo, hi = s_hi;
@@ -132,11 +134,11 @@ k_decode(const uint8_t *__restrict__ rec, const int64_t *__restrict__ index, int
         { int a = 0, b = hi - lo;
           while (a < b)
             { const int m = (a + b) >> 1;
-              if (six[m] <= i) a = m + 1; else b = m;
+              if (six[m] <= ibase + i) a = m + 1; else b = m;
             }
           p = lo + a;
         }
-      else p = dec_bisect(index, lo, hi, i);
+      else p = dec_bisect(index, lo, hi, ibase + i);
       const uint8_t *r = sb + (i - i0) * pbyte;
       u64 word = 0;
       int w = 0;
@@ -541,9 +543,8 @@ extern "C" int smg_engine_bind(smg_engine *e, int kmer, int64_t nels, const uint
   return SMG_OK;
 }
 
-extern "C" int smg_engine_decode(smg_engine *e, int kmer, int ibyte, int64_t nels,
-                                 const uint8_t *d_records, const int64_t *d_prefix_index,
-                                 char *errbuf, size_t errlen)
+static int decode_at(smg_engine *e, int kmer, int ibyte, int64_t nels, int64_t ibase, const uint8_t *d_records,
+                     const int64_t *d_prefix_index, char *errbuf, size_t errlen)
 { if (!e) return fail(errbuf, errlen, SMG_EINVAL, "null engine%s");
   if (ibyte < 1 || ibyte > 3) return fail(errbuf, errlen, SMG_EINVAL, "ibyte must be 1, 2 or 3%s");
   HIPCHK(hipSetDevice(e->device));
@@ -560,7 +561,7 @@ extern "C" int smg_engine_decode(smg_engine *e, int kmer, int ibyte, int64_t nel
   if (nels > 0)
     { const unsigned nblk = (unsigned) ((nels + DEC_TILE - 1) / DEC_TILE);
       hipLaunchKernelGGL(k_decode, dim3(nblk), dim3(TPB), 0, e->stream, d_records,
-                         d_prefix_index, 1 << (8 * ibyte), ibyte, kbyte, e->W, nels,
+                         d_prefix_index, 1 << (8 * ibyte), ibyte, kbyte, e->W, nels, ibase,
                          e->own_keys, e->own_cnt);
     }
   hipEventRecord(e->ev[1], e->stream);
@@ -569,6 +570,11 @@ extern "C" int smg_engine_decode(smg_engine *e, int kmer, int ibyte, int64_t nel
   e->st.ms_decode = ms;
   return SMG_OK;
 }
+
+extern "C" int smg_engine_decode(smg_engine *e, int kmer, int ibyte, int64_t nels,
+                                 const uint8_t *d_records, const int64_t *d_prefix_index,
+                                 char *errbuf, size_t errlen)
+{ return decode_at(e, kmer, ibyte, nels, 0, d_records, d_prefix_index, errbuf, errlen); }
 
 static int read_ctrl(smg_engine *e, char *errbuf, size_t errlen)
 { HIPCHK(hipMemcpyAsync(e->h_ctrl, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
@@ -1365,6 +1371,8 @@ extern "C" int smg_engine_extract(smg_engine *e, const uint16_t *d_labels, uint6
   return SMG_OK;
 }
 
+#include "smg_multi.hpp"
+
 // ---- one-shot host entry ----------------------------------------------------------------------
 
 // labels == NULL: hetmers.  labels != NULL: additionally the extract leg; *records receives a malloc'ed
@@ -1382,6 +1390,25 @@ static int host_run(const smg_table_view *tv, const smg_opts *opts, int64_t *plo
   int64_t sum = 0;
   for (int p = 0; p < tv->nparts; p++) sum += tv->part_nels[p];
   if (sum != tv->nels) return fail(errbuf, errlen, SMG_EFORMAT, "part sizes do not add up to nels%s");
+  { // several GPUs of the node (smg_multi.hpp); SMG_VIRTUAL_SHARDS is the 1-GPU test hook of that path
+    int ng = opts ? opts->ngpus : 0;
+    const char *v = getenv("SMG_VIRTUAL_SHARDS");
+    if (v && atoi(v) > 1) ng = atoi(v);
+    // SMG_FORCE_MULTI=1 (tests): take the multi-GPU code path even with one GPU -- a one-rank RCCL
+    // communicator, send/recv to self, all-reduce: checks the dlopen'ed RCCL entry points on a 1-GPU box
+    if (ng <= 1 && getenv("SMG_FORCE_MULTI") && !v) ng = -1;
+    if ((ng > 1 || ng == -1) && !labels)
+      { if (opts && (opts->condition & SMG_COND_SYMM))
+          { if (verbose) fprintf(stderr, "  [smg] the table has to be symmetrised first: using one GPU\n"); }
+        else if (tv->kmer > FAST_MAX_K)
+          { if (verbose) fprintf(stderr, "  [smg] k > 85: using one GPU\n"); }
+        else
+          { smg_opts o; memset(&o, 0, sizeof(o));
+            if (opts) o = *opts; else o.symcheck = SMG_SYM_HASH;
+            return host_run_multi(tv, &o, ng == -1 ? 1 : ng, plot, stats, errbuf, errlen);
+          }
+      }
+  }
 
   smg_engine *e = smg_engine_create(device, NULL, errbuf, errlen);
   if (!e) return SMG_ENODEV;

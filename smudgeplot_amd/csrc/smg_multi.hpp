@@ -1,0 +1,353 @@
+// smg_multi.hpp -- several GPUs of one node behind the C ABI (smg_opts.ngpus > 1): what the `hetmers`
+// executable uses when SMUDGEPLOT_GPUS=N is set, so that the unchanged `smudgeplot hetmers` CLI scales
+// over the node.  Included at the end of smg_hetmers.hip (uses the engine's internals).
+//
+// One host thread per GPU, each with its own engine.  The conditioned table is cut into contiguous PREFIX
+// shards on window-block boundaries (every scanned position is shard local; the reference's analogue is
+// the prefix-subtree task list of small_window, PloidyPlot.c:1040-1084).  Exchanges:
+//   1. complement requests: grouped by destination on the device (smg_engine_route), then one
+//      send/recv pair per peer inside ONE RCCL group call (an all-to-all over the xGMI links);
+//   2. ONE ncclAllReduce(SUM, int64[1001*501]) of the per-GPU histograms.
+// The symmetry proof (missing counts + fingerprint residues) is a few words per GPU and is reduced on the
+// host: all ranks live in one process.
+//
+// RCCL is resolved with dlopen at the first multi-GPU call: the single-GPU path (and a process that
+// already carries another RCCL, e.g. PyTorch's) never loads it.
+//
+// SMG_VIRTUAL_SHARDS=N (tests): N shards on ONE device, the exchanges done with device-to-device copies
+// and a host-side sum -- exercises the cutting, the ranged decode, the routing and the proof on a 1-GPU box.
+// The multi-process equivalent (one process per GPU, torch.distributed) is smudgeplot_amd/sharded.py.
+
+#pragma once
+#include <pthread.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>          // types and enums only: the functions are looked up at run time
+
+#define SMG_MAXGPU 16
+
+struct RcclApi
+{ void *lib;
+  ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *);
+  ncclResult_t (*CommDestroy)(ncclComm_t);
+  ncclResult_t (*GroupStart)(void);
+  ncclResult_t (*GroupEnd)(void);
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+  const char  *(*GetErrorString)(ncclResult_t);
+};
+
+static bool rccl_load(RcclApi *a, char *errbuf, size_t errlen)
+{ memset(a, 0, sizeof(*a));
+  const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so" };
+  for (unsigned i = 0; i < sizeof(names) / sizeof(names[0]) && !a->lib; i++) a->lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+  if (!a->lib) { fail(errbuf, errlen, SMG_ENODEV, "cannot load RCCL (librccl.so) for the multi-GPU run%s"); return false; }
+#define SYM(field, name) *(void **) (&a->field) = dlsym(a->lib, name); if (!a->field) { fail(errbuf, errlen, SMG_ENODEV, "RCCL symbol missing: %s", name); return false; }
+  SYM(CommInitAll, "ncclCommInitAll") SYM(CommDestroy, "ncclCommDestroy") SYM(GroupStart, "ncclGroupStart")
+  SYM(GroupEnd, "ncclGroupEnd") SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(AllReduce, "ncclAllReduce")
+  SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+  return true;
+}
+
+struct MultiCtx
+{ int  n;                                   // shards == threads
+  bool virt;                                // all shards on one device, no RCCL
+  int  devs[SMG_MAXGPU];
+  const smg_table_view *tv;
+  int  symcheck, condition, ethresh, W, pbyte;
+  int64_t cut[SMG_MAXGPU + 1];              // entry ranges of the shards in the input table
+  pthread_barrier_t bar;
+  volatile int failed;
+  // published by rank r, read by the others after a barrier
+  u64      first[SMG_MAXGPU][4];
+  int64_t  nshard[SMG_MAXGPU];
+  int64_t  counts[SMG_MAXGPU][SMG_MAXGPU];  // counts[src][dst], records
+  uint64_t *send[SMG_MAXGPU];
+  int64_t  missing[SMG_MAXGPU];
+  u64      fp[SMG_MAXGPU][4];
+  int64_t *h_plot[SMG_MAXGPU];              // virtual mode: per-shard histograms on the host
+  smg_stats st[SMG_MAXGPU];
+  int      rc[SMG_MAXGPU];
+  char     err[SMG_MAXGPU][256];
+  int      rw;
+  RcclApi  api;
+  ncclComm_t comm[SMG_MAXGPU];
+  int64_t *plot;                            // result (host), written by rank 0
+};
+
+struct MultiArg { MultiCtx *c; int r; };
+
+// copy the records of the entries [lo, hi) of the (multi-part) host table to the device
+static hipError_t multi_h2d_records(const smg_table_view *tv, int pbyte, int64_t lo, int64_t hi, uint8_t *d_rec)
+{ int64_t base = 0;
+  size_t off = 0;
+  for (int p = 0; p < tv->nparts && base < hi; p++)
+    { const int64_t pn = tv->part_nels[p];
+      const int64_t a = lo > base ? lo : base, b = hi < base + pn ? hi : base + pn;
+      if (a < b)
+        { const size_t bytes = (size_t) (b - a) * pbyte;
+          hipError_t he = hipMemcpy(d_rec + off, tv->part_data[p] + (size_t) (a - base) * pbyte, bytes, hipMemcpyHostToDevice);
+          if (he != hipSuccess) return he;
+          off += bytes;
+        }
+      base += pn;
+    }
+  return hipSuccess;
+}
+
+static int decode_at(smg_engine *e, int kmer, int ibyte, int64_t nels, int64_t ibase, const uint8_t *d_records,
+                     const int64_t *d_prefix_index, char *errbuf, size_t errlen);
+
+#define MFAIL(code, msg) do { c->rc[r] = fail(c->err[r], sizeof(c->err[r]), code, msg "%s"); c->failed = 1; } while (0)
+#define MOK (!c->failed)
+
+static void *multi_worker(void *argp)
+{ MultiArg *arg = (MultiArg *) argp;
+  MultiCtx *c = arg->c;
+  const int r = arg->r, n = c->n, W = c->W;
+  const smg_table_view *tv = c->tv;
+  smg_engine *e = NULL;
+  uint8_t *d_rec = NULL; int64_t *d_index = NULL, *d_plot = NULL;
+  uint64_t *recv = NULL;
+  u64 splitters[SMG_MAXGPU * 4];
+  char *eb = c->err[r]; const size_t el = sizeof(c->err[r]);
+  c->rc[r] = SMG_OK; c->err[r][0] = 0;
+  c->send[r] = NULL; c->h_plot[r] = NULL; c->nshard[r] = 0; c->missing[r] = 0;
+  memset(c->fp[r], 0, sizeof(c->fp[r])); memset(c->first[r], 0xFF, sizeof(c->first[r]));
+
+  // ---- shard on the device -------------------------------------------------------------------------------
+  if (hipSetDevice(c->devs[r]) != hipSuccess) MFAIL(SMG_ENODEV, "cannot select HIP device");
+  if (MOK && !(e = smg_engine_create(c->devs[r], NULL, eb, el))) { c->rc[r] = SMG_ENODEV; c->failed = 1; }
+  const int64_t lo = c->cut[r], hi = c->cut[r + 1], ns = hi - lo;
+  const size_t ixbytes = sizeof(int64_t) << (8 * tv->ibyte);
+  if (MOK)
+    { if (hipMalloc(&d_rec, (size_t) (ns > 0 ? ns : 1) * c->pbyte) != hipSuccess || hipMalloc(&d_index, ixbytes) != hipSuccess
+          || hipMalloc(&d_plot, sizeof(int64_t) * SMG_PLOT_CELLS) != hipSuccess)
+        MFAIL(SMG_ENOMEM, "out of device memory for the table shard");
+    }
+  if (MOK && (multi_h2d_records(tv, c->pbyte, lo, hi, d_rec) != hipSuccess
+              || hipMemcpy(d_index, tv->prefix_index, ixbytes, hipMemcpyHostToDevice) != hipSuccess))
+    MFAIL(SMG_ENODEV, "host to device copy failed");
+  if (MOK && (c->rc[r] = decode_at(e, tv->kmer, tv->ibyte, ns, lo, d_rec, d_index, eb, el))) c->failed = 1;
+  if (d_rec) { hipFree(d_rec); d_rec = NULL; }
+  if (d_index) { hipFree(d_index); d_index = NULL; }
+  if (MOK && (c->condition & SMG_COND_TRIM))
+    { int64_t nn = 0;
+      if ((c->rc[r] = smg_engine_condition(e, c->ethresh, 1, 0, &nn, eb, el))) c->failed = 1;
+    }
+  if (MOK)
+    { c->nshard[r] = e->n;
+      if (e->n > 0 && hipMemcpy(c->first[r], e->keys, sizeof(u64) * W, hipMemcpyDeviceToHost) != hipSuccess)
+        MFAIL(SMG_ENODEV, "device to host copy failed");
+    }
+  pthread_barrier_wait(&c->bar);                                                         // A: shards + first k-mers
+
+  // ---- pass 1, requests grouped by destination ---------------------------------------------------------
+  if (MOK)
+    { for (int s = n - 2; s >= 0; s--)            // an empty shard inherits its successor's first k-mer
+        if (c->nshard[s] == 0 && r == 0) memcpy(c->first[s], c->first[s + 1], sizeof(c->first[s]));
+    }
+  pthread_barrier_wait(&c->bar);                                                         // A2: splitters final
+  int64_t nreq = 0;
+  if (MOK)
+    { for (int s = 1; s < n; s++) memcpy(splitters + (size_t) (s - 1) * W, c->first[s], sizeof(u64) * W);
+      if ((c->rc[r] = smg_engine_pass1(e, c->symcheck, eb, el))) c->failed = 1;
+    }
+  if (MOK)
+    { nreq = smg_engine_nreq(e);
+      c->rw = smg_engine_record_words(e);
+      if (hipMalloc(&c->send[r], sizeof(uint64_t) * (size_t) (nreq > 0 ? nreq : 1) * c->rw) != hipSuccess)
+        MFAIL(SMG_ENOMEM, "out of device memory for the request exchange");
+    }
+  if (MOK && (c->rc[r] = smg_engine_route(e, (const uint64_t *) splitters, n, c->send[r], nreq, c->counts[r], eb, el))) c->failed = 1;
+  pthread_barrier_wait(&c->bar);                                                         // B: all counts known
+
+  // ---- exchange -------------------------------------------------------------------------------------------
+  int64_t nrecv = 0;
+  if (MOK)
+    { const int rw = c->rw;
+      for (int s = 0; s < n; s++) nrecv += c->counts[s][r];
+      if (hipMalloc(&recv, sizeof(uint64_t) * (size_t) (nrecv > 0 ? nrecv : 1) * rw) != hipSuccess)
+        MFAIL(SMG_ENOMEM, "out of device memory for the request exchange");
+      if (MOK && c->virt)
+        { int64_t roff = 0;
+          for (int s = 0; s < n && MOK; s++)
+            { int64_t soff = 0;
+              for (int d = 0; d < r; d++) soff += c->counts[s][d];
+              const int64_t cnt = c->counts[s][r];
+              if (cnt && hipMemcpy(recv + roff * rw, c->send[s] + soff * rw, sizeof(uint64_t) * (size_t) cnt * rw,
+                                   hipMemcpyDeviceToDevice) != hipSuccess)
+                MFAIL(SMG_ENODEV, "device to device copy failed");
+              roff += cnt;
+            }
+        }
+      else if (MOK)
+        { ncclResult_t nr = c->api.GroupStart();
+          int64_t soff = 0, roff = 0;
+          for (int p = 0; p < n && nr == ncclSuccess; p++)
+            { if (c->counts[r][p])
+                nr = c->api.Send(c->send[r] + soff * rw, (size_t) c->counts[r][p] * rw, ncclUint64, p, c->comm[r], e->stream);
+              if (nr == ncclSuccess && c->counts[p][r])
+                nr = c->api.Recv(recv + roff * rw, (size_t) c->counts[p][r] * rw, ncclUint64, p, c->comm[r], e->stream);
+              soff += c->counts[r][p]; roff += c->counts[p][r];
+            }
+          const ncclResult_t ne = c->api.GroupEnd();
+          if (nr == ncclSuccess) nr = ne;
+          if (nr != ncclSuccess || hipStreamSynchronize(e->stream) != hipSuccess)
+            { c->rc[r] = fail(eb, el, SMG_ENODEV, "RCCL request exchange failed: %s",
+                              nr != ncclSuccess ? c->api.GetErrorString(nr) : "stream error");
+              c->failed = 1;
+            }
+        }
+    }
+  if (MOK && (c->rc[r] = smg_engine_apply(e, recv, nrecv, &c->missing[r], eb, el))) c->failed = 1;
+  if (MOK) smg_engine_symhash(e, (uint64_t *) c->fp[r], eb, el);
+  pthread_barrier_wait(&c->bar);                                                         // C: proof words published
+  if (c->send[r]) { hipFree(c->send[r]); c->send[r] = NULL; }     // peers have copied what they needed
+  if (recv) { hipFree(recv); recv = NULL; }
+
+  // ---- symmetry proof (host reduction), pass 2, histogram reduction -------------------------------------
+  if (MOK)
+    { int64_t miss = 0; u64 f[4] = { 0, 0, 0, 0 };
+      for (int s = 0; s < n; s++) { miss += c->missing[s]; for (int q = 0; q < 4; q++) f[q] += c->fp[s][q]; }
+      bool symmetric = miss == 0;
+      if (c->symcheck == SMG_SYM_HASH) symmetric = symmetric && f[0] == f[2] && f[1] == f[3];
+      if (!symmetric)
+        MFAIL(SMG_ENOTSYM, "the table is not closed under reverse complement with equal counts: "
+                           "a multi-GPU run needs a conditioned table (use one GPU for this one)");
+    }
+  if (MOK && (c->rc[r] = smg_engine_pass2(e, d_plot, eb, el))) c->failed = 1;
+  if (MOK && c->virt)
+    { c->h_plot[r] = (int64_t *) malloc(sizeof(int64_t) * SMG_PLOT_CELLS);
+      if (!c->h_plot[r] || hipMemcpy(c->h_plot[r], d_plot, sizeof(int64_t) * SMG_PLOT_CELLS, hipMemcpyDeviceToHost) != hipSuccess)
+        MFAIL(SMG_ENODEV, "device to host copy failed");
+    }
+  else if (MOK)
+    { const ncclResult_t nr = c->api.AllReduce(d_plot, d_plot, SMG_PLOT_CELLS, ncclInt64, ncclSum, c->comm[r], e->stream);
+      if (nr != ncclSuccess || hipStreamSynchronize(e->stream) != hipSuccess)
+        { c->rc[r] = fail(eb, el, SMG_ENODEV, "RCCL all-reduce of the histograms failed: %s",
+                          nr != ncclSuccess ? c->api.GetErrorString(nr) : "stream error");
+          c->failed = 1;
+        }
+      if (MOK && r == 0 && hipMemcpy(c->plot, d_plot, sizeof(int64_t) * SMG_PLOT_CELLS, hipMemcpyDeviceToHost) != hipSuccess)
+        MFAIL(SMG_ENODEV, "device to host copy failed");
+    }
+  if (e) c->st[r] = e->st;
+  pthread_barrier_wait(&c->bar);                                                         // D: histograms ready
+  if (MOK && c->virt && r == 0)
+    { for (int cell = 0; cell < SMG_PLOT_CELLS; cell++)
+        { int64_t v = 0;
+          for (int s = 0; s < n; s++) v += c->h_plot[s][cell];
+          c->plot[cell] = v;
+        }
+    }
+  pthread_barrier_wait(&c->bar);                                                         // E: done with h_plot
+  free(c->h_plot[r]); c->h_plot[r] = NULL;
+  if (d_plot) hipFree(d_plot);
+  if (e) smg_engine_destroy(e);
+  return NULL;
+}
+#undef MFAIL
+#undef MOK
+
+// cut points: about n*r/N, moved to a prefix-index boundary that is also a window-block boundary
+static void multi_cuts(const smg_table_view *tv, int n, int64_t *cut)
+{ const int64_t ixlen = 1ll << (8 * tv->ibyte);
+  const int p0 = tv->kmer / 2, ib = 4 * tv->ibyte;          // bases in a window-block prefix / in an index bucket
+  // an index bucket fixes the first `ib` bases; a window block the first `p0`: when ib > p0 only every
+  // 4^(ib-p0)-th bucket boundary is also a block boundary
+  const int64_t gran = ib > p0 ? 1ll << (2 * (ib - p0)) : 1;
+  cut[0] = 0; cut[n] = tv->nels;
+  for (int r = 1; r < n; r++)
+    { const int64_t target = tv->nels / n * r;
+      int64_t lo = 0, hi = ixlen - 1;                         // smallest bucket b with index[b] >= target
+      while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (tv->prefix_index[m] < target) lo = m + 1; else hi = m; }
+      int64_t b = lo + 1;                                      // the cut goes in front of bucket b
+      b = (b + gran / 2) / gran * gran;
+      if (b >= ixlen) b = ixlen;
+      int64_t cpos = b == 0 ? 0 : tv->prefix_index[b - 1];
+      if (cpos < cut[r - 1]) cpos = cut[r - 1];
+      cut[r] = cpos;
+    }
+}
+
+static int host_run_multi(const smg_table_view *tv, const smg_opts *opts, int ngpus, int64_t *plot,
+                          smg_stats *stats, char *errbuf, size_t errlen)
+{ if (ngpus > SMG_MAXGPU) ngpus = SMG_MAXGPU;
+  if ((opts->condition & SMG_COND_SYMM))
+    return fail(errbuf, errlen, SMG_EINVAL, "a multi-GPU run cannot symmetrise the table (use one GPU, or condition it first)%s");
+  if (tv->kmer > FAST_MAX_K)
+    return fail(errbuf, errlen, SMG_EINVAL, "multi-GPU runs support k <= 85%s");
+  MultiCtx *c = new (std::nothrow) MultiCtx();
+  if (!c) return fail(errbuf, errlen, SMG_ENOMEM, "out of host memory%s");
+  memset(c, 0, sizeof(*c));
+  c->n = ngpus; c->tv = tv; c->symcheck = opts->symcheck == SMG_SYM_NONE ? SMG_SYM_HASH : opts->symcheck;
+  c->condition = opts->condition; c->ethresh = opts->ethresh;
+  c->W = (tv->kmer + 31) / 32;
+  c->pbyte = ((tv->kmer + 3) >> 2) + 2 - tv->ibyte;
+  c->plot = plot;
+  { const char *v = getenv("SMG_VIRTUAL_SHARDS"); c->virt = v && atoi(v) > 0; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    { delete c; return fail(errbuf, errlen, SMG_ENODEV, "no HIP device available (this engine has no CPU fallback)%s"); }
+  for (int r = 0; r < ngpus; r++) c->devs[r] = c->virt ? opts->device : opts->device + r;
+  if (!c->virt && opts->device + ngpus > ndev)
+    { delete c; return fail(errbuf, errlen, SMG_EINVAL, "fewer HIP devices than SMUDGEPLOT_GPUS asks for%s"); }
+  if (!c->virt)
+    { if (!rccl_load(&c->api, errbuf, errlen)) { delete c; return SMG_ENODEV; }
+      const ncclResult_t nr = c->api.CommInitAll(c->comm, ngpus, c->devs);
+      if (nr != ncclSuccess)
+        { const int rc = fail(errbuf, errlen, SMG_ENODEV, "ncclCommInitAll failed: %s", c->api.GetErrorString(nr)); delete c; return rc; }
+    }
+  multi_cuts(tv, ngpus, c->cut);
+  pthread_barrier_init(&c->bar, NULL, (unsigned) ngpus);
+  pthread_t th[SMG_MAXGPU];
+  MultiArg args[SMG_MAXGPU];
+  hipEvent_t t0, t1;
+  hipSetDevice(c->devs[0]);
+  hipEventCreate(&t0); hipEventCreate(&t1);
+  hipEventRecord(t0, 0);
+  for (int r = 0; r < ngpus; r++) { args[r].c = c; args[r].r = r; }
+  int started = 0;
+  for (int r = 1; r < ngpus; r++)
+    if (pthread_create(&th[r], NULL, multi_worker, &args[r]) == 0) started++;
+  int rc = SMG_OK;
+  if (started != ngpus - 1)
+    { // cannot run with a partial team: the barrier would never release.  Nothing else has started waiting
+      // on it yet only if NO thread was created; otherwise this process cannot recover cleanly.
+      rc = fail(errbuf, errlen, SMG_ENOMEM, "cannot create the per-GPU host threads%s");
+      if (started) { fprintf(stderr, "smg_hetmers: fatal: partial thread team\n"); abort(); }
+    }
+  else
+    { multi_worker(&args[0]);
+      for (int r = 1; r < ngpus; r++) pthread_join(th[r], NULL);
+      for (int r = 0; r < ngpus && rc == SMG_OK; r++)
+        if (c->rc[r] != SMG_OK) { rc = c->rc[r]; if (errbuf && errlen) snprintf(errbuf, errlen, "GPU %d: %s", c->devs[r], c->err[r]); }
+    }
+  hipSetDevice(c->devs[0]);
+  hipEventRecord(t1, 0); hipEventSynchronize(t1);
+  float wall = 0; hipEventElapsedTime(&wall, t0, t1);
+  hipEventDestroy(t0); hipEventDestroy(t1);
+  if (rc == SMG_OK)
+    { smg_stats st; memset(&st, 0, sizeof(st));
+      st.path = 1; st.key_words = c->W;
+      for (int r = 0; r < ngpus; r++)
+        { st.nels += c->st[r].nels; st.nrequests += c->st[r].nrequests;
+#define MX(f) if (c->st[r].f > st.f) st.f = c->st[r].f
+          MX(ms_decode); MX(ms_pass1); MX(ms_rclookup); MX(ms_pass2);
+#undef MX
+        }
+      for (int cell = 0; cell < SMG_PLOT_CELLS; cell++) st.npairs += plot[cell];
+      st.ms_total = wall;                  // H2D + decode + both passes + exchanges, all shards
+      if (stats) *stats = st;
+      if (opts->verbose)
+        fprintf(stderr, "  [smg] n=%lld k=%d gpus=%d%s  decode %.2f ms, pass1 %.2f, exchange+rc-lookup %.2f, pass2 %.2f "
+                "(slowest shard each), wall incl. H2D %.2f ms\n", (long long) st.nels, tv->kmer, ngpus,
+                c->virt ? " (virtual shards on one device)" : "", st.ms_decode, st.ms_pass1, st.ms_rclookup, st.ms_pass2, wall);
+    }
+  if (!c->virt) for (int r = 0; r < ngpus; r++) c->api.CommDestroy(c->comm[r]);
+  pthread_barrier_destroy(&c->bar);
+  delete c;
+  return rc;
+}

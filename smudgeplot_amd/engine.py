@@ -43,7 +43,7 @@ class TableView(C.Structure):
 
 class Opts(C.Structure):
     _fields_ = [("device", C.c_int32), ("symcheck", C.c_int32), ("verbose", C.c_int32),
-                ("condition", C.c_int32), ("ethresh", C.c_int32), ("reserved", C.c_int32)]
+                ("condition", C.c_int32), ("ethresh", C.c_int32), ("ngpus", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -145,7 +145,7 @@ COND_TRIM, COND_SYMM = 1, 2
 
 
 def hetmers_run(table, device: int = 0, symcheck: str = "exact", verbose: int = 0, condition: int = 0,
-                ethresh: int = 0):
+                ethresh: int = 0, ngpus: int = 0):
     """Host FastK table (`ktab.KTable`) -> (plot int64[1001,501], stats dict).
     condition: COND_TRIM | COND_SYMM to trim to count >= ethresh / symmetrise on the device first
     (what the reference delegates to Logex / Symmex, PloidyPlot.c:1381-1414).
@@ -155,7 +155,7 @@ def hetmers_run(table, device: int = 0, symcheck: str = "exact", verbose: int = 
     """
     lib = load_library()
     tv, keep = _table_view(table)
-    opts = Opts(device, _SYM[symcheck], verbose, condition, ethresh, 0)
+    opts = Opts(device, _SYM[symcheck], verbose, condition, ethresh, ngpus)
     plot = np.zeros(PLOT_CELLS, dtype=np.int64)
     st = Stats()
     buf = C.create_string_buffer(512)

@@ -429,3 +429,75 @@ def test_table_sizes_around_the_pass1_tile(n_target):
     plot, st = engine.hetmers_run(table_from(packed, cc, k), symcheck="hash")
     assert np.array_equal(plot, want)
     assert st["path"] == (2 if n_target % 2 else 1)
+
+
+# ---- several GPUs behind the C ABI (smg_multi.hpp), exercised as VIRTUAL shards on the one GPU of the box --
+
+@pytest.mark.parametrize("shards", [2, 3, 5])
+@pytest.mark.parametrize("name", ["k31_i1", "k31_i3_p4", "k21_i2_p2", "k17_i1", "k51_i1_p3", "k65_i1", "k32_i1_p2"])
+def test_multi_gpu_path_virtual_shards_golden(name, shards, monkeypatch):
+    """prefix cuts from the FastK index, ranged decode, request routing between shards, host-side proof,
+    histogram sum: everything of the multi-GPU path except the RCCL calls themselves"""
+    g = load_golden(name)
+    monkeypatch.setenv("SMG_VIRTUAL_SHARDS", str(shards))
+    for mode in ("hash", "exact"):
+        plot, st = engine.hetmers_run(make_table(g), symcheck=mode)
+        assert engine.smu_text(plot) == g["smu"], (name, shards, mode)
+        assert st["nels"] == len(g["counts"]) and st["path"] == 1
+
+
+def test_multi_gpu_path_small_k_wide_index(monkeypatch):
+    """k=17 with a 3-byte index: an index bucket (12 bases) is FINER than a window block (8 bases), so only
+    every 256th bucket boundary may carry a cut"""
+    g = load_golden("k17_i1")
+    g = dict(g, ibyte=3, nparts=3)
+    monkeypatch.setenv("SMG_VIRTUAL_SHARDS", "4")
+    plot, st = engine.hetmers_run(make_table(g), symcheck="hash")
+    assert engine.smu_text(plot) == g["smu"]
+
+
+def test_multi_gpu_path_medium_table_and_executable(tmp_path, monkeypatch):
+    k = 31
+    keys, cnt = synth.diploid_table_u64(200000, k=k, seed=15, het_frac=0.3, cov=40, L=8)
+    packed = ktab.u64_to_packed(keys, k)
+    ktab.write_ktab(str(tmp_path / "t"), k, packed, cnt, ibyte=2, nparts=3)
+    subprocess.run([ORACLE_BIN, "-e8", f"-o{tmp_path}/orc", str(tmp_path / "t")], check=True)
+    want = (tmp_path / "orc.smu").read_text()
+    env = dict(os.environ, SMUDGEPLOT_GPUS="4", SMG_VIRTUAL_SHARDS="4")
+    r = subprocess.run([HETMERS_BIN, "-e8", "-T4", "-v", "-ogpu4", "t"], cwd=tmp_path, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "gpus=4 (virtual shards on one device)" in r.stderr
+    assert (tmp_path / "gpu4.smu").read_text() == want
+    # untrimmed input: every shard trims its own entries
+    cnt2 = cnt.copy()
+    rng = np.random.default_rng(1)
+    # lower BOTH members of some complement classes below the threshold (the table stays symmetric)
+    rc = ktab.revcomp_u64(keys, k)
+    j = np.searchsorted(keys, rc)
+    pick = rng.random(len(keys)) < 0.1
+    pick = pick | pick[j]
+    cnt2[pick] = 3
+    ktab.write_ktab(str(tmp_path / "u"), k, packed, cnt2, ibyte=2, nparts=2)
+    keep = cnt2 >= 8
+    ktab.write_ktab(str(tmp_path / "uc"), k, packed[keep], cnt2[keep], ibyte=2, nparts=2)
+    subprocess.run([ORACLE_BIN, "-e8", f"-o{tmp_path}/orc2", str(tmp_path / "uc")], check=True)
+    r = subprocess.run([HETMERS_BIN, "-e8", "-v", "-ogpu2", "u"], cwd=tmp_path, capture_output=True, text=True,
+                       env=dict(os.environ, SMUDGEPLOT_GPUS="3", SMG_VIRTUAL_SHARDS="3"))
+    assert r.returncode == 0, r.stderr
+    assert "  The input table is untrimmed yet symmetric\n" in r.stderr and "gpus=3" in r.stderr
+    assert (tmp_path / "gpu2.smu").read_text() == (tmp_path / "orc2.smu").read_text()
+    # a table that is not closed: the multi-GPU path refuses it loudly (one GPU would take the general path)
+    bad = np.ones(len(cnt), bool); bad[len(cnt) // 3] = False
+    monkeypatch.setenv("SMG_VIRTUAL_SHARDS", "2")
+    with pytest.raises(engine.EngineError) as ei:
+        engine.hetmers_run(table_from(packed[bad], cnt[bad], k), symcheck="hash")
+    assert ei.value.code == -5
+
+
+def test_multi_gpu_path_one_rank_rccl(monkeypatch):
+    """SMG_FORCE_MULTI: the multi-GPU path with ONE rank on the real RCCL calls (communicator, grouped
+    send/recv to self, all-reduce) -- the most a 1-GPU box can check of them"""
+    g = load_golden("k31_i3_p4")
+    monkeypatch.setenv("SMG_FORCE_MULTI", "1")
+    plot, st = engine.hetmers_run(make_table(g), symcheck="hash", verbose=1)
+    assert engine.smu_text(plot) == g["smu"]
