@@ -501,3 +501,35 @@ def test_multi_gpu_path_one_rank_rccl(monkeypatch):
     monkeypatch.setenv("SMG_FORCE_MULTI", "1")
     plot, st = engine.hetmers_run(make_table(g), symcheck="hash", verbose=1)
     assert engine.smu_text(plot) == g["smu"]
+
+
+def test_config4_octoploid_standin_eight_shards_vs_reference(tmp_path):
+    """BASELINE configs[3] (Fragaria x ananassa, octoploid, 8 GPUs) as a synthetic stand-in: 8 haplotypes with
+    independent SNPs, k=31.  The drop-in executable runs it as EIGHT prefix shards (virtual shards on this
+    box's one GPU: same cutting / routing / reduction as 8 GPUs, copies instead of RCCL) and must be byte
+    identical to the reference binary on the same files; one GPU must agree too."""
+    import torch
+    from conftest import REF_BIN
+    from smudgeplot_amd import synth_device
+    if not os.path.exists(REF_BIN):
+        pytest.skip("prebuilt reference binary not present")
+    k, L = 31, 12
+    tk, tc = synth_device.polyploid_table(600_000, ploidy=8, div=0.02, cov_hap=15.0, k=k, L=L, seed=4, device="cuda:0")
+    keys = tk.cpu().numpy().view(np.uint64); cnt = tc.cpu().numpy().view(np.uint16)
+    del tk, tc
+    assert len(cnt) > 3_000_000
+    synth.write_u64_table(str(tmp_path / "t"), keys, cnt, k, ibyte=3, nparts=8)
+    r = subprocess.run([REF_BIN, f"-e{L}", f"-T{min(32, os.cpu_count() or 1)}", "-oref", "t.ktab"], cwd=tmp_path,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    want = (tmp_path / "ref.smu").read_text()
+    assert want.count("\n") > 1000
+    for gpus, out in ((8, "g8"), (1, "g1")):
+        env = dict(os.environ, SMUDGEPLOT_GPUS=str(gpus))
+        if gpus > 1:
+            env["SMG_VIRTUAL_SHARDS"] = str(gpus)
+        q = subprocess.run([HETMERS_BIN, f"-e{L}", "-T8", "-v", f"-o{out}", "t.ktab"], cwd=tmp_path, capture_output=True,
+                           text=True, env=env)
+        assert q.returncode == 0, q.stderr
+        assert (f"gpus={gpus}" in q.stderr) == (gpus > 1)
+        assert (tmp_path / f"{out}.smu").read_text() == want, gpus
