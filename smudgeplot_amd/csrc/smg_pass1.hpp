@@ -39,6 +39,9 @@
 #define R_WIN   30                       // partners are searched within +-30 entries
 #define R_CRED  (R_SCAN + 32)
 #define R_BIG   0x80000000u
+// (A bank-conflict-free SoA layout of cred/ent/lcn -- slot s at (s&3)*264 + (s>>2) -- was measured: the v5 PMC
+//  shows more LDS conflict cycles than LDS issue cycles, but the extra index arithmetic and the narrower
+//  LDS writes cost more VALU than the conflicts cost time: 21.9 ms vs 20.8 ms.  The kernel is VALU bound.)
 #ifndef R_D
 #define R_D     3                        // distances scanned in registers; farther partners: tail loop
 #endif
