@@ -396,6 +396,34 @@ kf_apply_sorted(FastArgs A, const u64 *__restrict__ keys_sorted, int64_t nreq, F
 // (Running 4 independent look-ups per thread in lockstep was tried and lost 1.1 ms of 8.1: the kernel streams
 // ~26 GB -- every k-mer line of the table is touched -- so it is bandwidth, not latency, that bounds it.)
 
+// ---- look-ups of records with a count/flag word (W > 1, or the exact proof): ordered through an index -----
+// The records are (W+1) words wide, too wide to be moved by every radix pass: a (leading 32 k-mer bits,
+// record number) pair is sorted instead and the look-ups walk the records in that order.
+__global__ void __launch_bounds__(F_TPB)
+kf_sortkey(const u64 *__restrict__ rec, int rw, int64_t n, uint32_t *__restrict__ key, uint32_t *__restrict__ idx)
+{ const int64_t stride = (int64_t) gridDim.x * F_TPB;
+  for (int64_t r = (int64_t) blockIdx.x * F_TPB + threadIdx.x; r < n; r += stride)
+    { key[r] = (uint32_t) (rec[r * rw] >> 32); idx[r] = (uint32_t) r; }
+}
+
+template <int W> __global__ void __launch_bounds__(F_TPB)
+kf_apply_indexed(FastArgs A, const u64 *__restrict__ rec, const uint32_t *__restrict__ perm, int64_t n,
+                 int check_count, FastCtl *__restrict__ ctl)
+{ const int64_t stride = (int64_t) gridDim.x * F_TPB;
+  for (int64_t r = (int64_t) blockIdx.x * F_TPB + threadIdx.x; r < n; r += stride)
+    { const u64 *q = rec + (size_t) perm[r] * (W + 1);
+      Key<W> y;
+#pragma unroll
+      for (int w = 0; w < W; w++) y.w[w] = q[w];
+      const u64 meta = q[W];
+      const int64_t j = find_key<W>(A.keys, A.dir, y);
+      bool bad = j < 0;
+      if (!bad && check_count) bad = A.cnt[j] != (unsigned) (meta & 0xFFFF);
+      if (bad) { if (ctl->missing == 0) ctl->missing = 1; continue; }
+      if (meta >> 16 & 1) A.pflag[j] = 1;
+    }
+}
+
 // exact symmetry proof of every local entry against the local table (single GPU)
 template <int W> __global__ void __launch_bounds__(F_TPB)
 kf_verify(FastArgs A, FastCtl *__restrict__ ctl)
@@ -687,7 +715,7 @@ kf_route_scatter(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk
 // Entries deferred by kf_pass1_r (their window block is longer than the +-30 entry window): exact walk by
 // binary searches, final code byte, and -- for the ones that own a pair at p > k-1-p -- a request.
 // One chunk per workgroup iteration batch, same chunk list as pass 1.
-template <int RW> __global__ void __launch_bounds__(F_TPB)
+template <int W, int RW> __global__ void __launch_bounds__(F_TPB)
 kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, unsigned nbig, u64 *__restrict__ req,
           uint32_t *__restrict__ chunk_fill, unsigned max_chunks, FastCtl *__restrict__ ctl)
 { constexpr int rw = RW;
@@ -703,14 +731,15 @@ kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, unsigned nbig, u64 *
         { const int64_t i = biglist[r];
           unsigned s_all, s_hi, w2;
           int64_t partner;
-          big_block_scan<1>(A.keys, A.cnt, A.n, A.g, i, s_all, s_hi, partner, w2);
+          big_block_scan<W>(A.keys, A.cnt, A.n, A.g, i, s_all, s_hi, partner, w2);
           A.code[i] = (uint8_t) make_code(s_all, partner - i, w2);
           if (s_hi > 0)
-            { Key<1> kx = load_key<1>(A.keys, i);
-              const Key<1> rc = revcomp<1>(kx, A.g.k);
+            { const Key<W> kx = load_key<W>(A.keys, i);
+              const Key<W> rc = revcomp<W>(kx, A.g.k);
               const unsigned q = atomicAdd(&s_qn, 1u);
-              sq[q * rw] = rc.w[0];
-              if (rw == 2) sq[q * rw + 1] = (u64) A.cnt[i] | (1ull << 16);
+#pragma unroll
+              for (int w = 0; w < W; w++) sq[q * rw + w] = rc.w[w];
+              if (rw > W) sq[q * rw + W] = (u64) A.cnt[i] | (1ull << 16);
             }
         }
       __syncthreads();

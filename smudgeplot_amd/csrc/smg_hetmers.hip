@@ -405,6 +405,8 @@ struct smg_engine
   void        *sort_tmp; int64_t sort_tmp_cap;
   u64         *dense;  int64_t dense_cap;    // compacted requests
   uint32_t    *chunk_off; int64_t chunk_off_cap;
+  uint32_t    *skey[2]; int64_t skey_cap[2];   // index sort of wide records: leading k-mer bits (in, out)
+  uint32_t    *sidx[2]; int64_t sidx_cap[2];   //                                  record numbers (in, out)
   uint32_t    *biglist; int64_t biglist_cap;    // bytes
   int          rw;                           // 64-bit words per request record
   uint32_t    *chunk_fill; int64_t chunk_cap; // bytes
@@ -420,7 +422,7 @@ struct smg_engine
   Dir          dir;
   bool         prepared;      // pass 1 of the current table has run
   bool         fast;          // fast path in use
-  unsigned     p1_grid[2][2]; // resident workgroups of kf_pass1_r<RW, ODD> (0 = not asked yet)
+  unsigned     p1_grid[2][3]; // resident workgroups of kf_pass1_r<W, RW, ..> by [W-1][RW-1] (0 = not asked yet)
   unsigned     n_chunks;
   u64          fp[4];
   smg_stats    st;
@@ -484,7 +486,7 @@ extern "C" void smg_engine_destroy(smg_engine *e)
   hipSetDevice(e->device);
   hipStreamSynchronize(e->stream);
   hipFree(e->own_keys); hipFree(e->own_cnt); hipFree(e->deg); hipFree(e->pflag); hipFree(e->bstart);
-  hipFree(e->req); hipFree(e->req2); hipFree(e->sort_tmp); hipFree(e->dense); hipFree(e->chunk_off); hipFree(e->biglist); hipFree(e->chunk_fill); hipFree(e->route_cnt); hipFree(e->route_off);
+  hipFree(e->req); hipFree(e->req2); hipFree(e->sort_tmp); hipFree(e->dense); hipFree(e->chunk_off); hipFree(e->skey[0]); hipFree(e->skey[1]); hipFree(e->sidx[0]); hipFree(e->sidx[1]); hipFree(e->biglist); hipFree(e->chunk_fill); hipFree(e->route_cnt); hipFree(e->route_off);
   hipFree(e->partials); hipFree(e->ctrl); hipFree(e->d_split);
   hipHostFree(e->h_ctrl); hipHostFree(e->h_partials);
   for (int i = 0; i < 8; i++) hipEventDestroy(e->ev[i]);
@@ -776,32 +778,41 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
       memset(e->fp, 0, sizeof(e->fp));
       return SMG_OK;
     }
-  const bool narrow = e->W == 1;                       // k <= 32: the specialised kernel
+  const bool narrow = e->W <= 2;                       // k <= 64: kf_pass1_r (blocked register scan)
   const int64_t ntiles = narrow ? (e->n + R_OWN - 1) / R_OWN : (e->n + F_TILE - 1) / F_TILE;
   GeoR gr;
   { const int p0 = e->kmer / 2, sbits = 2 * (e->kmer - p0);
-    gr.k = e->kmer; gr.kshift = 64 - 2 * e->kmer;
-    gr.pshift = 32 - 2 * p0;
-    gr.smask = sbits >= 32 ? 0xFFFFFFFFu : ((1u << sbits) - 1u);
+    gr.k = e->kmer;
+    if (e->W == 1)
+      { gr.kshift = 64 - 2 * e->kmer;
+        gr.pshift = 32 - 2 * p0;
+      }
+    else
+      { gr.kshift = 128 - 2 * e->kmer;                 // 33 <= k <= 64: 0 .. 62
+        gr.pshift = 64 - 2 * p0;                        // p0 = 16 .. 32
+      }
+    gr.smask = sbits >= 64 ? ~0ull : ((1ull << sbits) - 1ull);
     gr.mshift = sbits - 2;
   }
   const bool odd = (e->kmer & 1) != 0;
   unsigned grid = P1_GRID;
   if (narrow)
     { // persistent workgroups: exactly what is resident (a static tile stride must not have stragglers)
-      if (!e->p1_grid[e->rw - 1][odd])
+      unsigned &cached = e->p1_grid[e->W - 1][e->rw - 1];
+      if (!cached)
         { int nb = 0, cus = 0;
           hipError_t he;
-          // (the four RW x ODD variants of one KF class use the same registers and LDS: ask for one of them)
-          if (e->rw == 1) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kf_pass1_r<1, true, true>, R_TPB, 0);
-          else            he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kf_pass1_r<2, true, true>, R_TPB, 0);
-          if (he != hipSuccess || nb < 1) nb = 4;
+          // (the ODD / KF variants of one (W, RW) class use the same registers and LDS: ask for one of them)
+          if (e->W == 1 && e->rw == 1) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kf_pass1_r<1, 1, true, true>, R_TPB, 0);
+          else if (e->W == 1)          he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kf_pass1_r<1, 2, true, true>, R_TPB, 0);
+          else                         he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kf_pass1_r<2, 3, true, false>, R_TPB, 0);
+          if (he != hipSuccess || nb < 1) nb = 3;
           if (nb > 8) nb = 8;
           if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || cus < 1) cus = 256;
           { const char *g = getenv("SMG_P1_WGS_PER_CU"); if (g && atoi(g) > 0) nb = atoi(g); }
-          e->p1_grid[e->rw - 1][odd] = (unsigned) (nb * cus);
+          cached = (unsigned) (nb * cus);
         }
-      grid = e->p1_grid[e->rw - 1][odd];
+      grid = cached;
     }
   if (grid > P1_MAXGRID) grid = P1_MAXGRID;
   if ((int64_t) grid > ntiles) grid = (unsigned) ntiles;
@@ -823,13 +834,14 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
       hipEventRecord(e->ev[2], e->stream);
       if (narrow)
         {
-#define LAUNCH_R(RW_, ODD_, KF_) hipLaunchKernelGGL((kf_pass1_r<RW_, ODD_, KF_>), dim3(grid), dim3(R_TPB), 0, e->stream, a, gr, \
+#define LAUNCH_R(W_, RW_, ODD_, KF_) hipLaunchKernelGGL((kf_pass1_r<W_, RW_, ODD_, KF_>), dim3(grid), dim3(R_TPB), 0, e->stream, a, gr, \
                               e->bstart, e->req, e->chunk_fill, maxc, e->biglist, (unsigned) big_cap, emit_all, want_fp, \
                               e->partials, &e->ctrl->fast, ntiles)
-#define LAUNCH_R2(RW_, ODD_) { if (kf) LAUNCH_R(RW_, ODD_, true); else LAUNCH_R(RW_, ODD_, false); }
+#define LAUNCH_R2(RW_, ODD_) { if (kf) LAUNCH_R(1, RW_, ODD_, true); else LAUNCH_R(1, RW_, ODD_, false); }
           const bool kf = gr.pshift < 32 && gr.kshift < 32;          // 17 <= k <= 32
-          if (e->rw == 1) { if (odd) LAUNCH_R2(1, true) else LAUNCH_R2(1, false) }
-          else            { if (odd) LAUNCH_R2(2, true) else LAUNCH_R2(2, false) }
+          if (e->W == 2)       { if (odd) LAUNCH_R(2, 3, true, false); else LAUNCH_R(2, 3, false, false); }
+          else if (e->rw == 1) { if (odd) LAUNCH_R2(1, true) else LAUNCH_R2(1, false) }
+          else                 { if (odd) LAUNCH_R2(2, true) else LAUNCH_R2(2, false) }
 #undef LAUNCH_R2
 #undef LAUNCH_R
         }
@@ -864,12 +876,10 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
           const unsigned nbig = e->h_ctrl->fast.nbig;
           unsigned fb = (nbig + F_TPB - 1) / F_TPB;
           if (fb > 256) fb = 256;
-          if (e->rw == 1)
-            hipLaunchKernelGGL(kf_bigfix<1>, dim3(fb), dim3(F_TPB), 0, e->stream, a, e->biglist, nbig, e->req,
-                               e->chunk_fill, maxc, &e->ctrl->fast);
-          else
-            hipLaunchKernelGGL(kf_bigfix<2>, dim3(fb), dim3(F_TPB), 0, e->stream, a, e->biglist, nbig, e->req,
-                               e->chunk_fill, maxc, &e->ctrl->fast);
+#define BIGFIX(W_, RW_) hipLaunchKernelGGL((kf_bigfix<W_, RW_>), dim3(fb), dim3(F_TPB), 0, e->stream, a, e->biglist, nbig, e->req, \
+                              e->chunk_fill, maxc, &e->ctrl->fast)
+          if (e->W == 2) BIGFIX(2, 3); else if (e->rw == 1) BIGFIX(1, 1); else BIGFIX(1, 2);
+#undef BIGFIX
           hipEventRecord(e->ev[3], e->stream);
           if ((rc = read_ctrl(e, errbuf, errlen))) return rc;
           if (e->h_ctrl->fast.n_chunks > maxc)
@@ -934,6 +944,40 @@ static int apply_sorted(smg_engine *e, const u64 *keys_in, int64_t nsort, char *
   return SMG_OK;
 }
 
+// records with a count/flag word: sort (leading 32 k-mer bits, record number) pairs on the upper 24 bits, look up in
+// that order (small batches are looked up as they come)
+static int apply_indexed(smg_engine *e, const u64 *rec, int64_t n, int check_count, char *errbuf, size_t errlen)
+{ int rc;
+  if (n <= 0) return SMG_OK;
+  FastArgs a = make_fast(e);
+  int64_t nb = (n + F_TPB - 1) / F_TPB;
+  if (nb > 16384) nb = 16384;
+  if (n < SORT_MIN || n >= 0xFFFFFFF0ll)
+    {
+#define CALL(WW) hipLaunchKernelGGL(kf_apply<WW>, dim3((unsigned) (nb > 8192 ? 8192 : nb)), dim3(F_TPB), 0, e->stream, a, rec, \
+                   (const uint32_t *) NULL, n, check_count, &e->ctrl->fast)
+      DISPATCH_W3(e, CALL)
+#undef CALL
+      return SMG_OK;
+    }
+  for (int q = 0; q < 2; q++)
+    { if ((rc = grow(&e->skey[q], &e->skey_cap[q], n * 4 + 16, errbuf, errlen))) return rc;
+      if ((rc = grow(&e->sidx[q], &e->sidx_cap[q], n * 4 + 16, errbuf, errlen))) return rc;
+    }
+  hipLaunchKernelGGL(kf_sortkey, dim3((unsigned) nb), dim3(F_TPB), 0, e->stream, rec, e->W + 1, n, e->skey[0], e->sidx[0]);
+  size_t tmp = 0;
+  HIPCHK(rocprim::radix_sort_pairs<smg_sort_config>(nullptr, tmp, e->skey[0], e->skey[1], e->sidx[0], e->sidx[1], (size_t) n,
+                                                    8u, 32u, e->stream));
+  if ((rc = grow((char **) &e->sort_tmp, &e->sort_tmp_cap, (int64_t) tmp + 16, errbuf, errlen))) return rc;
+  HIPCHK(rocprim::radix_sort_pairs<smg_sort_config>(e->sort_tmp, tmp, e->skey[0], e->skey[1], e->sidx[0], e->sidx[1], (size_t) n,
+                                                    8u, 32u, e->stream));
+#define CALL(WW) hipLaunchKernelGGL(kf_apply_indexed<WW>, dim3((unsigned) nb), dim3(F_TPB), 0, e->stream, a, rec, e->sidx[1], n, \
+                   check_count, &e->ctrl->fast)
+  DISPATCH_W3(e, CALL)
+#undef CALL
+  return SMG_OK;
+}
+
 static int fast_apply(smg_engine *e, const u64 *flat, int64_t nflat, int check_count, int64_t *missing,
                       char *errbuf, size_t errlen)
 { FastArgs a = make_fast(e);
@@ -962,20 +1006,25 @@ static int fast_apply(smg_engine *e, const u64 *flat, int64_t nflat, int check_c
       if (rc) return rc;
     }
   else if (!flat && e->n_chunks > 0)
-    {
-#define CALL(WW) hipLaunchKernelGGL(kf_apply<WW>, dim3(e->n_chunks), dim3(F_TPB), 0, e->stream, a, e->req, \
-                   e->chunk_fill, (int64_t) 0, check_count, &e->ctrl->fast)
-      DISPATCH_W3(e, CALL)
-#undef CALL
+    { // records with a count/flag word (W > 1, exact proof): compact the chunks, then index-sorted look-ups
+      const int64_t nreq = e->st.nrequests;
+      if (nreq > 0)
+        { const int rw = e->rw;
+          if ((rc = grow(&e->dense, &e->dense_cap, nreq * (int64_t) sizeof(u64) * rw, errbuf, errlen))) return rc;
+          if ((rc = grow(&e->chunk_off, &e->chunk_off_cap, (int64_t) e->n_chunks * 4 + 4, errbuf, errlen))) return rc;
+          size_t tmp = 0;
+          HIPCHK(rocprim::exclusive_scan(nullptr, tmp, e->chunk_fill, e->chunk_off, 0u, (size_t) e->n_chunks,
+                                         rocprim::plus<uint32_t>(), e->stream));
+          if ((rc = grow((char **) &e->sort_tmp, &e->sort_tmp_cap, (int64_t) tmp + 16, errbuf, errlen))) return rc;
+          HIPCHK(rocprim::exclusive_scan(e->sort_tmp, tmp, e->chunk_fill, e->chunk_off, 0u, (size_t) e->n_chunks,
+                                         rocprim::plus<uint32_t>(), e->stream));
+          hipLaunchKernelGGL(kf_compact, dim3(e->n_chunks), dim3(F_TPB), 0, e->stream, e->req, e->chunk_fill,
+                             e->chunk_off, rw, e->dense);
+          if ((rc = apply_indexed(e, e->dense, nreq, check_count, errbuf, errlen))) return rc;
+        }
     }
   else if (flat && nflat > 0)
-    { int64_t nb = (nflat + F_TPB - 1) / F_TPB;
-      if (nb > 8192) nb = 8192;
-#define CALL(WW) hipLaunchKernelGGL(kf_apply<WW>, dim3((unsigned) nb), dim3(F_TPB), 0, e->stream, a, flat, \
-                   (const uint32_t *) NULL, nflat, check_count, &e->ctrl->fast)
-      DISPATCH_W3(e, CALL)
-#undef CALL
-    }
+    { if ((rc = apply_indexed(e, flat, nflat, check_count, errbuf, errlen))) return rc; }
   hipEventRecord(e->ev[5], e->stream);
   HIPCHK(hipGetLastError());
   rc = read_ctrl(e, errbuf, errlen);

@@ -1,4 +1,4 @@
-// smg_pass1.hpp -- kf_pass1_r: pass 1 for k <= 32 (one 64-bit word per k-mer), the headline kernel.
+// smg_pass1.hpp -- kf_pass1_r: pass 1 for k <= 64 (W = 1 or 2 64-bit words per k-mer); W = 1 is the headline kernel.
 //
 // The v3 kernel (kf_pass1_s, LDS-staged strided scan) turned out to be VALU-issue bound: 310 vector
 // instructions per table entry, VALU pipes 83 % busy, HBM at 1.8 TB/s (profiles/r01_v3_pmc_*).  This
@@ -47,52 +47,67 @@
 #endif
 #define R_QCAP  1536                     // LDS request queue (records); flushed when the next tile might not fit
 
+// per-entry scan words: the first p0 bases ("pre") and the last k-p0 bases ("suf") of the k-mer, each in ONE
+// machine word of this type: 32 bits for k <= 32 (p0 <= 16), 64 bits for 33 <= k <= 64 (p0 <= 32)
+template <int W> struct RWord;
+template <> struct RWord<1> { typedef unsigned type; };
+template <> struct RWord<2> { typedef u64 type; };
+
 struct GeoR
-{ int      k;
-  int      pshift;       // pre = hi >> pshift            (32 - 2*p0; 32 means "no prefix": k == 1)
-  int      kshift;       // 64 - 2k
-  unsigned smask;        // low 2*(k-p0) bits
-  int      mshift;       // odd k: suffix >> mshift != 0  <=> the top suffix base (position p0) differs
+{ int  k;
+  int  pshift;       // W=1: pre = hi32 >> pshift (32 - 2*p0; 32 means "no prefix": k == 1);  W=2: pre = w0 >> pshift (64 - 2*p0)
+  int  kshift;       // W=1: 64 - 2k;  W=2: 128 - 2k  (the k-mer is left aligned in W words)
+  u64  smask;        // low 2*(k-p0) bits
+  int  mshift;       // odd k: suffix >> mshift != 0  <=> the top suffix base (position p0) differs
 };
+
+SMG_DEV int r_popc(unsigned v) { return __popc(v); }
+SMG_DEV int r_popc(u64 v) { return __popcll(v); }
 
 // contribution of one pair to its LOWER entry: count 1 | delta code (31 + d) << 8 | mid << 24; the UPPER
 // entry gets the same with delta code 31 - d.  With exactly one pair the delta field IS the code byte.
-template <bool ODD> SMG_DEV unsigned r_val(unsigned dd, int d, const GeoR &G)
+template <bool ODD, typename WT> SMG_DEV unsigned r_val(WT dd, int d, const GeoR &G)
 { unsigned v = 1u | ((unsigned) (31 + d) << 8);
-  if (ODD) v += (dd >> G.mshift) << 24;
+  if (ODD) v += (unsigned) (dd >> G.mshift) << 24;
   return v;
 }
 #define R_UP(v, d) ((v) - ((unsigned) (2 * (d)) << 8))
 
-// KF: 17 <= k <= 32, the k-mer straddles both 32-bit halves (pshift and kshift below 32): no selects
-template <bool KF> SMG_DEV void r_unpack(u64 x, const GeoR &G, unsigned &pre, unsigned &suf)
-{ const unsigned hi = (unsigned) (x >> 32), lo = (unsigned) x;
-  if (KF)
-    { pre = hi >> G.pshift;
-      suf = __builtin_amdgcn_alignbit(hi, lo, G.kshift) & G.smask;
+// KF (W=1 only): 17 <= k <= 32, the k-mer straddles both 32-bit halves (pshift and kshift below 32): no selects
+template <int W, bool KF> SMG_DEV void
+r_unpack(const Key<W> &x, const GeoR &G, typename RWord<W>::type &pre, typename RWord<W>::type &suf)
+{ if constexpr (W == 1)
+    { const unsigned hi = (unsigned) (x.w[0] >> 32), lo = (unsigned) x.w[0];
+      if (KF)
+        { pre = hi >> G.pshift;
+          suf = __builtin_amdgcn_alignbit(hi, lo, G.kshift) & (unsigned) G.smask;
+        }
+      else
+        { pre = G.pshift < 32 ? hi >> G.pshift : 0u;
+          suf = (G.kshift >= 32 ? hi >> (G.kshift - 32) : __builtin_amdgcn_alignbit(hi, lo, G.kshift)) & (unsigned) G.smask;
+        }
     }
   else
-    { pre = G.pshift < 32 ? hi >> G.pshift : 0u;
-      suf = (G.kshift >= 32 ? hi >> (G.kshift - 32) : __builtin_amdgcn_alignbit(hi, lo, G.kshift)) & G.smask;
+    { pre = x.w[0] >> G.pshift;                                     // pshift = 64 - 2*p0 in 0..32
+      suf = (G.kshift ? (x.w[1] >> G.kshift) | (x.w[0] << (64 - G.kshift)) : x.w[1]) & G.smask;
     }
 }
 
 // the 12 register tests of one thread: entries 0..3 are its own, 4..6 its right neighbour's
-template <bool ODD, bool CHECK> SMG_DEV void
-r_slots(const unsigned (&pre)[8], const unsigned (&suf)[8], const unsigned (&cn)[8], const GeoR &G,
-        unsigned (&acc)[4 + R_D])
-{
+template <bool ODD, bool CHECK, typename WT> SMG_DEV void
+r_slots(const WT (&pre)[8], const WT (&suf)[8], const unsigned (&cn)[8], const GeoR &G, unsigned (&acc)[4 + R_D])
+{ const WT AA = (WT) 0xAAAAAAAAAAAAAAAAull;
 #pragma unroll
   for (int a = 0; a < 4; a++)
     {
 #pragma unroll
       for (int d = 1; d <= R_D; d++)
         { const int b = a + d;
-          const unsigned dd = suf[a] ^ suf[b];
-          const unsigned tt = ((dd << 1) | dd) & 0xAAAAAAAAu;
-          bool hit = (pre[a] == pre[b]) && (__popc(tt) == 1);
+          const WT dd = suf[a] ^ suf[b];
+          const WT tt = ((dd << 1) | dd) & AA;
+          bool hit = (pre[a] == pre[b]) && (r_popc(tt) == 1);
           if (CHECK) hit = hit && (cn[a] + cn[b] <= SMG_SMAX);
-          const unsigned v = r_val<ODD>(dd, d, G);
+          const unsigned v = r_val<ODD, WT>(dd, d, G);
           acc[a] += hit ? v : 0u;
           acc[b] += hit ? R_UP(v, d) : 0u;
         }
@@ -106,11 +121,13 @@ struct RShared                            // the workgroup's LDS arrays (pointer
 
 // One tile: phases 1-3.  INNER tiles lie completely inside the table (all but the first and the last one):
 // vector loads, no bounds checks, no table-end cases in the directory code.
-template <int RW, bool ODD, bool KF, bool INNER> SMG_DEV void
+// RW = 64-bit words per request record: W (the complement k-mer) or W + 1 (+ count | has-hi-pair << 16).
+template <int W, int RW, bool ODD, bool KF, bool INNER> SMG_DEV void
 r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict__ bstart,
        FastCtl *__restrict__ ctl, int emit_all, int want_fp, int64_t g0, int t,
        u64 &fa, u64 &fb, unsigned &fneg)
-{ const int slot0 = 4 * t;
+{ typedef typename RWord<W>::type WT;
+  const int slot0 = 4 * t;
   const int64_t i0 = g0 + slot0;
   const int64_t n = A.n;
   const u64 *__restrict__ keys = A.keys;
@@ -121,14 +138,21 @@ r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict_
   // ---- phase 1: load 8 consecutive entries, scan the first three distances in registers ------------------
   // (no software prefetch: 5 resident workgroups per CU hide the load latency, and the registers a
   //  prefetch pins are worth more as occupancy)
-  { u64 kk[8]; unsigned pre[8], suf[8], cn[8];
+  { Key<W> kk[8]; WT pre[8], suf[8]; unsigned cn[8];
     if (INNER)
-      { const u64 *kt = keys + i0;
-        const uint16_t *ct = cnts + i0;
+      { const uint16_t *ct = cnts + i0;
+        if constexpr (W == 1)
+          { const u64 *kt = keys + i0;
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-          { const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(kt + 2 * q);
-            kk[2 * q] = v.x; kk[2 * q + 1] = v.y;
+            for (int q = 0; q < 4; q++)
+              { const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(kt + 2 * q);
+                kk[2 * q].w[0] = v.x; kk[2 * q + 1].w[0] = v.y;
+              }
+          }
+        else
+          {
+#pragma unroll
+            for (int e = 0; e < 8; e++) kk[e] = load_key<W>(keys, i0 + e);
           }
 #pragma unroll
         for (int q = 0; q < 2; q++)
@@ -143,21 +167,38 @@ r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict_
           { const int64_t i = i0 + e;
             const bool ok = i >= 0 && i < n;
             vmask |= (unsigned) ok << e;
-            kk[e] = ok ? keys[i] : 0ull;
+            const Key<W> kx = load_key<W>(keys, ok ? i : 0);
+#pragma unroll
+            for (int w = 0; w < W; w++) kk[e].w[w] = ok ? kx.w[w] : 0ull;
             cn[e] = ok ? (unsigned) cnts[i] : 0xFFFFu;
           }
       }
     //@mark P1_UNPACK
 #pragma unroll
-    for (int e = 0; e < 8; e++) r_unpack<KF>(kk[e], G, pre[e], suf[e]);
+    for (int e = 0; e < 8; e++) r_unpack<W, KF>(kk[e], G, pre[e], suf[e]);
     // LDS copy for the tail loop and the epilogue
-    { ulonglong2 w0, w1;
-      w0.x = kk[0]; w0.y = kk[1]; w1.x = kk[2]; w1.y = kk[3];
-      *reinterpret_cast<ulonglong2 *>(&S.ent[slot0]) = w0;
-      *reinterpret_cast<ulonglong2 *>(&S.ent[slot0 + 2]) = w1;
+    { if constexpr (W == 1)
+        { ulonglong2 w0, w1;
+          w0.x = kk[0].w[0]; w0.y = kk[1].w[0]; w1.x = kk[2].w[0]; w1.y = kk[3].w[0];
+          *reinterpret_cast<ulonglong2 *>(&S.ent[slot0]) = w0;
+          *reinterpret_cast<ulonglong2 *>(&S.ent[slot0 + 2]) = w1;
+        }
+      else
+        {
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            { ulonglong2 v; v.x = kk[r].w[0]; v.y = kk[r].w[1];
+              *reinterpret_cast<ulonglong2 *>(&S.ent[(slot0 + r) * W]) = v;
+            }
+        }
       *reinterpret_cast<ushort4 *>(&S.lcn[slot0]) = make_ushort4((unsigned short) cn[0], (unsigned short) cn[1],
                                                                (unsigned short) cn[2], (unsigned short) cn[3]);
-      if (t == R_TPB - 1) { S.ent[R_SCAN] = kk[4]; S.lcn[R_SCAN] = (uint16_t) cn[4]; }
+      if (t == R_TPB - 1)
+        {
+#pragma unroll
+          for (int w = 0; w < W; w++) S.ent[R_SCAN * W + w] = kk[4].w[w];
+          S.lcn[R_SCAN] = (uint16_t) cn[4];
+        }
     }
     //@mark P1_SLOTS
     unsigned acc[4 + R_D];
@@ -166,14 +207,14 @@ r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict_
     { unsigned mx = cn[0];
 #pragma unroll
       for (int e = 1; e < 4 + R_D; e++) mx = mx > cn[e] ? mx : cn[e];
-      if (__all(mx <= SMG_FMAX)) r_slots<ODD, false>(pre, suf, cn, G, acc);
-      else                       r_slots<ODD, true>(pre, suf, cn, G, acc);
+      if (__all(mx <= SMG_FMAX)) r_slots<ODD, false, WT>(pre, suf, cn, G, acc);
+      else                       r_slots<ODD, true, WT>(pre, suf, cn, G, acc);
     }
     //@mark P1_CREDIT
     // every result goes to the entry's credit word (own entries too: frees the registers)
 #pragma unroll
     for (int e = 0; e < 4 + R_D; e++) atomicAdd(&S.cred[slot0 + e], acc[e]);     // unconditional: no VALU spent on tests
-    // entries whose block continues past distance 3
+    // entries whose block continues past distance R_D
     unsigned alive = 0;
 #pragma unroll
     for (int r = 0; r < 4; r++) alive |= (unsigned) (pre[r] == pre[r + R_D + 1]) << r;
@@ -183,7 +224,7 @@ r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict_
   lds_barrier();
 
   //@mark P2_TAIL
-  // ---- phase 2: tail, distances 4..30 from the LDS copy (global memory past the tile edge), rare --------
+  // ---- phase 2: tail, distances R_D+1..30 from the LDS copy (global memory past the tile edge), rare ------
   { const unsigned tn = *S.s_tn;
     // items are dealt to waves 0 and 1 only: the other two skip the whole phase (the kernel is VALU bound)
     for (unsigned q = ((unsigned) (t & 63) << 1) | (unsigned) (t >> 6); t < 128 && q < tn; q += 128)
@@ -191,21 +232,21 @@ r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict_
         const int ts = 4 * (int) (item & 0xFF);
         for (unsigned m = item >> 8; m; m &= m - 1)
           { const int sa = ts + __ffs(m) - 1;
-            unsigned pa, sfa, pb, sfb;
-            r_unpack<KF>(S.ent[sa], G, pa, sfa);
+            WT pa, sfa, pb, sfb;
+            r_unpack<W, KF>(lds_key<W>(S.ent, sa), G, pa, sfa);
             const unsigned ca = S.lcn[sa];
             for (int d = R_D + 1; d <= R_WIN + 1; d++)
               { const int sb = sa + d;
                 unsigned cb;
                 if (!INNER && g0 + sb >= n) break;
-                if (sb < R_SCAN) { r_unpack<KF>(S.ent[sb], G, pb, sfb); cb = S.lcn[sb]; }
-                else             { r_unpack<KF>(keys[g0 + sb], G, pb, sfb); cb = cnts[g0 + sb]; }
+                if (sb < R_SCAN) { r_unpack<W, KF>(lds_key<W>(S.ent, sb), G, pb, sfb); cb = S.lcn[sb]; }
+                else             { r_unpack<W, KF>(load_key<W>(keys, g0 + sb), G, pb, sfb); cb = cnts[g0 + sb]; }
                 if (pb != pa) break;
                 if (d > R_WIN) { atomicOr(&S.cred[sa], R_BIG); atomicOr(&S.cred[sb], R_BIG); break; }
-                const unsigned dd = sfa ^ sfb;
-                const unsigned tt = ((dd << 1) | dd) & 0xAAAAAAAAu;
-                if (__popc(tt) == 1 && ca + cb <= SMG_SMAX)
-                  { const unsigned v = r_val<ODD>(dd, d, G);
+                const WT dd = sfa ^ sfb;
+                const WT tt = ((dd << 1) | dd) & (WT) 0xAAAAAAAAAAAAAAAAull;
+                if (r_popc(tt) == 1 && ca + cb <= SMG_SMAX)
+                  { const unsigned v = r_val<ODD, WT>(dd, d, G);
                     atomicAdd(&S.cred[sa], v);
                     atomicAdd(&S.cred[sb], R_UP(v, d));
                   }
@@ -219,13 +260,13 @@ r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict_
   // ---- phase 3: owned entries, one at a time from LDS (keeps the register count low) ----------------------
   if (slot0 >= R_HALO)
     { unsigned codes = 0;
-      uint32_t bcur = dir_bucket(A.dir, S.ent[slot0]);
+      uint32_t bcur = dir_bucket(A.dir, S.ent[slot0 * W]);
 #pragma unroll 1
       for (int r = 0; r < 4; r++)
         { const int64_t i = i0 + r;
           const bool ok = INNER || (vmask >> r & 1) != 0;
           const unsigned R = S.cred[slot0 + r];
-          const u64 x = S.ent[slot0 + r];
+          const Key<W> x = lds_key<W>(S.ent, slot0 + r);
           const unsigned c = S.lcn[slot0 + r];
           const unsigned count = R & 0xFF, c1 = (R >> 8) & 0x7F;
           const bool w2 = !ODD || ((R >> 24) & 0x7F) == 0;
@@ -239,18 +280,18 @@ r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict_
           //@mark P3_DIR
           // order check + bucket directory: the first entry of every bucket stores its index
           if (INNER)
-            { const u64 xn = S.ent[slot0 + r + 1];
-              const uint32_t bn = dir_bucket(A.dir, xn);
-              if (!(x < xn)) ctl->unsorted = 1;
+            { const Key<W> xn = lds_key<W>(S.ent, slot0 + r + 1);
+              const uint32_t bn = dir_bucket(A.dir, xn.w[0]);
+              if (!key_lt<W>(x, xn)) ctl->unsorted = 1;
               if (bn != bcur) bstart[bn] = (uint32_t) (i + 1);
               bcur = bn;
             }
           else if (ok)
             { if (i == 0) bstart[bcur] = 0u;
               if (i + 1 < n)
-                { const u64 xn = S.ent[slot0 + r + 1];
-                  const uint32_t bn = dir_bucket(A.dir, xn);
-                  if (!(x < xn)) ctl->unsorted = 1;
+                { const Key<W> xn = lds_key<W>(S.ent, slot0 + r + 1);
+                  const uint32_t bn = dir_bucket(A.dir, xn.w[0]);
+                  if (!key_lt<W>(x, xn)) ctl->unsorted = 1;
                   if (bn != bcur) bstart[bn] = (uint32_t) (i + 1);
                   bcur = bn;
                 }
@@ -260,15 +301,12 @@ r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict_
           // complement: for the fingerprint of every owned entry, and for the request of the emitting ones
           const bool emit = ok && !big && (emit_all || hi);
           if (emit || (want_fp && ok))
-            { Key<1> kx, rc;
-              kx.w[0] = x;
-              rc = revcomp<1>(kx, G.k);
+            { const Key<W> rc = revcomp<W>(x, G.k);
               if (want_fp && ok)
-                { const bool lt = x < rc.w[0];
-                  const bool gt = ODD ? !lt : x > rc.w[0];        // odd k: no k-mer is its own complement
-                  Key<1> cz; cz.w[0] = lt ? x : rc.w[0];
+                { const bool lt = key_lt<W>(x, rc);
+                  const bool gt = ODD ? !lt : key_lt<W>(rc, x);   // odd k: no k-mer is its own complement
                   u64 ha, hb;
-                  arx_hash<1>(cz, c, ha, hb);
+                  arx_hash<W>(lt ? x : rc, c, ha, hb);
                   const u64 sg = gt ? ~0ull : 0ull;               // -h == (h ^ ~0) + 1
                   if (ODD) { fa += ha ^ sg; fb += hb ^ sg; }
                   else
@@ -280,8 +318,9 @@ r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict_
               //@mark P3_EMIT
               if (emit)
                 { const unsigned q = atomicAdd(S.s_qn, 1u);
-                  if (RW == 1) S.sq[q] = rc.w[0];
-                  else { S.sq[2 * q] = rc.w[0]; S.sq[2 * q + 1] = (u64) c | ((u64) hi << 16); }
+#pragma unroll
+                  for (int w = 0; w < W; w++) S.sq[q * RW + w] = rc.w[w];
+                  if (RW > W) S.sq[q * RW + W] = (u64) c | ((u64) hi << 16);
                 }
             }
         }
@@ -299,15 +338,15 @@ r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict_
 #define R_WAVES_PER_EU 5
 #endif
 
-template <int RW, bool ODD, bool KF> __global__ void __launch_bounds__(R_TPB)
-__attribute__((amdgpu_waves_per_eu(R_WAVES_PER_EU, R_WAVES_PER_EU)))
+template <int W, int RW, bool ODD, bool KF> __global__ void __launch_bounds__(R_TPB)
+__attribute__((amdgpu_waves_per_eu(W == 2 ? 3 : (RW == 1 ? R_WAVES_PER_EU : 4), W == 2 ? 3 : (RW == 1 ? R_WAVES_PER_EU : 4))))
 kf_pass1_r(FastArgs A, GeoR G, uint32_t *__restrict__ bstart, u64 *__restrict__ req,
            uint32_t *__restrict__ chunk_fill, unsigned max_chunks, uint32_t *__restrict__ biglist,
            unsigned big_cap, int emit_all, int want_fp, u64 *__restrict__ partials,
            FastCtl *__restrict__ ctl, int64_t ntiles)
 { __shared__ unsigned cred[R_CRED];      // per entry: count | delta code << 8 | mid << 24 | BIG
   __shared__ uint16_t tailq[R_TPB];      // thread | alive mask << 8
-  __shared__ u64      ent[R_SCAN + 4];   // the scanned k-mers (+ the first one of the next tile)
+  __shared__ u64      ent[(R_SCAN + 4) * W];   // the scanned k-mers (+ the first one of the next tile)
   __shared__ uint16_t lcn[R_SCAN + 4];
   __shared__ u64      sq[(RW == 1 ? R_QCAP : R_OWN) * RW];
   __shared__ uint32_t sbig[R_OWN];
@@ -330,9 +369,9 @@ kf_pass1_r(FastArgs A, GeoR G, uint32_t *__restrict__ bstart, u64 *__restrict__ 
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
     { const int64_t g0 = tile * R_OWN - R_HALO;
       if (g0 >= 0 && g0 + R_SCAN + 4 <= n)
-        r_tile<RW, ODD, KF, true>(A, G, S, bstart, ctl, emit_all, want_fp, g0, t, fa, fb, fneg);
+        r_tile<W, RW, ODD, KF, true>(A, G, S, bstart, ctl, emit_all, want_fp, g0, t, fa, fb, fneg);
       else
-        r_tile<RW, ODD, KF, false>(A, G, S, bstart, ctl, emit_all, want_fp, g0, t, fa, fb, fneg);
+        r_tile<W, RW, ODD, KF, false>(A, G, S, bstart, ctl, emit_all, want_fp, g0, t, fa, fb, fneg);
       lds_barrier();
       //@mark P4_FLUSH
       // zero the credit words for the next tile
