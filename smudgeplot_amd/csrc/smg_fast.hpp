@@ -54,6 +54,8 @@ struct FastArgs
   Dir             dir;           // bstart written by pass 1, read by apply
   uint8_t        *code;
   uint8_t        *pflag;         // pflag[j] != 0 : entry j has a prefix-side pair
+  uint16_t       *sig;           // k <= 32: the 16 k-mer bits below the directory bucket bits (look-up signatures)
+  int             sigsh;         //          sig[i] = (uint16_t) (keys[i] >> sigsh)
   int             dbg;           // SMG_DBG_SKIP bits (timing experiments only; results invalid)
 };
 
@@ -381,15 +383,53 @@ kf_check_sorted(const u64 *__restrict__ before, const u64 *__restrict__ after, i
 // Requests sorted by k-mer (key-only records): neighbouring lanes look up neighbouring k-mers, so the
 // directory words, the k-mer lines and the P bytes they touch are shared -- the look-ups stream the
 // table once instead of fetching ~4 random 128-byte lines per request.
+// The look-up itself reads SIGNATURES, not k-mers: sig[i] = the 16 k-mer bits below the bucket bits (2 bytes
+// per entry, written by pass 1).  Inside its bucket a request is located by bisection on the signatures; a
+// single matching signature IS the complement (the run only counts if the table is closed under reverse
+// complement, which the fingerprint proves: a request whose complement is absent can then only mark a wrong
+// entry in a run that is discarded anyway); several matching signatures are told apart by their k-mers.
+// This cuts the look-up traffic from 20 GB of k-mer lines to 5 GB of signature lines (+ rare k-mer reads).
 template <int W> __global__ void __launch_bounds__(F_TPB)
 kf_apply_sorted(FastArgs A, const u64 *__restrict__ keys_sorted, int64_t nreq, FastCtl *__restrict__ ctl)
 { const int64_t stride = (int64_t) gridDim.x * F_TPB;
+  const Dir d = A.dir;
   for (int64_t r = (int64_t) blockIdx.x * F_TPB + threadIdx.x; r < nreq; r += stride)
     { Key<W> y;
 #pragma unroll
       for (int w = 0; w < W; w++) y.w[w] = keys_sorted[r * W + w];
-      const int64_t j = find_key<W>(A.keys, A.dir, y);
-      if (j < 0) { if (ctl->missing == 0) ctl->missing = 1; continue; }
+      if (W > 1 || A.sig == NULL)
+        { const int64_t j = find_key<W>(A.keys, A.dir, y);
+          if (j < 0) { if (ctl->missing == 0) ctl->missing = 1; continue; }
+          A.pflag[j] = 1;
+          continue;
+        }
+      const uint32_t hb = (uint32_t) (y.w[0] >> 32) >> d.dsh;
+      bool bad = hb < d.b0 || hb - d.b0 >= d.nb;
+      int64_t lo = 0, hi = 0;
+      if (!bad)
+        { uint32_t b = hb - d.b0;
+          lo = d.bstart[b];
+          bad = lo == (int64_t) DIR_UNSET;
+          if (!bad)
+            { hi = d.bstart[++b];
+              while (hi == (int64_t) DIR_UNSET) hi = d.bstart[++b];
+            }
+        }
+      if (bad) { if (ctl->missing == 0) ctl->missing = 1; continue; }
+      const unsigned sy = (unsigned) (y.w[0] >> A.sigsh) & 0xFFFFu;
+      const int64_t bhi = hi;
+      while (lo < hi)                                    // first entry of the bucket with signature >= sy
+        { const int64_t m = (lo + hi) >> 1;
+          if (A.sig[m] < sy) lo = m + 1; else hi = m;
+        }
+      int64_t j = lo;
+      if (j >= bhi || A.sig[j] != sy) { if (ctl->missing == 0) ctl->missing = 1; continue; }
+      if (j + 1 < bhi && A.sig[j + 1] == sy)             // several entries share the signature: compare k-mers
+        { int64_t e2 = j + 1;
+          while (e2 < bhi && A.sig[e2] == sy) e2++;
+          j = lower_bound_key<W>(A.keys, j, e2, y);
+          if (j >= e2 || !key_eq<W>(load_key<W>(A.keys, j), y)) { if (ctl->missing == 0) ctl->missing = 1; continue; }
+        }
       A.pflag[j] = 1;
     }
 }
