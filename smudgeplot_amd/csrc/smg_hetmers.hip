@@ -771,7 +771,7 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
   if ((rc = grow(&e->deg, &e->deg_cap, ((e->n + 15) & ~15ll) + 32, errbuf, errlen))) return rc;
   const int64_t pbytes = ((e->n + 15) & ~15ll) + 32;
   if ((rc = grow(&e->pflag, &e->pflag_cap, pbytes, errbuf, errlen))) return rc;
-  HIPCHK(hipMemsetAsync(e->pflag, 0, (size_t) pbytes, e->stream));
+  if (e->W > 2) HIPCHK(hipMemsetAsync(e->pflag, 0, (size_t) pbytes, e->stream));   // kf_pass1_r zeroes the flags itself
   if (e->W == 1 && (rc = grow(&e->sig, &e->sig_cap, 2 * pbytes, errbuf, errlen))) return rc;
   if ((rc = dir_geometry(e, errbuf, errlen))) return rc;
   if (e->n > 0)
