@@ -533,3 +533,13 @@ def test_config4_octoploid_standin_eight_shards_vs_reference(tmp_path):
         assert q.returncode == 0, q.stderr
         assert (f"gpus={gpus}" in q.stderr) == (gpus > 1)
         assert (tmp_path / f"{out}.smu").read_text() == want, gpus
+
+
+def test_randomised_soak_against_the_oracle():
+    """tools/soak.py: random k / size / block structure / proof mode / virtual multi-GPU shards / conditioning from
+    raw tables, every plot compared with the numpy oracle (3000 cases were run when this was written)"""
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak.py"), "250", "11"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "250/250 cases agree" in r.stdout
