@@ -56,7 +56,6 @@ struct FastArgs
   uint8_t        *pflag;         // pflag[j] != 0 : entry j has a prefix-side pair
   uint16_t       *sig;           // k <= 32: the 16 k-mer bits below the directory bucket bits (look-up signatures)
   int             sigsh;         //          sig[i] = (uint16_t) (keys[i] >> sigsh)
-  int             dbg;           // SMG_DBG_SKIP bits (timing experiments only; results invalid)
 };
 
 struct FastCtl                    // device control words of the fast path
@@ -89,39 +88,6 @@ template <int W> __device__ __noinline__ void
 big_block_scan(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, int64_t n,
                const Geo g, int64_t i, unsigned &s_all, unsigned &s_hi, int64_t &partner,
                unsigned &w2)
-{ const Key<W> x = load_key<W>(keys, i);
-  const unsigned c = cnt[i];
-  int64_t a = 0, b = i;
-  while (a < b)
-    { const int64_t m = (a + b) >> 1;
-      if (same_block<W>(x, load_key<W>(keys, m), g)) b = m; else a = m + 1;
-    }
-  const int64_t blo = a;
-  a = i + 1; b = n;
-  while (a < b)
-    { const int64_t m = (a + b) >> 1;
-      if (!same_block<W>(x, load_key<W>(keys, m), g)) b = m; else a = m + 1;
-    }
-  const int64_t bhi = a;
-  s_all = 0; s_hi = 0; partner = -1; w2 = 0;
-  for (int p = g.p0; p < g.k; p++)
-    for (int d = 1; d <= 3; d++)
-      { const Key<W> y = flip_base<W>(x, p, d);
-        const int64_t j = lower_bound_key<W>(keys, blo, bhi, y);
-        if (j < bhi && key_eq<W>(load_key<W>(keys, j), y) && c + (unsigned) cnt[j] <= SMG_SMAX)
-          { const unsigned hi = (p != g.k - 1 - p);
-            if (s_all == 0) { partner = j; w2 = hi; }
-            s_all++; s_hi += hi;
-          }
-      }
-}
-
-// same walk, force-inlined: inside kf_pass1_s a real call would spill live registers to scratch,
-// and every scratch reload waits on vmcnt -- which also drains the in-flight tile prefetch
-template <int W> SMG_DEV void
-big_block_scan_inl(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, int64_t n,
-                   const Geo g, int64_t i, unsigned &s_all, unsigned &s_hi, int64_t &partner,
-                   unsigned &w2)
 { const Key<W> x = load_key<W>(keys, i);
   const unsigned c = cnt[i];
   int64_t a = 0, b = i;

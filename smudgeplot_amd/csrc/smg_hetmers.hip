@@ -757,7 +757,6 @@ static FastArgs make_fast(smg_engine *e)
   a.code = e->deg; a.pflag = e->pflag;
   a.sig = e->W == 1 ? e->sig : NULL;
   a.sigsh = 16 + e->dir.dsh;               // the 16 bits right below the directory's bucket bits
-  { const char *d = getenv("SMG_DBG_SKIP"); a.dbg = d ? atoi(d) : 0; }
   return a;
 }
 

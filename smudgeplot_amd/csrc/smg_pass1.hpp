@@ -327,8 +327,7 @@ r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict_
             }
         }
       //@mark P3_STORE
-      if (!(A.dbg & 8))
-        { if (INNER || (vmask & 0xF) == 0xF)
+      { if (INNER || (vmask & 0xF) == 0xF)
             { *reinterpret_cast<unsigned *>(A.code + i0) = codes;
               *reinterpret_cast<unsigned *>(A.pflag + i0) = 0u;          // saves a 1-byte-per-entry memset per run
               if (W == 1) *reinterpret_cast<u64 *>(A.sig + i0) = sigs;
