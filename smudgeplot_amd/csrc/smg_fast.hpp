@@ -430,17 +430,6 @@ kf_apply_indexed(FastArgs A, const u64 *__restrict__ rec, const uint32_t *__rest
     }
 }
 
-// exact symmetry proof of every local entry against the local table (single GPU)
-template <int W> __global__ void __launch_bounds__(F_TPB)
-kf_verify(FastArgs A, FastCtl *__restrict__ ctl)
-{ const int64_t stride = (int64_t) gridDim.x * F_TPB;
-  for (int64_t i = (int64_t) blockIdx.x * F_TPB + threadIdx.x; i < A.n; i += stride)
-    { const Key<W> r = revcomp<W>(load_key<W>(A.keys, i), A.g.k);
-      const int64_t j = find_key<W>(A.keys, A.dir, r);
-      if (j < 0 || A.cnt[j] != A.cnt[i]) { if (ctl->missing == 0) ctl->missing = 1; }
-    }
-}
-
 // ---- pass 2 ------------------------------------------------------------------------------------
 
 SMG_DEV unsigned tri_index(unsigned s, unsigned m)       // cell of (sum, min) in the LDS tile

@@ -427,7 +427,7 @@ struct smg_engine
   unsigned     n_chunks;
   u64          fp[4];
   smg_stats    st;
-  hipEvent_t   ev[8];
+  hipEvent_t   ev[10];        // 0,1 decode  2,3 pass 1  4,5 look-ups  6,7 pass 2  8,9 whole run
 };
 
 static int fail(char *errbuf, size_t errlen, int code, const char *fmt, const char *a = "")
@@ -478,7 +478,7 @@ extern "C" smg_engine *smg_engine_create(int device, void *stream, char *errbuf,
     { fail(errbuf, errlen, SMG_ENOMEM, "cannot allocate the control block%s");
       delete e; return NULL;
     }
-  for (int i = 0; i < 8; i++) hipEventCreate(&e->ev[i]);
+  for (int i = 0; i < 10; i++) hipEventCreate(&e->ev[i]);
   return e;
 }
 
@@ -490,7 +490,7 @@ extern "C" void smg_engine_destroy(smg_engine *e)
   hipFree(e->req); hipFree(e->req2); hipFree(e->sort_tmp); hipFree(e->dense); hipFree(e->chunk_off); hipFree(e->skey[0]); hipFree(e->skey[1]); hipFree(e->sidx[0]); hipFree(e->sidx[1]); hipFree(e->biglist); hipFree(e->chunk_fill); hipFree(e->route_cnt); hipFree(e->route_off);
   hipFree(e->partials); hipFree(e->ctrl); hipFree(e->d_split);
   hipHostFree(e->h_ctrl); hipHostFree(e->h_partials);
-  for (int i = 0; i < 8; i++) hipEventDestroy(e->ev[i]);
+  for (int i = 0; i < 10; i++) hipEventDestroy(e->ev[i]);
   delete e;
 }
 
@@ -983,8 +983,7 @@ static int apply_indexed(smg_engine *e, const u64 *rec, int64_t n, int check_cou
 
 static int fast_apply(smg_engine *e, const u64 *flat, int64_t nflat, int check_count, int64_t *missing,
                       char *errbuf, size_t errlen)
-{ FastArgs a = make_fast(e);
-  int rc;
+{ int rc;
   hipEventRecord(e->ev[4], e->stream);
   if (e->W == 1 && e->rw == 1)
     { if (!flat)
@@ -1031,25 +1030,6 @@ static int fast_apply(smg_engine *e, const u64 *flat, int64_t nflat, int check_c
   hipEventRecord(e->ev[5], e->stream);
   HIPCHK(hipGetLastError());
   rc = read_ctrl(e, errbuf, errlen);
-  if (rc) return rc;
-  float ms = 0; hipEventElapsedTime(&ms, e->ev[4], e->ev[5]);
-  e->st.ms_rclookup += ms;
-  if (missing) *missing = e->h_ctrl->fast.missing;
-  return SMG_OK;
-}
-
-static int fast_verify(smg_engine *e, int64_t *missing, char *errbuf, size_t errlen)
-{ FastArgs a = make_fast(e);
-  hipEventRecord(e->ev[4], e->stream);
-  if (e->n > 0)
-    { int64_t nb = (e->n + F_TPB - 1) / F_TPB;
-      if (nb > 16384) nb = 16384;
-#define CALL(WW) hipLaunchKernelGGL(kf_verify<WW>, dim3((unsigned) nb), dim3(F_TPB), 0, e->stream, a, &e->ctrl->fast)
-      DISPATCH_W3(e, CALL)
-#undef CALL
-    }
-  hipEventRecord(e->ev[5], e->stream);
-  int rc = read_ctrl(e, errbuf, errlen);
   if (rc) return rc;
   float ms = 0; hipEventElapsedTime(&ms, e->ev[4], e->ev[5]);
   e->st.ms_rclookup += ms;
@@ -1184,34 +1164,30 @@ extern "C" int smg_engine_run(smg_engine *e, int symcheck, int64_t *d_plot, smg_
 { if (!e || !d_plot) return fail(errbuf, errlen, SMG_EINVAL, "null argument%s");
   HIPCHK(hipSetDevice(e->device));
   int rc;
-  hipEvent_t t0, t1;
-  hipEventCreate(&t0); hipEventCreate(&t1);
-  hipEventRecord(t0, e->stream);
+  hipEventRecord(e->ev[8], e->stream);
   e->st.ms_pass1 = e->st.ms_rclookup = e->st.ms_pass2 = 0;
   bool symmetric = false;
   if (symcheck != SMG_SYM_NONE && e->kmer <= FAST_MAX_K)
-    { rc = fast_pass1(e, 0, 0, symcheck == SMG_SYM_HASH, errbuf, errlen);
+    { // hash : requests from the entries that own a hi-side pair; closure proven by the fingerprint
+      // exact: EVERY entry sends (rc(kmer), count) and the look-up compares the count -- the same records the
+      //        sharded protocol exchanges, index-sorted look-ups (kf_apply_indexed)
+      const int exact = symcheck == SMG_SYM_EXACT;
+      rc = fast_pass1(e, exact, exact, symcheck == SMG_SYM_HASH, errbuf, errlen);
       if (rc) return rc;
       int64_t missing = 0;
-      // hash mode: the fingerprint covers (k-mer, count), the per-request count check is redundant
-      if ((rc = fast_apply(e, NULL, 0, symcheck != SMG_SYM_HASH, &missing, errbuf, errlen))) return rc;
+      if ((rc = fast_apply(e, NULL, 0, exact, &missing, errbuf, errlen))) return rc;
       symmetric = (missing == 0);
       if (symmetric && symcheck == SMG_SYM_HASH)
         symmetric = e->fp[0] == e->fp[2] && e->fp[1] == e->fp[3];
-      if (symmetric && symcheck == SMG_SYM_EXACT)
-        { if ((rc = fast_verify(e, &missing, errbuf, errlen))) return rc;
-          symmetric = (missing == 0);
-        }
       if (symmetric && (rc = fast_pass2(e, d_plot, errbuf, errlen))) return rc;
     }
   else if (symcheck != SMG_SYM_NONE)
     { if ((rc = counted_symmetric(e, symcheck, d_plot, &symmetric, errbuf, errlen))) return rc; }
   if (!symmetric && (rc = run_general(e, d_plot, errbuf, errlen))) return rc;
-  hipEventRecord(t1, e->stream);
+  hipEventRecord(e->ev[9], e->stream);
   HIPCHK(hipStreamSynchronize(e->stream));
-  float ms = 0; hipEventElapsedTime(&ms, t0, t1);
+  float ms = 0; hipEventElapsedTime(&ms, e->ev[8], e->ev[9]);
   e->st.ms_total = ms;
-  hipEventDestroy(t0); hipEventDestroy(t1);
   if (stats) *stats = e->st;
   return SMG_OK;
 }
