@@ -48,7 +48,7 @@ extern "C" {
    (the property `Symmex` establishes; the reference only spot-checks entry #1,
    PloidyPlot.c:1199-1229).  If the proof fails the engine silently switches to the general
    all-positions path, which assumes nothing, so the answer is the reference's either way. */
-#define SMG_SYM_EXACT  0     /* look up the complement of EVERY entry (exact, ~3x slower)      */
+#define SMG_SYM_EXACT  0     /* look up the complement of EVERY entry (exact, ~4x slower)      */
 #define SMG_SYM_HASH   1     /* 128-bit additive multiset fingerprint of T vs rc(T) + exact   */
                              /* look-ups for the entries that own a pair (what the `hetmers`  */
                              /* executable and bench.py use unless told otherwise)            */
