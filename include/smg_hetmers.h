@@ -120,6 +120,15 @@ int smg_hetmers_extract(const smg_table_view *table, const smg_opts *opts, const
                         smg_stats *stats, char *errbuf, size_t errlen);
 void smg_free(void *p);
 
+/* ---- conditioning as a service: trim / symmetrise a host table, get the conditioned table back -------
+   Stands in for running FastK's `Logex '<out>=A[e-]'` and `Symmex` by hand (the reference's own use of
+   them: PloidyPlot.c:1381-1414).  opts->condition / opts->ethresh select the steps.
+   *keys_out: malloc'ed (smg_free) *nels_out * *words_out uint64, k-mers left aligned, sorted;
+   *counts_out: malloc'ed uint16[*nels_out].                                                          */
+int smg_condition_table(const smg_table_view *table, const smg_opts *opts, uint64_t **keys_out,
+                        uint16_t **counts_out, int64_t *nels_out, int *words_out,
+                        char *errbuf, size_t errlen);
+
 /* number of usable HIP devices (0 when there is none or the runtime is missing)             */
 int smg_device_count(void);
 

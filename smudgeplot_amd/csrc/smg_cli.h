@@ -40,7 +40,7 @@ static char *path_n_root(const char *name, const char *suffix)
   return strdup(name);
 }
 
-static void system_x(const char *command)       /* SystemX, gene_core.c:19-24 */
+__attribute__((unused)) static void system_x(const char *command)       /* SystemX, gene_core.c:19-24 */
 { if (system(command) != 0)
     { fprintf(stderr, "%s: Command '%s' failed\n", Prog_Name, command);
       exit(1);
@@ -82,7 +82,7 @@ typedef struct smg_cli
   int   argc;                  /* positional arguments left in argv[1..argc-1] */
 } smg_cli;
 
-static void smg_cli_parse(int argc, char *argv[], smg_cli *c)
+__attribute__((unused)) static void smg_cli_parse(int argc, char *argv[], smg_cli *c)
 { int flags[128];
   int i, j, k;
   c->nthreads = 4; c->ethresh = 4; c->sort_path = "/tmp"; c->out = NULL;
@@ -125,7 +125,7 @@ static void smg_cli_parse(int argc, char *argv[], smg_cli *c)
   c->verbose = flags['v'];
 }
 
-static void smg_cli_usage_tail(void)
+__attribute__((unused)) static void smg_cli_usage_tail(void)
 { fprintf(stderr, "\n");
   fprintf(stderr, "      -o: root name for output table\n");
   fprintf(stderr, "            default is root of <source> argument\n");
@@ -140,7 +140,7 @@ static void smg_cli_usage_tail(void)
 /* Open the table, probe it, condition it (on the device by default, with FastK's tools when
    SMUDGEPLOT_USE_FASTK_TOOLS=1), fill the engine options.  Returns the name of a temporary
    conditioned table to Fastrm afterwards (malloc'ed) or NULL.   PloidyPlot.c:1341-1426          */
-static char *smg_cli_open_table(const smg_cli *c, const char *SRC, smg_ktab *T, smg_opts *opts)
+__attribute__((unused)) static char *smg_cli_open_table(const smg_cli *c, const char *SRC, smg_ktab *T, smg_opts *opts)
 { const char *troot = "";        /* mktemp("._SPAIR.XXXX") yields "" with 4 X's: temps are
                                     literally ".trim"/".symx" in the cwd  */
   int   trim, symm, use_tools = 0, condition = 0;
@@ -229,7 +229,7 @@ static void smg_cli_table_view(const smg_ktab *T, smg_table_view *tv)
   tv->prefix_index = T->index;
 }
 
-static void smg_cli_remove_temp(char *input)
+__attribute__((unused)) static void smg_cli_remove_temp(char *input)
 { if (input != NULL)
     { char *command = (char *) malloc(strlen(input) + 100);
       if (command == NULL) exit(1);

@@ -1526,3 +1526,51 @@ extern "C" int smg_hetmers_extract(const smg_table_view *tv, const smg_opts *opt
 }
 
 extern "C" void smg_free(void *p) { free(p); }
+
+// ---- stand-alone conditioning: host table in, conditioned host table out (third "next" row of the scope table) ----
+extern "C" int smg_condition_table(const smg_table_view *tv, const smg_opts *opts, uint64_t **keys_out,
+                                   uint16_t **counts_out, int64_t *nels_out, int *words_out,
+                                   char *errbuf, size_t errlen)
+{ if (!tv || !opts || !keys_out || !counts_out || !nels_out || !words_out)
+    return fail(errbuf, errlen, SMG_EINVAL, "null argument%s");
+  *keys_out = NULL; *counts_out = NULL; *nels_out = 0; *words_out = 0;
+  if (tv->ibyte < 1 || tv->ibyte > 3) return fail(errbuf, errlen, SMG_EINVAL, "ibyte must be 1, 2 or 3%s");
+  const int kbyte = (tv->kmer + 3) >> 2, pbyte = kbyte + 2 - tv->ibyte;
+  if (pbyte < 3) return fail(errbuf, errlen, SMG_EINVAL, "k-mer shorter than the index prefix%s");
+  smg_engine *e = smg_engine_create(opts->device, NULL, errbuf, errlen);
+  if (!e) return SMG_ENODEV;
+  int rc = SMG_OK;
+  uint8_t *d_rec = NULL; int64_t *d_index = NULL;
+  uint64_t *hk = NULL; uint16_t *hc = NULL;
+  const size_t ixbytes = sizeof(int64_t) << (8 * tv->ibyte);
+#define BAIL(code, msg) { rc = fail(errbuf, errlen, code, msg "%s"); goto done; }
+  if (hipMalloc(&d_rec, (size_t) (tv->nels > 0 ? tv->nels : 1) * pbyte) != hipSuccess || hipMalloc(&d_index, ixbytes) != hipSuccess)
+    BAIL(SMG_ENOMEM, "out of device memory for the table")
+  if (multi_h2d_records(tv, pbyte, 0, tv->nels, d_rec) != hipSuccess
+      || hipMemcpy(d_index, tv->prefix_index, ixbytes, hipMemcpyHostToDevice) != hipSuccess)
+    BAIL(SMG_ENODEV, "host to device copy failed")
+  if ((rc = smg_engine_decode(e, tv->kmer, tv->ibyte, tv->nels, d_rec, d_index, errbuf, errlen))) goto done;
+  hipFree(d_rec); d_rec = NULL;
+  if (opts->condition
+      && (rc = smg_engine_condition(e, opts->ethresh, opts->condition & SMG_COND_TRIM, opts->condition & SMG_COND_SYMM,
+                                    NULL, errbuf, errlen)))
+    goto done;
+  { const int64_t n = e->n;
+    hk = (uint64_t *) malloc(sizeof(uint64_t) * (size_t) (n > 0 ? n : 1) * e->W);
+    hc = (uint16_t *) malloc(sizeof(uint16_t) * (size_t) (n > 0 ? n : 1));
+    if (!hk || !hc) BAIL(SMG_ENOMEM, "out of host memory for the conditioned table")
+    if (n > 0 && (hipMemcpy(hk, e->keys, sizeof(uint64_t) * (size_t) n * e->W, hipMemcpyDeviceToHost) != hipSuccess
+                  || hipMemcpy(hc, e->cnt, sizeof(uint16_t) * (size_t) n, hipMemcpyDeviceToHost) != hipSuccess))
+      BAIL(SMG_ENODEV, "device to host copy failed")
+    *keys_out = hk; *counts_out = hc; *nels_out = n; *words_out = e->W;
+    hk = NULL; hc = NULL;
+  }
+done:
+#undef BAIL
+  free(hk); free(hc);
+  if (d_rec) hipFree(d_rec);
+  if (d_index) hipFree(d_index);
+  smg_engine_destroy(e);
+  return rc;
+}
+

@@ -61,7 +61,7 @@ EXPORTS = [
     "smg_engine_decode", "smg_engine_bind", "smg_engine_condition", "smg_engine_run", "smg_engine_pass1",
     "smg_engine_nreq", "smg_engine_record_words", "smg_engine_route", "smg_engine_apply",
     "smg_engine_apply_own", "smg_engine_symhash", "smg_engine_pass2", "smg_engine_stats",
-    "smg_engine_extract", "smg_hetmers_extract", "smg_free", "smg_version",
+    "smg_engine_extract", "smg_hetmers_extract", "smg_free", "smg_condition_table", "smg_version",
 ]
 
 _lib = None
@@ -128,6 +128,8 @@ def load_library():
     lib.smg_hetmers_extract.argtypes = [C.POINTER(TableView), C.POINTER(Opts), vp, vp, C.POINTER(vp),
                                         C.POINTER(i64), C.POINTER(i32), C.POINTER(Stats), *err]
     lib.smg_free.argtypes = [vp]
+    lib.smg_condition_table.argtypes = [C.POINTER(TableView), C.POINTER(Opts), C.POINTER(vp), C.POINTER(vp),
+                                        C.POINTER(i64), C.POINTER(i32), *err]
     _lib = lib
     return lib
 

@@ -543,3 +543,31 @@ def test_randomised_soak_against_the_oracle():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak.py"), "250", "11"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "250/250 cases agree" in r.stdout
+
+
+def test_standalone_conditioning_tool_writes_the_numpy_conditioned_table(tmp_path):
+    """smg_condition: raw canonical table in, FastK table out -- the k-mers and counts it writes must equal the
+    numpy conditioning entry for entry, and the REFERENCE binary must accept the file as conditioned"""
+    from conftest import REF_BIN, ROOT
+    tool = os.path.join(ROOT, "smudgeplot_amd", "bin", "smg_condition")
+    for k, ibyte, nparts in ((31, 2, 3), (51, 1, 2), (24, 1, 1)):
+        L = 6
+        (rp, rcnt), (cp, cc) = _raw_table(k, 70 + k, L)
+        ktab.write_ktab(str(tmp_path / f"raw{k}"), k, rp, rcnt, ibyte=ibyte, nparts=nparts)
+        r = subprocess.run([tool, f"-e{L}", "-v", f"raw{k}.ktab", f"cond{k}"], cwd=tmp_path, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        t = ktab.read_ktab(str(tmp_path / f"cond{k}"))
+        assert t.k == k and t.ibyte == ibyte and t.nparts == nparts
+        assert np.array_equal(t.packed, cp) and np.array_equal(t.counts, cc)
+        # trim only / symmetrise only
+        r = subprocess.run([tool, f"-e{L}", "-t", f"raw{k}", f"trim{k}"], cwd=tmp_path, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        tt = ktab.read_ktab(str(tmp_path / f"trim{k}"))
+        keep = rcnt >= L
+        assert np.array_equal(tt.packed, rp[keep]) and np.array_equal(tt.counts, rcnt[keep])
+        if os.path.exists(REF_BIN):
+            q = subprocess.run([REF_BIN, f"-e{L}", "-T2", "-v", "-oref", f"cond{k}"], cwd=tmp_path, capture_output=True, text=True)
+            assert q.returncode == 0, q.stderr
+            assert "  The input table is trimmed and symmetric\n" in q.stderr
+            assert (tmp_path / "ref.smu").read_text() == brute.smu_text(brute.hetmers_plot(cp, cc, k))
+            os.remove(tmp_path / "ref.smu")
