@@ -327,6 +327,15 @@ kf_compact(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill,
   for (unsigned e = threadIdx.x; e < fill; e += F_TPB) dst[e] = src[e];
 }
 
+// holes of the chunk list -> sentinel words the look-ups skip (all ones: for k < 32 the pad bits of a real k-mer
+// are zero, so it cannot be a request; k = 32 uses the compaction path)
+__global__ void __launch_bounds__(F_TPB)
+kf_fill_holes(u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill)
+{ const unsigned fill = chunk_fill[blockIdx.x];
+  u64 *c = req + (size_t) blockIdx.x * F_CH;
+  for (unsigned e = fill + threadIdx.x; e < F_CH; e += F_TPB) c[e] = ~0ull;
+}
+
 // self-check of a sort (debug / tests): order on the leading 32 bits + order-free checksums
 __global__ void __launch_bounds__(F_TPB)
 kf_check_sorted(const u64 *__restrict__ before, const u64 *__restrict__ after, int64_t n, int lobit,
@@ -356,13 +365,15 @@ kf_check_sorted(const u64 *__restrict__ before, const u64 *__restrict__ after, i
 // entry in a run that is discarded anyway); several matching signatures are told apart by their k-mers.
 // This cuts the look-up traffic from 20 GB of k-mer lines to 5 GB of signature lines (+ rare k-mer reads).
 template <int W> __global__ void __launch_bounds__(F_TPB)
-kf_apply_sorted(FastArgs A, const u64 *__restrict__ keys_sorted, int64_t nreq, FastCtl *__restrict__ ctl)
+kf_apply_sorted(FastArgs A, const u64 *__restrict__ keys_sorted, int64_t nreq, int skip_sentinels,
+                FastCtl *__restrict__ ctl)
 { const int64_t stride = (int64_t) gridDim.x * F_TPB;
   const Dir d = A.dir;
   for (int64_t r = (int64_t) blockIdx.x * F_TPB + threadIdx.x; r < nreq; r += stride)
     { Key<W> y;
 #pragma unroll
       for (int w = 0; w < W; w++) y.w[w] = keys_sorted[r * W + w];
+      if (skip_sentinels && y.w[0] == ~0ull) continue;
       if (W > 1 || A.sig == NULL)
         { const int64_t j = find_key<W>(A.keys, A.dir, y);
           if (j < 0) { if (ctl->missing == 0) ctl->missing = 1; continue; }

@@ -913,7 +913,8 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
 typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
                                    rocprim::default_config, 0> smg_sort_config;
 
-static int apply_sorted(smg_engine *e, const u64 *keys_in, int64_t nsort, char *errbuf, size_t errlen)
+// sort nsort keys and look them up in that order; holes != 0: the list contains sentinel words (kf_fill_holes)
+static int apply_sorted(smg_engine *e, const u64 *keys_in, int64_t nsort, int holes, char *errbuf, size_t errlen)
 { int rc;
   if (nsort <= 0) return SMG_OK;
   FastArgs a = make_fast(e);
@@ -943,7 +944,7 @@ static int apply_sorted(smg_engine *e, const u64 *keys_in, int64_t nsort, char *
             return fail(errbuf, errlen, SMG_ENODEV, "request sort self-check failed (rocPRIM radix sort)%s");
         }
     }
-  hipLaunchKernelGGL(kf_apply_sorted<1>, dim3((unsigned) nb), dim3(F_TPB), 0, e->stream, a, src, nsort, &e->ctrl->fast);
+  hipLaunchKernelGGL(kf_apply_sorted<1>, dim3((unsigned) nb), dim3(F_TPB), 0, e->stream, a, src, nsort, holes, &e->ctrl->fast);
   return SMG_OK;
 }
 
@@ -989,7 +990,14 @@ static int fast_apply(smg_engine *e, const u64 *flat, int64_t nflat, int check_c
     { if (!flat)
         { // squeeze the per-workgroup chunks into one dense array, then sort + look up in order
           const int64_t nreq = e->st.nrequests;
-          if (nreq > 0 && e->n_chunks > 0)
+          const int64_t nslots = (int64_t) e->n_chunks * F_CH;
+          if (nreq > 0 && e->n_chunks > 0 && nslots <= nreq + nreq / 8 && nslots >= SORT_MIN && e->kmer < 32)
+            { // nearly every chunk is full (kf_pass1_r splits its batches): sort the chunk array in place of a
+              // compaction pass, holes as sentinels behind the requests
+              hipLaunchKernelGGL(kf_fill_holes, dim3(e->n_chunks), dim3(F_TPB), 0, e->stream, e->req, e->chunk_fill);
+              rc = apply_sorted(e, e->req, nslots, 1, errbuf, errlen);
+            }
+          else if (nreq > 0 && e->n_chunks > 0)
             { if ((rc = grow(&e->dense, &e->dense_cap, nreq * (int64_t) sizeof(u64), errbuf, errlen))) return rc;
               if ((rc = grow(&e->chunk_off, &e->chunk_off_cap, (int64_t) e->n_chunks * 4 + 4, errbuf, errlen))) return rc;
               size_t tmp = 0;
@@ -1000,11 +1008,11 @@ static int fast_apply(smg_engine *e, const u64 *flat, int64_t nflat, int check_c
                                              rocprim::plus<uint32_t>(), e->stream));
               hipLaunchKernelGGL(kf_compact, dim3(e->n_chunks), dim3(F_TPB), 0, e->stream, e->req, e->chunk_fill,
                                  e->chunk_off, 1, e->dense);
-              rc = apply_sorted(e, e->dense, nreq, errbuf, errlen);
+              rc = apply_sorted(e, e->dense, nreq, 0, errbuf, errlen);
             }
           else rc = SMG_OK;
         }
-      else rc = apply_sorted(e, flat, nflat, errbuf, errlen);
+      else rc = apply_sorted(e, flat, nflat, 0, errbuf, errlen);
       if (rc) return rc;
     }
   else if (!flat && e->n_chunks > 0)

@@ -393,24 +393,32 @@ kf_pass1_r(FastArgs A, GeoR G, uint32_t *__restrict__ bstart, u64 *__restrict__ 
       const unsigned qn = s_qn;
       const unsigned qcap = RW == 1 ? R_QCAP : R_OWN;
       if (qn > 0 && (qn + R_OWN > qcap || tile + gridDim.x >= ntiles))
-        { const unsigned old_chunk = s_chunk, old_used = s_used;
-          const bool fresh = old_chunk == F_NOCHUNK || old_used + qn > F_CH;
+        { // a batch that does not fit is SPLIT: its head fills the current chunk to the brim, the rest opens a new
+          // one -- every chunk but a workgroup's last is full, so the host can sort the chunk array as it is
+          // (holes filled with a sentinel) instead of compacting it first
+          const unsigned old_chunk = s_chunk, old_used = s_used;
+          const unsigned room = old_chunk == F_NOCHUNK ? 0u : F_CH - old_used;
+          const unsigned head = qn < room ? qn : room;
           lds_barrier();
           if (t == 0)
-            { if (fresh)
-                { if (old_chunk != F_NOCHUNK && old_chunk < max_chunks) chunk_fill[old_chunk] = old_used;
+            { s_base = (u64) old_chunk * F_CH + old_used;          // only used when head > 0
+              if (qn > head)
+                { if (old_chunk != F_NOCHUNK && old_chunk < max_chunks) chunk_fill[old_chunk] = F_CH;
                   s_chunk = atomicAdd(&ctl->n_chunks, 1u);
-                  s_used = 0;
+                  s_used = qn - head;
                 }
-              s_base = (u64) s_chunk * F_CH + s_used;
-              s_used += qn;
+              else s_used = old_used + qn;
               s_total += qn;
               s_qn = 0;
             }
           lds_barrier();
-          if (s_chunk < max_chunks)
+          if (head && old_chunk < max_chunks)
             { u64 *o = req + s_base * RW;
-              for (unsigned e = t; e < qn * RW; e += R_TPB) o[e] = sq[e];
+              for (unsigned e = t; e < head * RW; e += R_TPB) o[e] = sq[e];
+            }
+          if (qn > head && s_chunk < max_chunks)
+            { u64 *o = req + (u64) s_chunk * F_CH * RW;
+              for (unsigned e = t; e < (qn - head) * RW; e += R_TPB) o[e] = sq[head * RW + e];
             }
         }
       const unsigned nb = s_nbig;
