@@ -41,6 +41,10 @@
 #define CODE_FAR    62
 #define CODE_W2     64
 #define CODE_DEFER  0xFF                  // placeholder until kf_bigfix has redone the entry
+#define CODE_P      0x80                  // set by the look-ups: the entry has a prefix-side pair ("P flag")
+// Exactly one request can name an entry (the one from its reverse complement), so the read-modify-write of the
+// byte needs no atomic; bytes of other entries are untouched by a byte store.
+#define SET_P(A, j) ((A).code[j] = (uint8_t) ((A).code[j] | CODE_P))
 
 #define P2_TPB   1024
 #define P2_SMAX  208                  // LDS plot tile covers sums < P2_SMAX (43.7 KB; with the 32 KB queue: 2 WGs/CU)
@@ -53,7 +57,6 @@ struct FastArgs
   Geo             g;
   Dir             dir;           // bstart written by pass 1, read by apply
   uint8_t        *code;
-  uint8_t        *pflag;         // pflag[j] != 0 : entry j has a prefix-side pair
   uint16_t       *sig;           // k <= 32: the 16 k-mer bits below the directory bucket bits (look-up signatures)
   int             sigsh;         //          sig[i] = (uint16_t) (keys[i] >> sigsh)
 };
@@ -313,7 +316,7 @@ kf_apply(FastArgs A, const u64 *__restrict__ req, const uint32_t *__restrict__ c
       bool bad = j < 0;
       if (!bad && check_count) bad = A.cnt[j] != (unsigned) (meta & 0xFFFF);
       if (bad) { if (ctl->missing == 0) ctl->missing = 1; continue; }
-      if (meta >> 16 & 1) A.pflag[j] = 1;          // plain byte store: no read-modify-write
+      if (meta >> 16 & 1) SET_P(A, j);
     }
 }
 
@@ -377,7 +380,7 @@ kf_apply_sorted(FastArgs A, const u64 *__restrict__ keys_sorted, int64_t nreq, i
       if (W > 1 || A.sig == NULL)
         { const int64_t j = find_key<W>(A.keys, A.dir, y);
           if (j < 0) { if (ctl->missing == 0) ctl->missing = 1; continue; }
-          A.pflag[j] = 1;
+          SET_P(A, j);
           continue;
         }
       const uint32_t hb = (uint32_t) (y.w[0] >> 32) >> d.dsh;
@@ -407,7 +410,7 @@ kf_apply_sorted(FastArgs A, const u64 *__restrict__ keys_sorted, int64_t nreq, i
           j = lower_bound_key<W>(A.keys, j, e2, y);
           if (j >= e2 || !key_eq<W>(load_key<W>(A.keys, j), y)) { if (ctl->missing == 0) ctl->missing = 1; continue; }
         }
-      A.pflag[j] = 1;
+      SET_P(A, j);
     }
 }
 // (Running 4 independent look-ups per thread in lockstep was tried and lost 1.1 ms of 8.1: the kernel streams
@@ -437,7 +440,7 @@ kf_apply_indexed(FastArgs A, const u64 *__restrict__ rec, const uint32_t *__rest
       bool bad = j < 0;
       if (!bad && check_count) bad = A.cnt[j] != (unsigned) (meta & 0xFFFF);
       if (bad) { if (ctl->missing == 0) ctl->missing = 1; continue; }
-      if (meta >> 16 & 1) A.pflag[j] = 1;
+      if (meta >> 16 & 1) SET_P(A, j);
     }
 }
 
@@ -482,7 +485,7 @@ p2_candidate(const FastArgs &A, unsigned *tile, u64 *__restrict__ plot, int64_t 
     }
   else
     j = i + (int) lo6 - 31;
-  const unsigned cj = A.code[j], pi = A.pflag[i], pj = A.pflag[j];
+  const unsigned cj = A.code[j], pi = ci & CODE_P, pj = cj & CODE_P;
   const unsigned ni = A.cnt[i], nj = A.cnt[j];
   const unsigned lj = cj & 63;
   if (lj == CODE_NONE || lj == CODE_MULTI) return;    // partner has several pairs
@@ -515,7 +518,7 @@ kf_pass2(FastArgs A, u64 *__restrict__ plot)
             { const unsigned ci = (wv[q] >> (8 * bb)) & 0xFF;
               const unsigned lo6 = ci & 63;
               const int li = t * P2_VEC + 4 * q + bb;
-              const bool cand = lo6 >= 32 && lo6 != CODE_MULTI && c0 + li < A.n;
+              const bool cand = lo6 >= 32 && lo6 != CODE_MULTI && !(ci & CODE_P) && c0 + li < A.n;
               const u64 m = __ballot(cand);
               if (m)
                 { const int lane = t & 63, lead = __ffsll((long long) m) - 1;
@@ -600,8 +603,8 @@ kf_extract(FastArgs A, const uint16_t *__restrict__ labels, u64 *__restrict__ ou
               if (lo6 == CODE_FAR) { far_partner<W>(A, i, j, w2); ok = j > i; }
               else j = i + (int) lo6 - 31;
               if (ok)
-                { const unsigned lj = A.code[j] & 63;
-                  ok = lj != CODE_NONE && lj != CODE_MULTI && !(A.pflag[i] | A.pflag[j]);
+                { const unsigned cj = A.code[j], lj = cj & 63;
+                  ok = lj != CODE_NONE && lj != CODE_MULTI && !((ci | cj) & CODE_P);
                 }
               if (ok)
                 { const unsigned ni = A.cnt[i], nj = A.cnt[j];

@@ -398,7 +398,6 @@ struct smg_engine
   u64         *own_keys;      // owned copies (decode path)
   uint16_t    *own_cnt;
   uint8_t     *deg;    int64_t deg_cap;      // degree bytes (counted path) / code bytes (fast path)
-  uint8_t     *pflag;  int64_t pflag_cap;
   uint16_t    *sig;    int64_t sig_cap;       // k <= 32: look-up signatures (2 bytes per entry)
   uint32_t    *bstart; int64_t bstart_cap;
   u64         *req;    int64_t req_cap;      // bytes
@@ -486,7 +485,7 @@ extern "C" void smg_engine_destroy(smg_engine *e)
 { if (!e) return;
   hipSetDevice(e->device);
   hipStreamSynchronize(e->stream);
-  hipFree(e->own_keys); hipFree(e->own_cnt); hipFree(e->deg); hipFree(e->pflag); hipFree(e->sig); hipFree(e->bstart);
+  hipFree(e->own_keys); hipFree(e->own_cnt); hipFree(e->deg); hipFree(e->sig); hipFree(e->bstart);
   hipFree(e->req); hipFree(e->req2); hipFree(e->sort_tmp); hipFree(e->dense); hipFree(e->chunk_off); hipFree(e->skey[0]); hipFree(e->skey[1]); hipFree(e->sidx[0]); hipFree(e->sidx[1]); hipFree(e->biglist); hipFree(e->chunk_fill); hipFree(e->route_cnt); hipFree(e->route_off);
   hipFree(e->partials); hipFree(e->ctrl); hipFree(e->d_split);
   hipHostFree(e->h_ctrl); hipHostFree(e->h_partials);
@@ -754,7 +753,7 @@ static int run_general(smg_engine *e, int64_t *d_plot, char *errbuf, size_t errl
 static FastArgs make_fast(smg_engine *e)
 { FastArgs a;
   a.keys = e->keys; a.cnt = e->cnt; a.n = e->n; a.g = e->geo; a.dir = e->dir;
-  a.code = e->deg; a.pflag = e->pflag;
+  a.code = e->deg;
   a.sig = e->W == 1 ? e->sig : NULL;
   a.sigsh = 16 + e->dir.dsh;               // the 16 bits right below the directory's bucket bits
   return a;
@@ -769,8 +768,6 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
   e->fast = true;
   if ((rc = grow(&e->deg, &e->deg_cap, ((e->n + 15) & ~15ll) + 32, errbuf, errlen))) return rc;
   const int64_t pbytes = ((e->n + 15) & ~15ll) + 32;
-  if ((rc = grow(&e->pflag, &e->pflag_cap, pbytes, errbuf, errlen))) return rc;
-  if (e->W > 2) HIPCHK(hipMemsetAsync(e->pflag, 0, (size_t) pbytes, e->stream));   // kf_pass1_r zeroes the flags itself
   if (e->W == 1 && (rc = grow(&e->sig, &e->sig_cap, 2 * pbytes, errbuf, errlen))) return rc;
   if ((rc = dir_geometry(e, errbuf, errlen))) return rc;
   if (e->n > 0)

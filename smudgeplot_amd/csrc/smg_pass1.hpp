@@ -329,14 +329,12 @@ r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict_
       //@mark P3_STORE
       { if (INNER || (vmask & 0xF) == 0xF)
             { *reinterpret_cast<unsigned *>(A.code + i0) = codes;
-              *reinterpret_cast<unsigned *>(A.pflag + i0) = 0u;          // saves a 1-byte-per-entry memset per run
               if (W == 1) *reinterpret_cast<u64 *>(A.sig + i0) = sigs;
             }
           else
             for (int r = 0; r < 4; r++)
               if (vmask >> r & 1)
                 { A.code[i0 + r] = (uint8_t) (codes >> (8 * r));
-                  A.pflag[i0 + r] = 0;
                   if (W == 1) A.sig[i0 + r] = (uint16_t) (sigs >> (16 * r));
                 }
         }
