@@ -152,9 +152,14 @@ def main():
            "ms_rclookup": (nreq if args.symcheck == "hash" else n_local) * 10.0}
     # the dominant KERNEL: pass 1 and pass 2 are one launch each; the look-up phase is a chain of
     # short launches (compact, 4 radix passes, in-order look-ups), each well below pass 1
-    single = {"ms_pass1": "kf_pass1_r<%d,%s>" % (1 if args.symcheck == "hash" else 2, "true" if args.k & 1 else "false")
-              if args.k <= 32 else "kf_pass1<W>",
-              "ms_pass2": "kf_pass2<1>" if args.k <= 32 else "kf_pass2<W>"}
+    tf = lambda b: "true" if b else "false"                                   # noqa: E731
+    if args.k <= 32:
+        p1 = "kf_pass1_r<1, %d, %s, %s>" % (1 if args.symcheck == "hash" else 2, tf(args.k & 1), tf(17 <= args.k))
+    elif args.k <= 64:
+        p1 = "kf_pass1_r<2, 3, %s, false>" % tf(args.k & 1)
+    else:
+        p1 = "kf_pass1<3>"
+    single = {"ms_pass1": p1, "ms_pass2": "kf_pass2<%d>" % ((args.k + 31) // 32)}
     dom = max(single, key=ms.get)
     achieved = alg[dom] / (ms[dom] * 1e-3) / 1e9 if ms[dom] > 0 else 0.0
     traffic, traffic_src = None, None
