@@ -292,6 +292,36 @@ kf_pass1(FastArgs A, uint32_t *__restrict__ bstart, u64 *__restrict__ req,
     }
 }
 
+// index of the entry whose k-mer is y, or -1: directory bucket, bisection on the bucket's signatures, k-mer
+// comparison only among entries that share the signature.  A single matching signature is taken for the
+// complement (see kf_apply_sorted); without signatures (W = 3) the k-mers are bisected directly.
+template <int W> SMG_DEV int64_t sig_find(const FastArgs &A, const Key<W> &y)
+{ if (A.sig == NULL) return find_key<W>(A.keys, A.dir, y);
+  const Dir d = A.dir;
+  const uint32_t hb = (uint32_t) (y.w[0] >> 32) >> d.dsh;
+  if (hb < d.b0 || hb - d.b0 >= d.nb) return -1;
+  uint32_t b = hb - d.b0;
+  int64_t lo = d.bstart[b];
+  if (lo == (int64_t) DIR_UNSET) return -1;
+  int64_t hi = d.bstart[++b];
+  while (hi == (int64_t) DIR_UNSET) hi = d.bstart[++b];
+  const unsigned sy = (unsigned) (y.w[0] >> A.sigsh) & 0xFFFFu;
+  const int64_t bhi = hi;
+  while (lo < hi)                                    // first entry of the bucket with signature >= sy
+    { const int64_t m = (lo + hi) >> 1;
+      if (A.sig[m] < sy) lo = m + 1; else hi = m;
+    }
+  int64_t j = lo;
+  if (j >= bhi || A.sig[j] != sy) return -1;
+  if (j + 1 < bhi && A.sig[j + 1] == sy)             // several entries share the signature: compare k-mers
+    { int64_t e2 = j + 1;
+      while (e2 < bhi && A.sig[e2] == sy) e2++;
+      j = lower_bound_key<W>(A.keys, j, e2, y);
+      if (j >= e2 || !key_eq<W>(load_key<W>(A.keys, j), y)) return -1;
+    }
+  return j;
+}
+
 // ---- apply: set the P bit of every requested complement ---------------------------------------
 // chunk_fill != NULL : one workgroup per chunk of the local request list
 // chunk_fill == NULL : flat list of nflat records (received from other ranks), grid-stride
@@ -312,7 +342,7 @@ kf_apply(FastArgs A, const u64 *__restrict__ req, const uint32_t *__restrict__ c
 #pragma unroll
       for (int w = 0; w < W; w++) y.w[w] = q[w];
       const u64 meta = q[W];
-      const int64_t j = find_key<W>(A.keys, A.dir, y);
+      const int64_t j = sig_find<W>(A, y);
       bool bad = j < 0;
       if (!bad && check_count) bad = A.cnt[j] != (unsigned) (meta & 0xFFFF);
       if (bad) { if (ctl->missing == 0) ctl->missing = 1; continue; }
@@ -371,45 +401,13 @@ template <int W> __global__ void __launch_bounds__(F_TPB)
 kf_apply_sorted(FastArgs A, const u64 *__restrict__ keys_sorted, int64_t nreq, int skip_sentinels,
                 FastCtl *__restrict__ ctl)
 { const int64_t stride = (int64_t) gridDim.x * F_TPB;
-  const Dir d = A.dir;
   for (int64_t r = (int64_t) blockIdx.x * F_TPB + threadIdx.x; r < nreq; r += stride)
     { Key<W> y;
 #pragma unroll
       for (int w = 0; w < W; w++) y.w[w] = keys_sorted[r * W + w];
       if (skip_sentinels && y.w[0] == ~0ull) continue;
-      if (W > 1 || A.sig == NULL)
-        { const int64_t j = find_key<W>(A.keys, A.dir, y);
-          if (j < 0) { if (ctl->missing == 0) ctl->missing = 1; continue; }
-          SET_P(A, j);
-          continue;
-        }
-      const uint32_t hb = (uint32_t) (y.w[0] >> 32) >> d.dsh;
-      bool bad = hb < d.b0 || hb - d.b0 >= d.nb;
-      int64_t lo = 0, hi = 0;
-      if (!bad)
-        { uint32_t b = hb - d.b0;
-          lo = d.bstart[b];
-          bad = lo == (int64_t) DIR_UNSET;
-          if (!bad)
-            { hi = d.bstart[++b];
-              while (hi == (int64_t) DIR_UNSET) hi = d.bstart[++b];
-            }
-        }
-      if (bad) { if (ctl->missing == 0) ctl->missing = 1; continue; }
-      const unsigned sy = (unsigned) (y.w[0] >> A.sigsh) & 0xFFFFu;
-      const int64_t bhi = hi;
-      while (lo < hi)                                    // first entry of the bucket with signature >= sy
-        { const int64_t m = (lo + hi) >> 1;
-          if (A.sig[m] < sy) lo = m + 1; else hi = m;
-        }
-      int64_t j = lo;
-      if (j >= bhi || A.sig[j] != sy) { if (ctl->missing == 0) ctl->missing = 1; continue; }
-      if (j + 1 < bhi && A.sig[j + 1] == sy)             // several entries share the signature: compare k-mers
-        { int64_t e2 = j + 1;
-          while (e2 < bhi && A.sig[e2] == sy) e2++;
-          j = lower_bound_key<W>(A.keys, j, e2, y);
-          if (j >= e2 || !key_eq<W>(load_key<W>(A.keys, j), y)) { if (ctl->missing == 0) ctl->missing = 1; continue; }
-        }
+      const int64_t j = sig_find<W>(A, y);
+      if (j < 0) { if (ctl->missing == 0) ctl->missing = 1; continue; }
       SET_P(A, j);
     }
 }
@@ -436,7 +434,7 @@ kf_apply_indexed(FastArgs A, const u64 *__restrict__ rec, const uint32_t *__rest
 #pragma unroll
       for (int w = 0; w < W; w++) y.w[w] = q[w];
       const u64 meta = q[W];
-      const int64_t j = find_key<W>(A.keys, A.dir, y);
+      const int64_t j = sig_find<W>(A, y);
       bool bad = j < 0;
       if (!bad && check_count) bad = A.cnt[j] != (unsigned) (meta & 0xFFFF);
       if (bad) { if (ctl->missing == 0) ctl->missing = 1; continue; }

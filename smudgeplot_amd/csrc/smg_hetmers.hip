@@ -446,7 +446,7 @@ static int fail(char *errbuf, size_t errlen, int code, const char *fmt, const ch
 #define DISPATCH_W3(e, CALL)                                                                  \
   switch ((e)->W) { case 1: CALL(1); break; case 2: CALL(2); break; default: CALL(3); break; }
 
-extern "C" const char *smg_version(void) { return "smudgeplot_amd 0.2 (hetmers engine, gfx950)"; }
+extern "C" const char *smg_version(void) { return "smudgeplot_amd 0.3 (hetmers engine, gfx950)"; }
 
 extern "C" int smg_device_count(void)
 { int n = 0;
@@ -754,7 +754,7 @@ static FastArgs make_fast(smg_engine *e)
 { FastArgs a;
   a.keys = e->keys; a.cnt = e->cnt; a.n = e->n; a.g = e->geo; a.dir = e->dir;
   a.code = e->deg;
-  a.sig = e->W == 1 ? e->sig : NULL;
+  a.sig = e->W <= 2 ? e->sig : NULL;
   a.sigsh = 16 + e->dir.dsh;               // the 16 bits right below the directory's bucket bits
   return a;
 }
@@ -768,7 +768,7 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
   e->fast = true;
   if ((rc = grow(&e->deg, &e->deg_cap, ((e->n + 15) & ~15ll) + 32, errbuf, errlen))) return rc;
   const int64_t pbytes = ((e->n + 15) & ~15ll) + 32;
-  if (e->W == 1 && (rc = grow(&e->sig, &e->sig_cap, 2 * pbytes, errbuf, errlen))) return rc;
+  if (e->W <= 2 && (rc = grow(&e->sig, &e->sig_cap, 2 * pbytes, errbuf, errlen))) return rc;
   if ((rc = dir_geometry(e, errbuf, errlen))) return rc;
   if (e->n > 0)
     HIPCHK(hipMemsetAsync(e->bstart, 0xFF, sizeof(uint32_t) * ((size_t) e->dir.nb + 2), e->stream));

@@ -276,7 +276,7 @@ r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict_
           const bool hi = count == 1 ? w2 : count >= 2;            // owns a pair at p > k-1-p
           if (big) code = CODE_DEFER;
           codes |= code << (8 * r);
-          if (W == 1)        // look-up signature: parked in the (already consumed) count slot, stored 4 at a time below
+          if (W <= 2)        // look-up signature: parked in the (already consumed) count slot, stored 4 at a time below
             { const unsigned xh = (unsigned) (x.w[0] >> 32), xl = (unsigned) x.w[0];
               S.lcn[slot0 + r] = (uint16_t) (A.sigsh >= 32 ? xh >> (A.sigsh - 32) : __builtin_amdgcn_alignbit(xh, xl, A.sigsh));
             }
@@ -331,13 +331,13 @@ r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict_
       //@mark P3_STORE
       { if (INNER || (vmask & 0xF) == 0xF)
             { *reinterpret_cast<unsigned *>(A.code + i0) = codes;
-              if (W == 1) *reinterpret_cast<u64 *>(A.sig + i0) = *reinterpret_cast<const u64 *>(&S.lcn[slot0]);
+              if (W <= 2) *reinterpret_cast<u64 *>(A.sig + i0) = *reinterpret_cast<const u64 *>(&S.lcn[slot0]);
             }
           else
             for (int r = 0; r < 4; r++)
               if (vmask >> r & 1)
                 { A.code[i0 + r] = (uint8_t) (codes >> (8 * r));
-                  if (W == 1) A.sig[i0 + r] = S.lcn[slot0 + r];
+                  if (W <= 2) A.sig[i0 + r] = S.lcn[slot0 + r];
                 }
         }
     }
