@@ -45,7 +45,8 @@
 #ifndef R_D
 #define R_D     3                        // distances scanned in registers; farther partners: tail loop
 #endif
-#define R_QCAP  1536                     // LDS request queue (records); flushed when the next tile might not fit
+#define R_QCAP  1280                     // LDS request queue (records); flushed when the next tile might not fit
+                                         // (sized so that SIX workgroups fit the 160 KB of LDS of a CU)
 
 // per-entry scan words: the first p0 bases ("pre") and the last k-p0 bases ("suf") of the k-mer, each in ONE
 // machine word of this type: 32 bits for k <= 32 (p0 <= 16), 64 bits for 33 <= k <= 64 (p0 <= 32)
@@ -115,7 +116,7 @@ r_slots(const WT (&pre)[8], const WT (&suf)[8], const unsigned (&cn)[8], const G
 }
 
 struct RShared                            // the workgroup's LDS arrays (pointers: the tile body is a function)
-{ unsigned *cred; uint16_t *tailq; u64 *ent; uint16_t *lcn; u64 *sq; uint32_t *sbig;
+{ unsigned *cred; uint16_t *tailq; u64 *ent; uint16_t *lcn; u64 *sq;
   unsigned *s_tn, *s_qn, *s_nbig;
 };
 
@@ -125,8 +126,9 @@ struct RShared                            // the workgroup's LDS arrays (pointer
 template <int W, int RW, bool ODD, bool KF, bool INNER> SMG_DEV void
 r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict__ bstart,
        FastCtl *__restrict__ ctl, int emit_all, int want_fp, int64_t g0, int t,
-       u64 &fa, u64 &fb, unsigned &fneg)
+       u64 &fa, u64 &fb, unsigned &fneg, unsigned &bigmask)
 { typedef typename RWord<W>::type WT;
+  bigmask = 0;                             // owned entries deferred to kf_bigfix (listed by the caller)
   const int slot0 = 4 * t;
   const int64_t i0 = g0 + slot0;
   const int64_t n = A.n;
@@ -280,7 +282,7 @@ r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict_
             { const unsigned xh = (unsigned) (x.w[0] >> 32), xl = (unsigned) x.w[0];
               S.lcn[slot0 + r] = (uint16_t) (A.sigsh >= 32 ? xh >> (A.sigsh - 32) : __builtin_amdgcn_alignbit(xh, xl, A.sigsh));
             }
-          if (ok && big) S.sbig[atomicAdd(S.s_nbig, 1u)] = (uint32_t) i;
+          if (ok && big) { bigmask |= 1u << r; atomicAdd(S.s_nbig, 1u); }
           //@mark P3_DIR
           // order check + bucket directory: the first entry of every bucket stores its index
           if (INNER)
@@ -344,11 +346,11 @@ r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict_
 }
 
 #ifndef R_WAVES_PER_EU
-#define R_WAVES_PER_EU 5
+#define R_WAVES_PER_EU 6
 #endif
 
 template <int W, int RW, bool ODD, bool KF> __global__ void __launch_bounds__(R_TPB)
-__attribute__((amdgpu_waves_per_eu(W == 2 ? 3 : (RW == 1 ? R_WAVES_PER_EU : 4), W == 2 ? 3 : (RW == 1 ? R_WAVES_PER_EU : 4))))
+__attribute__((amdgpu_waves_per_eu(W == 2 ? 3 : (RW == 1 ? R_WAVES_PER_EU : 5), W == 2 ? 3 : (RW == 1 ? R_WAVES_PER_EU : 5))))
 kf_pass1_r(FastArgs A, GeoR G, uint32_t *__restrict__ bstart, u64 *__restrict__ req,
            uint32_t *__restrict__ chunk_fill, unsigned max_chunks, uint32_t *__restrict__ biglist,
            unsigned big_cap, int emit_all, int want_fp, u64 *__restrict__ partials,
@@ -358,9 +360,8 @@ kf_pass1_r(FastArgs A, GeoR G, uint32_t *__restrict__ bstart, u64 *__restrict__ 
   __shared__ u64      ent[(R_SCAN + 4) * W];   // the scanned k-mers (+ the first one of the next tile)
   __shared__ uint16_t lcn[R_SCAN + 4];
   __shared__ u64      sq[(RW == 1 ? R_QCAP : R_OWN) * RW];
-  __shared__ uint32_t sbig[R_OWN];
   __shared__ u64      sfp[R_TPB / 64][2];
-  __shared__ unsigned s_tn, s_qn, s_nbig, s_chunk, s_used, s_bigbase;
+  __shared__ unsigned s_tn, s_qn, s_nbig, s_chunk, s_used, s_bigbase, s_bigcur;
   __shared__ u64      s_base, s_total;
 
   const int t = threadIdx.x;
@@ -369,7 +370,7 @@ kf_pass1_r(FastArgs A, GeoR G, uint32_t *__restrict__ bstart, u64 *__restrict__ 
   u64 fa = 0, fb = 0;                      // fingerprint: sum of (h ^ sign); the -1's are added at the end
   unsigned fneg = 0;
   RShared S;
-  S.cred = cred; S.tailq = tailq; S.ent = ent; S.lcn = lcn; S.sq = sq; S.sbig = sbig;
+  S.cred = cred; S.tailq = tailq; S.ent = ent; S.lcn = lcn; S.sq = sq;
   S.s_tn = &s_tn; S.s_qn = &s_qn; S.s_nbig = &s_nbig;
   for (int s = t; s < R_CRED; s += R_TPB) cred[s] = 0;
   if (t == 0) { s_chunk = F_NOCHUNK; s_used = 0; s_total = 0; s_tn = 0; s_qn = 0; s_nbig = 0; }
@@ -377,10 +378,11 @@ kf_pass1_r(FastArgs A, GeoR G, uint32_t *__restrict__ bstart, u64 *__restrict__ 
 
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
     { const int64_t g0 = tile * R_OWN - R_HALO;
+      unsigned bigmask;
       if (g0 >= 0 && g0 + R_SCAN + 4 <= n)
-        r_tile<W, RW, ODD, KF, true>(A, G, S, bstart, ctl, emit_all, want_fp, g0, t, fa, fb, fneg);
+        r_tile<W, RW, ODD, KF, true>(A, G, S, bstart, ctl, emit_all, want_fp, g0, t, fa, fb, fneg, bigmask);
       else
-        r_tile<W, RW, ODD, KF, false>(A, G, S, bstart, ctl, emit_all, want_fp, g0, t, fa, fb, fneg);
+        r_tile<W, RW, ODD, KF, false>(A, G, S, bstart, ctl, emit_all, want_fp, g0, t, fa, fb, fneg, bigmask);
       lds_barrier();
       //@mark P4_FLUSH
       // zero the credit words for the next tile
@@ -422,12 +424,16 @@ kf_pass1_r(FastArgs A, GeoR G, uint32_t *__restrict__ bstart, u64 *__restrict__ 
             }
         }
       const unsigned nb = s_nbig;
-      if (nb > 0)                                   // rare
-        { lds_barrier();
-          if (t == 0) { s_bigbase = atomicAdd(&ctl->nbig, nb); s_nbig = 0; }
+      if (nb > 0)                                   // rare: list the deferred entries (the k-mer copy is free now)
+        { uint32_t *list = reinterpret_cast<uint32_t *>(ent);
+          lds_barrier();
+          if (t == 0) { s_bigbase = atomicAdd(&ctl->nbig, nb); s_nbig = 0; s_bigcur = 0; }
+          lds_barrier();
+          for (unsigned m = bigmask; m; m &= m - 1)
+            list[atomicAdd(&s_bigcur, 1u)] = (uint32_t) (g0 + slot0 + __ffs(m) - 1);
           lds_barrier();
           for (unsigned e = t; e < nb; e += R_TPB)
-            if (s_bigbase + e < big_cap) biglist[s_bigbase + e] = sbig[e];
+            if (s_bigbase + e < big_cap) biglist[s_bigbase + e] = list[e];
         }
       if (t == 0) s_tn = 0;
       lds_barrier();
