@@ -86,7 +86,7 @@ typedef struct smg_opts
 typedef struct smg_stats
 { int64_t nels;          /* entries scanned                                                  */
   int64_t npairs;        /* one-away pairs that entered the histogram (weighted)             */
-  int64_t nrequests;     /* complement look-ups issued                                       */
+  int64_t nrequests;     /* complement look-ups issued (after the request filter)            */
   int32_t path;          /* 1 = symmetric half-scan, 2 = general all-positions path          */
   int32_t key_words;     /* 64-bit words per k-mer                                           */
   double  ms_h2d;        /* host -> device copies                                            */
@@ -95,6 +95,8 @@ typedef struct smg_stats
   double  ms_rclookup;   /* complement look-ups / degree exchange                            */
   double  ms_pass2;      /* unique-pair histogram                                            */
   double  ms_total;      /* decode .. histogram on device (no H2D)                           */
+  int64_t nemitted;      /* complement requests pass 1 emitted (before the request filter)   */
+  double  ms_filter;     /* request filter (also counted in ms_rclookup)                     */
 } smg_stats;
 
 /* ---- one-shot entry: host FastK table -> plot ------------------------------------------
@@ -195,6 +197,19 @@ int     smg_engine_route(smg_engine *e, const uint64_t *splitters, int nranks, u
 int     smg_engine_apply(smg_engine *e, const uint64_t *d_recv, int64_t nrecv, int64_t *missing,
                          char *errbuf, size_t errlen);
 int     smg_engine_apply_own(smg_engine *e, int64_t *missing, char *errbuf, size_t errlen);
+/* Request filter (hash proof, k <= 32).  A request only matters when its target is a candidate of
+   pass 2 (exactly one suffix-side pair).  Pass 1 records in a bit map which block ids -- the leading
+   id_bits = min(30, 2*(k/2)) bits of a k-mer -- hold a candidate; smg_engine_filter drops every request
+   whose target id has a clear bit, before the requests are routed, sorted or looked up.  Single shard:
+   apply_own filters with the engine's own map.  Sharded: every rank copies out the words its k-mer
+   range covers (blockmap_copy), the ranks exchange them, OR them into one map of `nwords` uint32 on
+   the device and pass that to filter, then route().  id_bits = 0: no map (exact proof or k > 32).
+   No counterpart in the reference (it has no complement look-ups at all: PloidyPlot.c scans every
+   position of every k-mer). */
+int     smg_engine_blockmap(smg_engine *e, int *id_bits, int64_t *nwords);
+int     smg_engine_blockmap_copy(smg_engine *e, int64_t word_lo, int64_t nw, uint32_t *d_dst,
+                                 char *errbuf, size_t errlen);
+int     smg_engine_filter(smg_engine *e, const uint32_t *d_map, int64_t *kept, char *errbuf, size_t errlen);
 int     smg_engine_symhash(smg_engine *e, uint64_t out[4], char *errbuf, size_t errlen);
 int     smg_engine_pass2(smg_engine *e, int64_t *d_plot, char *errbuf, size_t errlen);
 int     smg_engine_stats(smg_engine *e, smg_stats *stats);

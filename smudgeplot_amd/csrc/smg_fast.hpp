@@ -57,8 +57,10 @@ struct FastArgs
   Geo             g;
   Dir             dir;           // bstart written by pass 1, read by apply
   uint8_t        *code;
-  uint16_t       *sig;           // k <= 32: the 16 k-mer bits below the directory bucket bits (look-up signatures)
+  uint16_t       *sig;           // k <= 64: the 16 k-mer bits below the directory bucket bits (look-up signatures)
   int             sigsh;         //          sig[i] = (uint16_t) (keys[i] >> sigsh)
+  uint32_t       *bmap;          // candidate block map (or NULL): bit (hi32(kmer) >> bmsh) is set when a window block
+  int             bmsh;          //   (coarsened to <= 30 leading bits) holds an entry with exactly one suffix-side pair
 };
 
 struct FastCtl                    // device control words of the fast path
@@ -68,7 +70,8 @@ struct FastCtl                    // device control words of the fast path
   unsigned pad;
   u64      nreq;                 // requests written
   unsigned nbig;                 // entries deferred to kf_bigfix (window block longer than the halo)
-  unsigned pad2;
+  unsigned nf_chunks;            // kf_filter: chunks of the filtered request list
+  u64      nf_req;               // kf_filter: requests that survived
 };
 
 // ---- helpers -----------------------------------------------------------------------------------
@@ -367,6 +370,85 @@ kf_fill_holes(u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill)
 { const unsigned fill = chunk_fill[blockIdx.x];
   u64 *c = req + (size_t) blockIdx.x * F_CH;
   for (unsigned e = fill + threadIdx.x; e < F_CH; e += F_TPB) c[e] = ~0ull;
+}
+
+// ---- request filter -------------------------------------------------------------------------------------------
+// A request only matters when the entry it names is a CANDIDATE (exactly one suffix-side pair): its P flag is read
+// by pass 2 for candidates only.  Pass 1 records in a bitmap which window blocks (coarsened to <= 30 leading k-mer
+// bits: 128 MB at most, cache resident) hold a candidate; a request whose target block holds none is dropped before
+// it is sorted, looked up -- or sent over xGMI in a sharded run, where the per-rank bitmaps are exchanged first
+// (16 MB per rank at 8 GPUs against ~8 bytes x 17 % of the entries in requests).  Conservative by construction:
+// a set bit only means "maybe".  Key-only records (RW = 1).
+__global__ void __launch_bounds__(F_TPB)
+kf_filter(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill, unsigned n_chunks,
+          const uint32_t *__restrict__ bmap, int idshift, u64 *__restrict__ out, uint32_t *__restrict__ out_fill,
+          unsigned max_out, FastCtl *__restrict__ ctl)
+{ __shared__ u64      stage[F_CH];
+  __shared__ unsigned s_n, s_chunk, s_used;
+  __shared__ u64      s_base, s_total;
+  const int t = threadIdx.x;
+  if (t == 0) { s_n = 0; s_chunk = F_NOCHUNK; s_used = 0; s_total = 0; }
+  __syncthreads();
+  for (unsigned c = blockIdx.x; c < n_chunks; c += gridDim.x)
+    { const unsigned fill = chunk_fill[c];
+      const u64 *src = req + (size_t) c * F_CH;
+      for (unsigned r0 = 0; r0 < fill; r0 += 4 * F_TPB)          // four independent map reads in flight per thread
+        { u64 y[4]; uint32_t wd[4]; bool keep[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            { const unsigned r = r0 + j * F_TPB + t;
+              y[j] = r < fill ? src[r] : 0;
+            }
+#pragma unroll
+          for (int j = 0; j < 4; j++) wd[j] = bmap[(uint32_t) (y[j] >> idshift) >> 5];
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            { const unsigned r = r0 + j * F_TPB + t;
+              keep[j] = r < fill && ((wd[j] >> ((uint32_t) (y[j] >> idshift) & 31)) & 1u);
+            }
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            { const u64 m = __ballot(keep[j]);
+              if (m)
+                { const int lane = t & 63, lead = __ffsll((long long) m) - 1;
+                  unsigned qb = 0;
+                  if (lane == lead) qb = atomicAdd(&s_n, (unsigned) __popcll(m));
+                  qb = __shfl(qb, lead, 64);
+                  if (keep[j]) stage[qb + __popcll(m & ((1ull << lane) - 1))] = y[j];
+                }
+            }
+        }
+      __syncthreads();
+      // append the survivors of this chunk to the workgroup's output chunk, split so that chunks fill to the brim
+      const unsigned qn = s_n;
+      __syncthreads();
+      if (qn)
+        { const unsigned old_chunk = s_chunk, old_used = s_used;
+          const unsigned room = old_chunk == F_NOCHUNK ? 0u : F_CH - old_used;
+          const unsigned head = qn < room ? qn : room;
+          if (t == 0)
+            { s_base = (u64) old_chunk * F_CH + old_used;
+              if (qn > head)
+                { if (old_chunk != F_NOCHUNK && old_chunk < max_out) out_fill[old_chunk] = F_CH;
+                  s_chunk = atomicAdd(&ctl->nf_chunks, 1u);
+                  s_used = qn - head;
+                }
+              else s_used = old_used + qn;
+              s_total += qn;
+              s_n = 0;
+            }
+          __syncthreads();
+          if (head && old_chunk < max_out)
+            for (unsigned e = t; e < head; e += F_TPB) out[s_base + e] = stage[e];
+          if (qn > head && s_chunk < max_out)
+            for (unsigned e = t; e < qn - head; e += F_TPB) out[(u64) s_chunk * F_CH + e] = stage[head + e];
+          __syncthreads();
+        }
+    }
+  if (t == 0)
+    { if (s_chunk != F_NOCHUNK && s_chunk < max_out) out_fill[s_chunk] = s_used;
+      if (s_total) atomicAdd(&ctl->nf_req, s_total);
+    }
 }
 
 // self-check of a sort (debug / tests): order on the leading 32 bits + order-free checksums
@@ -740,6 +822,10 @@ kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, unsigned nbig, u64 *
           int64_t partner;
           big_block_scan<W>(A.keys, A.cnt, A.n, A.g, i, s_all, s_hi, partner, w2);
           A.code[i] = (uint8_t) make_code(s_all, partner - i, w2);
+          if (W == 1 && A.bmap && s_all == 1)             // a candidate: mark its block for the request filter
+            { const uint32_t id = (uint32_t) (A.keys[i] >> 32) >> A.bmsh;
+              atomicOr(&A.bmap[id >> 5], 1u << (id & 31));
+            }
           if (s_hi > 0)
             { const Key<W> kx = load_key<W>(A.keys, i);
               const Key<W> rc = revcomp<W>(kx, A.g.k);

@@ -411,6 +411,11 @@ struct smg_engine
   int          rw;                           // 64-bit words per request record
   uint32_t    *chunk_fill; int64_t chunk_cap; // bytes
   unsigned     max_chunks;
+  uint32_t    *bmap;   int64_t bmap_cap;     // candidate block map (request filter)
+  int          bm_bits;                      //   leading k-mer bits per block id (0 = not built by the last pass 1)
+  bool         filtered;                     //   the request list of the last pass 1 has been filtered
+  u64         *reqf;   int64_t reqf_cap;     // filtered request chunks (swapped with req)
+  uint32_t    *chunk_fillf; int64_t chunk_capf;
   uint32_t    *route_cnt;  int64_t route_cnt_cap;
   u64         *route_off;  int64_t route_off_cap;
   u64         *partials;   // [P1_MAXGRID][4]
@@ -486,7 +491,7 @@ extern "C" void smg_engine_destroy(smg_engine *e)
   hipSetDevice(e->device);
   hipStreamSynchronize(e->stream);
   hipFree(e->own_keys); hipFree(e->own_cnt); hipFree(e->deg); hipFree(e->sig); hipFree(e->bstart);
-  hipFree(e->req); hipFree(e->req2); hipFree(e->sort_tmp); hipFree(e->dense); hipFree(e->chunk_off); hipFree(e->skey[0]); hipFree(e->skey[1]); hipFree(e->sidx[0]); hipFree(e->sidx[1]); hipFree(e->biglist); hipFree(e->chunk_fill); hipFree(e->route_cnt); hipFree(e->route_off);
+  hipFree(e->req); hipFree(e->req2); hipFree(e->sort_tmp); hipFree(e->dense); hipFree(e->chunk_off); hipFree(e->skey[0]); hipFree(e->skey[1]); hipFree(e->sidx[0]); hipFree(e->sidx[1]); hipFree(e->biglist); hipFree(e->chunk_fill); hipFree(e->bmap); hipFree(e->reqf); hipFree(e->chunk_fillf); hipFree(e->route_cnt); hipFree(e->route_off);
   hipFree(e->partials); hipFree(e->ctrl); hipFree(e->d_split);
   hipHostFree(e->h_ctrl); hipHostFree(e->h_partials);
   for (int i = 0; i < 10; i++) hipEventDestroy(e->ev[i]);
@@ -756,8 +761,12 @@ static FastArgs make_fast(smg_engine *e)
   a.code = e->deg;
   a.sig = e->W <= 2 ? e->sig : NULL;
   a.sigsh = 16 + e->dir.dsh;               // the 16 bits right below the directory's bucket bits
+  a.bmap = e->bm_bits ? e->bmap : NULL;
+  a.bmsh = 32 - e->bm_bits;
   return a;
 }
+
+static int bm_id_bits(int kmer);
 
 static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, char *errbuf, size_t errlen)
 { int rc;
@@ -779,6 +788,15 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
       return SMG_OK;
     }
   const bool narrow = e->W <= 2;                       // k <= 64: kf_pass1_r (blocked register scan)
+  e->bm_bits = 0;
+  e->filtered = false;
+  if (e->W == 1 && e->rw == 1 && !emit_all && !getenv("SMG_NO_FILTER"))
+    { const int nbits = bm_id_bits(e->kmer);
+      const int64_t bytes = 4 * (((1ll << nbits) + 31) >> 5) + 4 * R_BMW + 64;
+      if ((rc = grow(&e->bmap, &e->bmap_cap, bytes, errbuf, errlen))) return rc;
+      HIPCHK(hipMemsetAsync(e->bmap, 0, (size_t) bytes, e->stream));
+      e->bm_bits = nbits;
+    }
   const int64_t ntiles = narrow ? (e->n + R_OWN - 1) / R_OWN : (e->n + F_TILE - 1) / F_TILE;
   GeoR gr;
   { const int p0 = e->kmer / 2, sbits = 2 * (e->kmer - p0);
@@ -898,6 +916,8 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
   float ms = 0; hipEventElapsedTime(&ms, e->ev[2], e->ev[3]);
   e->st.ms_pass1 = ms;
   e->st.nrequests = (int64_t) e->h_ctrl->fast.nreq;
+  e->st.nemitted = e->st.nrequests;
+  e->st.ms_filter = 0;
   e->prepared = true;
   return SMG_OK;
 }
@@ -979,9 +999,54 @@ static int apply_indexed(smg_engine *e, const u64 *rec, int64_t n, int check_cou
   return SMG_OK;
 }
 
+// block ids of the request filter = the leading bm_id_bits(k) bits of a k-mer (a function of k alone, so that the
+// maps of all the shards of a table line up): window blocks, coarsened to 2^30 ids (128 MB of bits) at most
+static int bm_id_bits(int kmer)
+{ int nbits = 2 * (kmer / 2);
+  if (nbits > 30) nbits = 30;
+  return nbits;
+}
+
+// drop the requests whose target window block holds no candidate (kf_filter); map = NULL: this engine's own map
+static int fast_filter(smg_engine *e, const uint32_t *map, char *errbuf, size_t errlen)
+{ int rc;
+  if (!(e->W == 1 && e->rw == 1) || e->n_chunks == 0) return SMG_OK;
+  if (!map) map = e->bm_bits ? e->bmap : NULL;
+  if (!map) return SMG_OK;
+  const int nbits = bm_id_bits(e->kmer);
+  unsigned grid = e->n_chunks < 2048 ? e->n_chunks : 2048;
+  const unsigned maxout = e->n_chunks + grid + 16;
+  // (the two chunk lists swap roles after every filter: keep them the same size, or pass 1 would reallocate)
+  { int64_t want = (int64_t) maxout * F_CH * (int64_t) sizeof(u64), wantf = (int64_t) maxout * 4 + 4;
+    if (want < e->req_cap) want = e->req_cap;
+    if (wantf < e->chunk_cap) wantf = e->chunk_cap;
+    if ((rc = grow(&e->reqf, &e->reqf_cap, want, errbuf, errlen))) return rc;
+    if ((rc = grow(&e->chunk_fillf, &e->chunk_capf, wantf, errbuf, errlen))) return rc;
+  }
+  hipEventRecord(e->ev[4], e->stream);
+  hipLaunchKernelGGL(kf_filter, dim3(grid), dim3(F_TPB), 0, e->stream, e->req, e->chunk_fill, e->n_chunks, map, 64 - nbits,
+                     e->reqf, e->chunk_fillf, maxout, &e->ctrl->fast);
+  hipEventRecord(e->ev[5], e->stream);
+  HIPCHK(hipGetLastError());
+  if ((rc = read_ctrl(e, errbuf, errlen))) return rc;
+  if (e->h_ctrl->fast.nf_chunks > maxout) return fail(errbuf, errlen, SMG_ENODEV, "request filter overflowed its chunk list%s");
+  { u64 *t = e->req; e->req = e->reqf; e->reqf = t; }
+  { int64_t t = e->req_cap; e->req_cap = e->reqf_cap; e->reqf_cap = t; }
+  { uint32_t *t = e->chunk_fill; e->chunk_fill = e->chunk_fillf; e->chunk_fillf = t; }
+  { int64_t t = e->chunk_cap; e->chunk_cap = e->chunk_capf; e->chunk_capf = t; }
+  e->n_chunks = e->h_ctrl->fast.nf_chunks;
+  e->st.nrequests = (int64_t) e->h_ctrl->fast.nf_req;
+  e->filtered = true;
+  float ms = 0; hipEventElapsedTime(&ms, e->ev[4], e->ev[5]);
+  e->st.ms_rclookup += ms;
+  e->st.ms_filter = ms;
+  return SMG_OK;
+}
+
 static int fast_apply(smg_engine *e, const u64 *flat, int64_t nflat, int check_count, int64_t *missing,
                       char *errbuf, size_t errlen)
 { int rc;
+  if (!flat && e->bm_bits && !e->filtered && (rc = fast_filter(e, NULL, errbuf, errlen))) return rc;
   hipEventRecord(e->ev[4], e->stream);
   if (e->W == 1 && e->rw == 1)
     { if (!flat)
@@ -1093,6 +1158,36 @@ extern "C" int smg_engine_apply_own(smg_engine *e, int64_t *missing, char *errbu
   if (!e->prepared) return fail(errbuf, errlen, SMG_EINVAL, "apply before pass1%s");
   HIPCHK(hipSetDevice(e->device));
   return fast_apply(e, NULL, 0, 1, missing, errbuf, errlen);
+}
+
+extern "C" int smg_engine_blockmap(smg_engine *e, int *id_bits, int64_t *nwords)
+{ if (!e || !id_bits || !nwords) return SMG_EINVAL;
+  *id_bits = e->prepared ? e->bm_bits : 0;
+  *nwords = *id_bits ? ((1ll << *id_bits) + 31) >> 5 : 0;
+  return SMG_OK;
+}
+
+extern "C" int smg_engine_blockmap_copy(smg_engine *e, int64_t word_lo, int64_t nw, uint32_t *d_dst,
+                                        char *errbuf, size_t errlen)
+{ NEED_FAST(e)
+  if (!e->prepared || !e->bm_bits) return fail(errbuf, errlen, SMG_EINVAL, "no block map: pass 1 (hash proof, k <= 32) has not run%s");
+  const int64_t nwords = ((1ll << e->bm_bits) + 31) >> 5;
+  if (word_lo < 0 || nw < 0 || word_lo + nw > nwords || (nw > 0 && !d_dst))
+    return fail(errbuf, errlen, SMG_EINVAL, "block map range out of bounds%s");
+  HIPCHK(hipSetDevice(e->device));
+  if (nw > 0) HIPCHK(hipMemcpyAsync(d_dst, e->bmap + word_lo, (size_t) nw * 4, hipMemcpyDeviceToDevice, e->stream));
+  return SMG_OK;
+}
+
+extern "C" int smg_engine_filter(smg_engine *e, const uint32_t *d_map, int64_t *kept, char *errbuf, size_t errlen)
+{ NEED_FAST(e)
+  if (!e->prepared) return fail(errbuf, errlen, SMG_EINVAL, "filter before pass1%s");
+  if (e->rw != 1 || e->W != 1) return fail(errbuf, errlen, SMG_EINVAL, "the request filter needs key-only requests (hash proof, k <= 32)%s");
+  if (!d_map && !e->bm_bits) return fail(errbuf, errlen, SMG_EINVAL, "no block map to filter with%s");
+  HIPCHK(hipSetDevice(e->device));
+  int rc = e->filtered ? SMG_OK : fast_filter(e, d_map, errbuf, errlen);
+  if (kept) *kept = e->st.nrequests;
+  return rc;
 }
 
 extern "C" int smg_engine_symhash(smg_engine *e, uint64_t out[4], char *errbuf, size_t errlen)

@@ -50,7 +50,8 @@ class Stats(C.Structure):
     _fields_ = [("nels", C.c_int64), ("npairs", C.c_int64), ("nrequests", C.c_int64),
                 ("path", C.c_int32), ("key_words", C.c_int32),
                 ("ms_h2d", C.c_double), ("ms_decode", C.c_double), ("ms_pass1", C.c_double),
-                ("ms_rclookup", C.c_double), ("ms_pass2", C.c_double), ("ms_total", C.c_double)]
+                ("ms_rclookup", C.c_double), ("ms_pass2", C.c_double), ("ms_total", C.c_double),
+                ("nemitted", C.c_int64), ("ms_filter", C.c_double)]
 
     def asdict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -60,7 +61,8 @@ EXPORTS = [
     "smg_hetmers_run", "smg_device_count", "smg_engine_create", "smg_engine_destroy",
     "smg_engine_decode", "smg_engine_bind", "smg_engine_condition", "smg_engine_run", "smg_engine_pass1",
     "smg_engine_nreq", "smg_engine_record_words", "smg_engine_route", "smg_engine_apply",
-    "smg_engine_apply_own", "smg_engine_symhash", "smg_engine_pass2", "smg_engine_stats",
+    "smg_engine_apply_own", "smg_engine_blockmap", "smg_engine_blockmap_copy", "smg_engine_filter",
+    "smg_engine_symhash", "smg_engine_pass2", "smg_engine_stats",
     "smg_engine_extract", "smg_hetmers_extract", "smg_free", "smg_condition_table", "smg_version",
 ]
 
@@ -121,6 +123,9 @@ def load_library():
     lib.smg_engine_route.argtypes = [vp, vp, i32, vp, i64, C.POINTER(i64), *err]
     lib.smg_engine_apply.argtypes = [vp, vp, i64, C.POINTER(i64), *err]
     lib.smg_engine_apply_own.argtypes = [vp, C.POINTER(i64), *err]
+    lib.smg_engine_blockmap.argtypes = [vp, C.POINTER(i32), C.POINTER(i64)]
+    lib.smg_engine_blockmap_copy.argtypes = [vp, i64, i64, vp, *err]
+    lib.smg_engine_filter.argtypes = [vp, vp, C.POINTER(i64), *err]
     lib.smg_engine_symhash.argtypes = [vp, C.POINTER(C.c_uint64), *err]
     lib.smg_engine_pass2.argtypes = [vp, vp, *err]
     lib.smg_engine_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -303,6 +308,20 @@ class Engine:
         missing = C.c_int64(0)
         _check(self.lib.smg_engine_apply_own(self.h, C.byref(missing), self._buf, 512), self._buf)
         return int(missing.value)
+
+    def blockmap(self):
+        """(id_bits, nwords) of the candidate block map of the last pass 1; id_bits 0 = none"""
+        bits, nw = C.c_int32(0), C.c_int64(0)
+        self.lib.smg_engine_blockmap(self.h, C.byref(bits), C.byref(nw))
+        return int(bits.value), int(nw.value)
+
+    def blockmap_copy(self, word_lo: int, nw: int, dst_ptr: int):
+        _check(self.lib.smg_engine_blockmap_copy(self.h, word_lo, nw, dst_ptr, self._buf, 512), self._buf)
+
+    def filter(self, map_ptr=None) -> int:
+        kept = C.c_int64(0)
+        _check(self.lib.smg_engine_filter(self.h, map_ptr, C.byref(kept), self._buf, 512), self._buf)
+        return int(kept.value)
 
     def symhash(self):
         out = (C.c_uint64 * 4)()

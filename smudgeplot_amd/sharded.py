@@ -6,7 +6,10 @@ prefix-subtree task decomposition of `small_window` (src/lib/PloidyPlot.c:1040-1
 
 Data path per run (see DESIGN.md "Multi-GPU"):
   1. pass 1 on every shard (window scan of the suffix-side positions: always shard local);
-  2. ONE exchange: every entry that owns a suffix-side pair sends (rc(kmer), count, S_hi) to the
+  2. request filter (hash proof, k <= 32): one all_gather of the candidate block maps (each rank contributes the
+     words its k-mer range covers: 128 MB / world at k = 31) -- a request whose target block holds no candidate
+     of pass 2 is dropped before it is sent (about 4 in 5 on a diploid table);
+     ONE exchange: every entry that owns a suffix-side pair sends (rc(kmer), count, S_hi) to the
      rank that owns the reverse complement  -> all_to_all_single over xGMI;
      the symmetry proof (fingerprints 4 x u64 + missing count) rides on the final all_reduce;
   3. pass 2 on every shard;
@@ -64,6 +67,15 @@ class TorchEngine:
     def apply_own(self):
         return self.e.apply_own()
 
+    def blockmap(self):
+        return self.e.blockmap()
+
+    def blockmap_copy(self, word_lo, nw, dst):
+        self.e.blockmap_copy(word_lo, nw, dst.data_ptr())
+
+    def filter(self, full_map=None):
+        return self.e.filter(None if full_map is None else full_map.data_ptr())
+
     def symhash(self):
         return self.e.symhash()
 
@@ -101,6 +113,16 @@ def fix_cut(keys_u64: np.ndarray, words: int, k: int, cut: int) -> int:
     while cut < n and prefix(cut) == prefix(cut - 1):
         cut += 1
     return cut
+
+
+def blockmap_ranges(splitters, words: int, world: int, bits: int):
+    """Word ranges (first word, length) of the candidate block map that the k-mer ranges of the ranks cover.
+    Block id = leading `bits` bits of a k-mer; rank r holds ids [id(first_r), id(first_{r+1})], so neighbours
+    share their boundary word (the receiver ORs the ranges together)."""
+    ids = [0] + [int(splitters[(r - 1) * words]) >> (64 - bits) for r in range(1, world)] + [(1 << bits) - 1]
+    wlo = [ids[r] >> 5 for r in range(world)]
+    wlen = [max((ids[r + 1] >> 5) - wlo[r] + 1, 1) for r in range(world)]
+    return wlo, wlen
 
 
 def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: str = "hash",
@@ -153,6 +175,19 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
     nreq = eng.nreq()
 
     if world > 1:
+        bits, nwords = eng.blockmap()
+        if bits:
+            wlo, wlen = blockmap_ranges(splitters, words, world, bits)
+            width = max(wlen)
+            mine = torch.zeros(width, dtype=torch.int32, device=dev)
+            eng.blockmap_copy(wlo[rank], wlen[rank], mine)
+            parts = torch.empty(world * width, dtype=torch.int32, device=dev)
+            dist.all_gather_into_tensor(parts, mine, group=group)
+            full = torch.zeros(nwords, dtype=torch.int32, device=dev)
+            for r in range(world):                  # ranges of neighbours share their boundary word: OR, not copy
+                full[wlo[r]: wlo[r] + wlen[r]] |= parts[r * width: r * width + wlen[r]]
+            nreq = eng.filter(full)
+            del parts, full, mine
         send = torch.empty(max(nreq, 1) * rw, dtype=torch.int64, device=dev)
         send_counts = eng.route(splitters, world, send)
         sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
@@ -186,5 +221,5 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
         raise NotSymmetric("table is not closed under reverse complement with equal counts; "
                            "run the single-GPU engine (general path) or condition the table")
     st = eng.stats()
-    st.update(rank=rank, world=world, shard_nels=n, sent=nreq, received=nrecv, engine=eng)
+    st.update(rank=rank, world=world, shard_nels=n, sent=nreq if world > 1 else 0, received=nrecv, engine=eng)
     return plot, st

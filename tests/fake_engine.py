@@ -74,7 +74,36 @@ class NumpyEngine:
             f = np.sum(h.view(np.int64) * sign, dtype=np.int64) if n else np.int64(0)
         self.fp = [int(np.uint64(np.int64(f))), 0, 0, 0]
 
+        self.symcheck = symcheck
+
     def nreq(self):
+        return len(self.req) // 2
+
+    # request filter: same protocol as the engine (block id = leading id_bits bits of the k-mer)
+    def blockmap(self):
+        if self.symcheck != "hash":
+            return 0, 0
+        bits = min(30, 2 * (self.k // 2))
+        return bits, ((1 << bits) + 31) >> 5
+
+    def _own_map(self):
+        bits, nwords = self.blockmap()
+        m = np.zeros(nwords, np.uint32)
+        ids = (self.keys[self.s_all == 1] >> np.uint64(64 - bits)).astype(np.int64)
+        np.bitwise_or.at(m, ids >> 5, (np.uint32(1) << (ids & 31).astype(np.uint32)))
+        return m
+
+    def blockmap_copy(self, word_lo, nw, dst):
+        dst[:nw] = torch.from_numpy(self._own_map()[word_lo: word_lo + nw].view(np.int32).copy())
+
+    def filter(self, full_map=None):
+        bits, _ = self.blockmap()
+        m = self._own_map() if full_map is None else full_map.cpu().numpy().view(np.uint32)
+        rec = self.req.reshape(-1, 2)
+        ids = (rec[:, 0] >> np.uint64(64 - bits)).astype(np.int64)
+        keep = ((m[ids >> 5] >> (ids & 31).astype(np.uint32)) & np.uint32(1)).astype(bool)
+        self.dropped = int((~keep).sum())
+        self.req = rec[keep].reshape(-1)
         return len(self.req) // 2
 
     def route(self, splitters, nranks, send):

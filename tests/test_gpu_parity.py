@@ -170,12 +170,15 @@ def test_large_table_sorted_lookup_path_vs_reference_binary(tmp_path, monkeypatc
     e = engine.Engine(0)
     e.bind(k, len(cnt), tk.data_ptr(), tc.data_ptr())
     texts = {}
-    for mode in ("hash", "exact"):
-        st = e.run(plot.data_ptr(), mode)
+    for mode in ("hash", "exact", "hash-unfiltered"):
+        if mode == "hash-unfiltered":            # (on a table this sparse the request filter leaves too few
+            monkeypatch.setenv("SMG_NO_FILTER", "1")     #  requests for the sorted path: run it without as well)
+        st = e.run(plot.data_ptr(), mode.split("-")[0])
         torch.cuda.synchronize()
-        assert st["path"] == 1 and st["nrequests"] > 100000
+        assert st["path"] == 1 and st["nemitted"] > 100000
+        assert mode == "hash" or st["nrequests"] > 100000
         texts[mode] = engine.smu_text(plot.cpu().numpy().reshape(1001, 501))
-    assert texts["hash"] == texts["exact"]
+    assert texts["hash"] == texts["exact"] == texts["hash-unfiltered"]
     synth.write_u64_table(str(tmp_path / "t"), keys, cnt, k, ibyte=2, nparts=3)
     r = subprocess.run([REF_BIN, "-e10", f"-T{min(16, os.cpu_count() or 1)}", "-oref", "t.ktab"], cwd=tmp_path,
                        capture_output=True, text=True)
@@ -237,6 +240,22 @@ def test_engine_object_with_torch_tensors_and_manual_two_shard_exchange():
         total += pl
     torch.cuda.synchronize()
     assert np.array_equal(total.cpu().numpy().reshape(1001, 501), want)
+
+
+@pytest.mark.parametrize("k,m,seed", [(31, 30000, 3), (21, 30000, 4), (12, 20000, 5), (32, 8000, 6)])
+def test_request_filter_changes_nothing_but_the_request_count(k, m, seed, monkeypatch):
+    """hash proof, k <= 32: requests whose target block holds no candidate are dropped before the look-ups"""
+    packed, cnt = synth.adversarial_table(k, m, 4, seed, low_complexity=40, dense=1)
+    want = brute.hetmers_plot(packed, cnt, k) if m * k <= 400000 else None
+    tab = table_from(packed, cnt, k)
+    plot_f, st_f = engine.hetmers_run(tab, symcheck="hash")
+    monkeypatch.setenv("SMG_NO_FILTER", "1")
+    plot_u, st_u = engine.hetmers_run(tab, symcheck="hash")
+    assert np.array_equal(plot_f, plot_u)
+    if want is not None:
+        assert np.array_equal(plot_f, want)
+    assert st_u["nrequests"] == st_u["nemitted"] == st_f["nemitted"] > 0
+    assert st_f["nrequests"] <= st_f["nemitted"]
 
 
 # ---- table conditioning on the device (row A0: what the reference delegates to Logex / Symmex) -------------
@@ -318,9 +337,23 @@ def _manual_sharded(k, tk, tc, cuts, dev, symcheck="hash"):
         en = sharded.TorchEngine(dev)
         en.bind(k, tk[cuts[r]:cuts[r + 1]].clone(), tc[cuts[r]:cuts[r + 1]].clone())    # aligned copies
         en.pass1(symcheck)
+        engs.append(en)
+    bits, nwords = engs[0].blockmap()
+    emitted = sum(en.nreq() for en in engs)
+    if bits:                                   # request filter: the exchange of the candidate block maps, by hand
+        wlo, wlen = sharded.blockmap_ranges(split, 1, world, bits)
+        full = torch.zeros(nwords, dtype=torch.int32, device=dev)
+        for r, en in enumerate(engs):
+            part = torch.zeros(wlen[r], dtype=torch.int32, device=dev)
+            en.blockmap_copy(wlo[r], wlen[r], part)
+            full[wlo[r]: wlo[r] + wlen[r]] |= part
+        for en in engs:
+            before = en.nreq()
+            assert en.filter(full) == en.nreq() <= before
+    for en in engs:
         buf = torch.empty(max(en.nreq(), 1) * en.record_words(), dtype=torch.int64, device=dev)
         counts.append(en.route(split, world, buf))
-        sends.append(buf); engs.append(en)
+        sends.append(buf)
     rw = engs[0].record_words()
     fps = np.zeros(4, dtype=np.uint64)
     for dst, en in enumerate(engs):
@@ -339,7 +372,8 @@ def _manual_sharded(k, tk, tc, cuts, dev, symcheck="hash"):
         en.pass2(pl)
         total += pl
     torch.cuda.synchronize()
-    return total, sum(sum(c) for c in counts)
+    assert sum(sum(c) for c in counts) <= emitted
+    return total, emitted
 
 
 def test_full_size_config3_properties():
