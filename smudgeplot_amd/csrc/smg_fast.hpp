@@ -379,8 +379,10 @@ kf_fill_holes(u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill)
 // it is sorted, looked up -- or sent over xGMI in a sharded run, where the per-rank bitmaps are exchanged first
 // (16 MB per rank at 8 GPUs against ~8 bytes x 17 % of the entries in requests).  Conservative by construction:
 // a set bit only means "maybe".  Key-only records (RW = 1).
+// chunk_fill = NULL: `req` is a flat array of nflat words (read in F_CH slices) that may hold sentinel words ~0 --
+// the host sorts long lists on their leading 8 bits first, so that the map words a workgroup probes stay in L2.
 __global__ void __launch_bounds__(F_TPB)
-kf_filter(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill, unsigned n_chunks,
+kf_filter(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill, unsigned n_chunks, int64_t nflat,
           const uint32_t *__restrict__ bmap, int idshift, u64 *__restrict__ out, uint32_t *__restrict__ out_fill,
           unsigned max_out, FastCtl *__restrict__ ctl)
 { __shared__ u64      stage[F_CH];
@@ -390,7 +392,12 @@ kf_filter(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill, 
   if (t == 0) { s_n = 0; s_chunk = F_NOCHUNK; s_used = 0; s_total = 0; }
   __syncthreads();
   for (unsigned c = blockIdx.x; c < n_chunks; c += gridDim.x)
-    { const unsigned fill = chunk_fill[c];
+    { unsigned fill;
+      if (chunk_fill) fill = chunk_fill[c];
+      else
+        { const int64_t left = nflat - (int64_t) c * F_CH;
+          fill = left < F_CH ? (unsigned) left : (unsigned) F_CH;
+        }
       const u64 *src = req + (size_t) c * F_CH;
       for (unsigned r0 = 0; r0 < fill; r0 += 4 * F_TPB)          // four independent map reads in flight per thread
         { u64 y[4]; uint32_t wd[4]; bool keep[4];
@@ -404,7 +411,7 @@ kf_filter(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill, 
 #pragma unroll
           for (int j = 0; j < 4; j++)
             { const unsigned r = r0 + j * F_TPB + t;
-              keep[j] = r < fill && ((wd[j] >> ((uint32_t) (y[j] >> idshift) & 31)) & 1u);
+              keep[j] = r < fill && ((wd[j] >> ((uint32_t) (y[j] >> idshift) & 31)) & 1u) && (chunk_fill || y[j] != ~0ull);
             }
 #pragma unroll
           for (int j = 0; j < 4; j++)

@@ -1024,8 +1024,25 @@ static int fast_filter(smg_engine *e, const uint32_t *map, char *errbuf, size_t 
     if ((rc = grow(&e->chunk_fillf, &e->chunk_capf, wantf, errbuf, errlen))) return rc;
   }
   hipEventRecord(e->ev[4], e->stream);
-  hipLaunchKernelGGL(kf_filter, dim3(grid), dim3(F_TPB), 0, e->stream, e->req, e->chunk_fill, e->n_chunks, map, 64 - nbits,
-                     e->reqf, e->chunk_fillf, maxout, &e->ctrl->fast);
+  const int64_t nslots = (int64_t) e->n_chunks * F_CH;
+  int64_t sort_min = 1 << 22;               // below this the probes are too few to matter
+  { const char *v = getenv("SMG_FILTER_SORT_MIN"); if (v) sort_min = atoll(v); if (sort_min < SORT_MIN) sort_min = SORT_MIN; }
+  if (nslots >= sort_min && e->kmer < 32 && !getenv("SMG_FILTER_UNSORTED"))
+    { // long list: the probes of the 128 MB map are random 64-byte fetches (7 ms for the 4.3e8 requests of the
+      // 1 Gbp table).  One radix pass on the leading 8 k-mer bits first (holes as sentinels, as for the look-ups)
+      // keeps the map words that the resident workgroups probe inside the L2 caches.
+      hipLaunchKernelGGL(kf_fill_holes, dim3(e->n_chunks), dim3(F_TPB), 0, e->stream, e->req, e->chunk_fill);
+      if ((rc = grow(&e->req2, &e->req2_cap, nslots * (int64_t) sizeof(u64), errbuf, errlen))) return rc;
+      size_t tmp = 0;
+      HIPCHK(rocprim::radix_sort_keys<smg_sort_config>(nullptr, tmp, e->req, e->req2, (size_t) nslots, 56u, 64u, e->stream));
+      if ((rc = grow((char **) &e->sort_tmp, &e->sort_tmp_cap, (int64_t) tmp + 16, errbuf, errlen))) return rc;
+      HIPCHK(rocprim::radix_sort_keys<smg_sort_config>(e->sort_tmp, tmp, e->req, e->req2, (size_t) nslots, 56u, 64u, e->stream));
+      hipLaunchKernelGGL(kf_filter, dim3(grid), dim3(F_TPB), 0, e->stream, e->req2, (const uint32_t *) NULL, e->n_chunks, nslots,
+                         map, 64 - nbits, e->reqf, e->chunk_fillf, maxout, &e->ctrl->fast);
+    }
+  else
+    hipLaunchKernelGGL(kf_filter, dim3(grid), dim3(F_TPB), 0, e->stream, e->req, e->chunk_fill, e->n_chunks, (int64_t) 0,
+                       map, 64 - nbits, e->reqf, e->chunk_fillf, maxout, &e->ctrl->fast);
   hipEventRecord(e->ev[5], e->stream);
   HIPCHK(hipGetLastError());
   if ((rc = read_ctrl(e, errbuf, errlen))) return rc;

@@ -64,6 +64,8 @@ struct MultiCtx
   int64_t  nshard[SMG_MAXGPU];
   int64_t  counts[SMG_MAXGPU][SMG_MAXGPU];  // counts[src][dst], records
   uint64_t *send[SMG_MAXGPU];
+  const uint32_t *bmap[SMG_MAXGPU];         // candidate block maps of the shards (request filter), bm_bits[r] = 0: none
+  int      bm_bits[SMG_MAXGPU];
   int64_t  missing[SMG_MAXGPU];
   u64      fp[SMG_MAXGPU][4];
   int64_t *h_plot[SMG_MAXGPU];              // virtual mode: per-shard histograms on the host
@@ -101,6 +103,47 @@ static int decode_at(smg_engine *e, int kmer, int ibyte, int64_t nels, int64_t i
 
 #define MFAIL(code, msg) do { c->rc[r] = fail(c->err[r], sizeof(c->err[r]), code, msg "%s"); c->failed = 1; } while (0)
 #define MOK (!c->failed)
+
+__global__ void km_or_words(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, int64_t n)
+{ for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x)
+    dst[i] |= src[i];
+}
+
+// request filter across shards: OR the word ranges that the k-mer ranges of the shards cover (neighbours share their
+// boundary word) into one map on this shard's device, then drop the requests whose target block holds no candidate
+static int multi_filter(MultiCtx *c, int r, smg_engine *e, const u64 *splitters, char *eb, size_t el)
+{ const int n = c->n, bits = c->bm_bits[r];
+  for (int s = 0; s < n; s++) if (c->bm_bits[s] != bits) return SMG_OK;       // (cannot happen: a function of k and the proof)
+  if (!bits) return SMG_OK;
+  const int64_t nwords = ((1ll << bits) + 31) >> 5;
+  int64_t wlo[SMG_MAXGPU], wlen[SMG_MAXGPU], width = 1;
+  for (int s = 0; s < n; s++)
+    { const u64 a = s == 0 ? 0 : splitters[(size_t) (s - 1) * c->W] >> (64 - bits);
+      const u64 b = s == n - 1 ? (1ull << bits) - 1 : splitters[(size_t) s * c->W] >> (64 - bits);
+      wlo[s] = (int64_t) (a >> 5);
+      wlen[s] = (int64_t) (b >> 5) - wlo[s] + 1;
+      if (wlen[s] < 1) wlen[s] = 1;
+      if (wlen[s] > width) width = wlen[s];
+    }
+  uint32_t *full = NULL, *tmp = NULL;
+  int rc = SMG_OK;
+  if (hipMalloc(&full, (size_t) nwords * 4) != hipSuccess || hipMalloc(&tmp, (size_t) width * 4) != hipSuccess)
+    rc = fail(eb, el, SMG_ENOMEM, "out of device memory for the block map exchange%s");
+  if (rc == SMG_OK && hipMemsetAsync(full, 0, (size_t) nwords * 4, e->stream) != hipSuccess) rc = fail(eb, el, SMG_ENODEV, "memset failed%s");
+  for (int s = 0; s < n && rc == SMG_OK; s++)
+    { hipError_t he = c->virt || c->devs[s] == c->devs[r]
+                        ? hipMemcpyAsync(tmp, c->bmap[s] + wlo[s], (size_t) wlen[s] * 4, hipMemcpyDeviceToDevice, e->stream)
+                        : hipMemcpyPeerAsync(tmp, c->devs[r], c->bmap[s] + wlo[s], c->devs[s], (size_t) wlen[s] * 4, e->stream);
+      if (he != hipSuccess) { rc = fail(eb, el, SMG_ENODEV, "block map copy failed: %s", hipGetErrorString(he)); break; }
+      unsigned nb = (unsigned) ((wlen[s] + 255) / 256);
+      if (nb > 4096) nb = 4096;
+      hipLaunchKernelGGL(km_or_words, dim3(nb), dim3(256), 0, e->stream, full + wlo[s], tmp, wlen[s]);
+    }
+  if (rc == SMG_OK) rc = smg_engine_filter(e, full, NULL, eb, el);
+  hipStreamSynchronize(e->stream);
+  hipFree(full); hipFree(tmp);
+  return rc;
+}
 
 static void *multi_worker(void *argp)
 { MultiArg *arg = (MultiArg *) argp;
@@ -154,6 +197,10 @@ static void *multi_worker(void *argp)
     { for (int s = 1; s < n; s++) memcpy(splitters + (size_t) (s - 1) * W, c->first[s], sizeof(u64) * W);
       if ((c->rc[r] = smg_engine_pass1(e, c->symcheck, eb, el))) c->failed = 1;
     }
+  c->bmap[r] = NULL; c->bm_bits[r] = 0;
+  if (MOK && e->bm_bits) { c->bmap[r] = e->bmap; c->bm_bits[r] = e->bm_bits; hipStreamSynchronize(e->stream); }
+  pthread_barrier_wait(&c->bar);                                                         // A3: block maps complete
+  if (MOK && (c->rc[r] = multi_filter(c, r, e, splitters, eb, el))) c->failed = 1;
   if (MOK)
     { nreq = smg_engine_nreq(e);
       c->rw = smg_engine_record_words(e);
@@ -333,7 +380,7 @@ static int host_run_multi(const smg_table_view *tv, const smg_opts *opts, int ng
     { smg_stats st; memset(&st, 0, sizeof(st));
       st.path = 1; st.key_words = c->W;
       for (int r = 0; r < ngpus; r++)
-        { st.nels += c->st[r].nels; st.nrequests += c->st[r].nrequests;
+        { st.nels += c->st[r].nels; st.nrequests += c->st[r].nrequests; st.nemitted += c->st[r].nemitted;
 #define MX(f) if (c->st[r].f > st.f) st.f = c->st[r].f
           MX(ms_decode); MX(ms_pass1); MX(ms_rclookup); MX(ms_pass2);
 #undef MX

@@ -249,6 +249,9 @@ def test_request_filter_changes_nothing_but_the_request_count(k, m, seed, monkey
     want = brute.hetmers_plot(packed, cnt, k) if m * k <= 400000 else None
     tab = table_from(packed, cnt, k)
     plot_f, st_f = engine.hetmers_run(tab, symcheck="hash")
+    monkeypatch.setenv("SMG_FILTER_SORT_MIN", "1")         # long lists are bucketed on their leading 8 bits first
+    plot_s, st_s = engine.hetmers_run(tab, symcheck="hash")
+    assert np.array_equal(plot_f, plot_s) and st_s["nrequests"] == st_f["nrequests"]
     monkeypatch.setenv("SMG_NO_FILTER", "1")
     plot_u, st_u = engine.hetmers_run(tab, symcheck="hash")
     assert np.array_equal(plot_f, plot_u)
