@@ -22,6 +22,8 @@ world_size>1 orchestration is exercised under gloo without a GPU.
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -137,6 +139,9 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    # SMG_FORCE_EXCHANGE=1 (tests): run the collectives of the exchange even in a one-rank group, so that the
+    # real backend (RCCL) sees every call of the multi-rank protocol on a single-GPU box
+    exchange = world > 1 or (dist.is_initialized() and os.environ.get("SMG_FORCE_EXCHANGE") == "1")
     dev = keys.device
     words = (k + 31) // 32
     n = counts.numel()
@@ -151,7 +156,7 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
     cached = getattr(eng, "_splitter_cache", None)
     if cached is not None and cached[0] == tag:
         splitters = cached[1]
-    elif world > 1:
+    elif exchange:
         first = torch.full((words,), -1, dtype=torch.int64, device=dev)       # all ones = +inf
         if n > 0:
             first.copy_(keys[:words])
@@ -165,7 +170,7 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
         for r in range(world - 2, -1, -1):
             if sizes[r] == 0:
                 firsts[r] = firsts[r + 1]
-        splitters = np.concatenate(firsts[1:])
+        splitters = np.concatenate(firsts[1:]) if world > 1 else np.zeros(0, np.uint64)
         eng._splitter_cache = (tag, splitters)
     else:
         splitters = np.zeros(0, np.uint64)
@@ -174,7 +179,7 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
     rw = eng.record_words()
     nreq = eng.nreq()
 
-    if world > 1:
+    if exchange:
         bits, nwords = eng.blockmap()
         if bits:
             wlo, wlen = blockmap_ranges(splitters, words, world, bits)
@@ -211,7 +216,7 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
     eng.pass2(plot)
     proof = np.array([missing] + eng.symhash(), dtype=np.uint64).view(np.int64)
     buf[PLOT_CELLS:] = torch.from_numpy(proof.copy()).to(dev)
-    if world > 1:
+    if exchange:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     pv = buf[PLOT_CELLS:].cpu().numpy().view(np.uint64)
     symmetric = pv[0] == 0
@@ -221,5 +226,5 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
         raise NotSymmetric("table is not closed under reverse complement with equal counts; "
                            "run the single-GPU engine (general path) or condition the table")
     st = eng.stats()
-    st.update(rank=rank, world=world, shard_nels=n, sent=nreq if world > 1 else 0, received=nrecv, engine=eng)
+    st.update(rank=rank, world=world, shard_nels=n, sent=nreq if exchange else 0, received=nrecv, engine=eng)
     return plot, st

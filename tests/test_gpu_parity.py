@@ -261,6 +261,38 @@ def test_request_filter_changes_nothing_but_the_request_count(k, m, seed, monkey
     assert st_f["nrequests"] <= st_f["nemitted"]
 
 
+@pytest.mark.parametrize("k,symcheck", [(31, "hash"), (12, "hash"), (31, "exact"), (40, "hash")])
+def test_sharded_driver_on_the_real_backend_one_rank_group(k, symcheck, monkeypatch):
+    """`sharded.hetmers_sharded` as bench.py runs it for N > 1 -- splitter all_gather, block-map all_gather, request
+    filter, route, all_to_all_single of counts and requests, apply, all_reduce of histogram + proof -- on RCCL with the
+    real engine; one rank is all this box has, SMG_FORCE_EXCHANGE makes it run every collective of the protocol"""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from smudgeplot_amd import sharded
+    packed, cnt = synth.adversarial_table(k, 6000, 4, 21, low_complexity=30, dense=1)
+    want = brute.hetmers_plot(packed, cnt, k) if k <= 31 else engine.hetmers_run(table_from(packed, cnt, k))[0]
+    words = (k + 31) // 32
+    buf = np.zeros((len(cnt), 8 * words), dtype=np.uint8)              # left-aligned big-endian words
+    buf[:, :packed.shape[1]] = packed
+    keys = buf.view(">u8").astype(np.uint64)
+    dev = torch.device("cuda:0")
+    tk = torch.from_numpy(np.ascontiguousarray(keys).view(np.int64).reshape(-1)).to(dev)
+    tc = torch.from_numpy(cnt.view(np.int16)).to(dev)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    monkeypatch.setenv("SMG_FORCE_EXCHANGE", "1")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        for _ in range(2):                               # second call: cached splitters, reused engine
+            plot, st = sharded.hetmers_sharded(k, tk, tc, symcheck=symcheck, eng=st["engine"] if _ else None)
+            assert np.array_equal(plot.cpu().numpy().reshape(1001, 501), want)
+            assert st["sent"] == st["received"] and st["world"] == 1
+    finally:
+        dist.destroy_process_group()
+
+
 # ---- table conditioning on the device (row A0: what the reference delegates to Logex / Symmex) -------------
 
 def _raw_table(k, seed, L):
