@@ -143,7 +143,9 @@ def main():
     # ---- roofline of the dominant kernel, from HIP events recorded by the engine on its stream
     ms = {key: float(np.mean([s[key] for s in eng_stats])) for key in ("ms_pass1", "ms_rclookup", "ms_pass2")}
     n_local = cnt.numel()
-    nreq = float(np.mean([s["nrequests"] for s in eng_stats]))
+    nreq = float(np.mean([s.get("nemitted", s["nrequests"]) for s in eng_stats]))   # requests pass 1 emitted
+    nkept = float(np.mean([s["nrequests"] for s in eng_stats]))                     # ... and the filter kept
+    ms_filter = float(np.mean([s.get("ms_filter", 0.0) for s in eng_stats]))
     # Algorithmic bytes per launch: the two scan kernels move B_alg/2 = 11 B per
     # entry each (10 B record + 1 B degree/code); the look-up phase moves one 8-byte k-mer + 2-byte
     # count per request (per entry in exact mode, where every complement is looked up).
@@ -187,6 +189,7 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg[dom], "kernel_ms": ms,
+                         "requests": {"emitted": nreq, "kept_by_filter": nkept, "ms_filter": ms_filter},
                          "lookup_phase_GBps": alg["ms_rclookup"] / (ms["ms_rclookup"] * 1e-3) / 1e9
                          if ms["ms_rclookup"] > 0 else 0.0,
                          "whole_job_frac_of_22B_roofline":

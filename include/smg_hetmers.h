@@ -197,13 +197,13 @@ int     smg_engine_route(smg_engine *e, const uint64_t *splitters, int nranks, u
 int     smg_engine_apply(smg_engine *e, const uint64_t *d_recv, int64_t nrecv, int64_t *missing,
                          char *errbuf, size_t errlen);
 int     smg_engine_apply_own(smg_engine *e, int64_t *missing, char *errbuf, size_t errlen);
-/* Request filter (hash proof, k <= 32).  A request only matters when its target is a candidate of
+/* Request filter (hash proof, k <= 64).  A request only matters when its target is a candidate of
    pass 2 (exactly one suffix-side pair).  Pass 1 records in a bit map which block ids -- the leading
    id_bits = min(30, 2*(k/2)) bits of a k-mer -- hold a candidate; smg_engine_filter drops every request
    whose target id has a clear bit, before the requests are routed, sorted or looked up.  Single shard:
    apply_own filters with the engine's own map.  Sharded: every rank copies out the words its k-mer
    range covers (blockmap_copy), the ranks exchange them, OR them into one map of `nwords` uint32 on
-   the device and pass that to filter, then route().  id_bits = 0: no map (exact proof or k > 32).
+   the device and pass that to filter, then route().  id_bits = 0: no map (exact proof or k > 64).
    No counterpart in the reference (it has no complement look-ups at all: PloidyPlot.c scans every
    position of every k-mer). */
 int     smg_engine_blockmap(smg_engine *e, int *id_bits, int64_t *nwords);

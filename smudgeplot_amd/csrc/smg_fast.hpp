@@ -378,14 +378,15 @@ kf_fill_holes(u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill)
 // bits: 128 MB at most, cache resident) hold a candidate; a request whose target block holds none is dropped before
 // it is sorted, looked up -- or sent over xGMI in a sharded run, where the per-rank bitmaps are exchanged first
 // (16 MB per rank at 8 GPUs against ~8 bytes x 17 % of the entries in requests).  Conservative by construction:
-// a set bit only means "maybe".  Key-only records (RW = 1).
+// a set bit only means "maybe".  Records of RW words, the first one the leading word of the target k-mer.
 // chunk_fill = NULL: `req` is a flat array of nflat words (read in F_CH slices) that may hold sentinel words ~0 --
 // the host sorts long lists on their leading 8 bits first, so that the map words a workgroup probes stay in L2.
-__global__ void __launch_bounds__(F_TPB)
+template <int RW> __global__ void __launch_bounds__(F_TPB)
 kf_filter(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill, unsigned n_chunks, int64_t nflat,
           const uint32_t *__restrict__ bmap, int idshift, u64 *__restrict__ out, uint32_t *__restrict__ out_fill,
           unsigned max_out, FastCtl *__restrict__ ctl)
-{ __shared__ u64      stage[F_CH];
+{ constexpr unsigned SL = RW == 1 ? F_CH : 4 * F_TPB;        // records staged between two flushes
+  __shared__ u64      stage[SL * RW];
   __shared__ unsigned s_n, s_chunk, s_used;
   __shared__ u64      s_base, s_total;
   const int t = threadIdx.x;
@@ -398,58 +399,66 @@ kf_filter(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill, 
         { const int64_t left = nflat - (int64_t) c * F_CH;
           fill = left < F_CH ? (unsigned) left : (unsigned) F_CH;
         }
-      const u64 *src = req + (size_t) c * F_CH;
-      for (unsigned r0 = 0; r0 < fill; r0 += 4 * F_TPB)          // four independent map reads in flight per thread
-        { u64 y[4]; uint32_t wd[4]; bool keep[4];
+      const u64 *src = req + (size_t) c * F_CH * RW;
+      for (unsigned s0 = 0; s0 < fill; s0 += SL)
+        { const unsigned send = fill < s0 + SL ? fill : s0 + SL;
+          for (unsigned r0 = s0; r0 < send; r0 += 4 * F_TPB)     // four independent map reads in flight per thread
+            { u64 y[4]; uint32_t wd[4]; bool keep[4];
 #pragma unroll
-          for (int j = 0; j < 4; j++)
-            { const unsigned r = r0 + j * F_TPB + t;
-              y[j] = r < fill ? src[r] : 0;
-            }
+              for (int j = 0; j < 4; j++)
+                { const unsigned r = r0 + j * F_TPB + t;
+                  y[j] = r < send ? src[(size_t) r * RW] : 0;
+                }
 #pragma unroll
-          for (int j = 0; j < 4; j++) wd[j] = bmap[(uint32_t) (y[j] >> idshift) >> 5];
+              for (int j = 0; j < 4; j++) wd[j] = bmap[(uint32_t) (y[j] >> idshift) >> 5];
 #pragma unroll
-          for (int j = 0; j < 4; j++)
-            { const unsigned r = r0 + j * F_TPB + t;
-              keep[j] = r < fill && ((wd[j] >> ((uint32_t) (y[j] >> idshift) & 31)) & 1u) && (chunk_fill || y[j] != ~0ull);
-            }
+              for (int j = 0; j < 4; j++)
+                { const unsigned r = r0 + j * F_TPB + t;
+                  keep[j] = r < send && ((wd[j] >> ((uint32_t) (y[j] >> idshift) & 31)) & 1u) && (chunk_fill || y[j] != ~0ull);
+                }
 #pragma unroll
-          for (int j = 0; j < 4; j++)
-            { const u64 m = __ballot(keep[j]);
-              if (m)
-                { const int lane = t & 63, lead = __ffsll((long long) m) - 1;
-                  unsigned qb = 0;
-                  if (lane == lead) qb = atomicAdd(&s_n, (unsigned) __popcll(m));
-                  qb = __shfl(qb, lead, 64);
-                  if (keep[j]) stage[qb + __popcll(m & ((1ull << lane) - 1))] = y[j];
+              for (int j = 0; j < 4; j++)
+                { const u64 m = __ballot(keep[j]);
+                  if (m)
+                    { const int lane = t & 63, lead = __ffsll((long long) m) - 1;
+                      unsigned qb = 0;
+                      if (lane == lead) qb = atomicAdd(&s_n, (unsigned) __popcll(m));
+                      qb = __shfl(qb, lead, 64);
+                      if (keep[j])
+                        { const unsigned q = qb + __popcll(m & ((1ull << lane) - 1));
+                          stage[q * RW] = y[j];
+#pragma unroll
+                          for (int w = 1; w < RW; w++) stage[q * RW + w] = src[(size_t) (r0 + j * F_TPB + t) * RW + w];
+                        }
+                    }
                 }
             }
-        }
-      __syncthreads();
-      // append the survivors of this chunk to the workgroup's output chunk, split so that chunks fill to the brim
-      const unsigned qn = s_n;
-      __syncthreads();
-      if (qn)
-        { const unsigned old_chunk = s_chunk, old_used = s_used;
-          const unsigned room = old_chunk == F_NOCHUNK ? 0u : F_CH - old_used;
-          const unsigned head = qn < room ? qn : room;
-          if (t == 0)
-            { s_base = (u64) old_chunk * F_CH + old_used;
-              if (qn > head)
-                { if (old_chunk != F_NOCHUNK && old_chunk < max_out) out_fill[old_chunk] = F_CH;
-                  s_chunk = atomicAdd(&ctl->nf_chunks, 1u);
-                  s_used = qn - head;
+          __syncthreads();
+          // append the survivors to the workgroup's output chunk, split so that chunks fill to the brim
+          const unsigned qn = s_n;
+          __syncthreads();
+          if (qn)
+            { const unsigned old_chunk = s_chunk, old_used = s_used;
+              const unsigned room = old_chunk == F_NOCHUNK ? 0u : F_CH - old_used;
+              const unsigned head = qn < room ? qn : room;
+              if (t == 0)
+                { s_base = (u64) old_chunk * F_CH + old_used;
+                  if (qn > head)
+                    { if (old_chunk != F_NOCHUNK && old_chunk < max_out) out_fill[old_chunk] = F_CH;
+                      s_chunk = atomicAdd(&ctl->nf_chunks, 1u);
+                      s_used = qn - head;
+                    }
+                  else s_used = old_used + qn;
+                  s_total += qn;
+                  s_n = 0;
                 }
-              else s_used = old_used + qn;
-              s_total += qn;
-              s_n = 0;
+              __syncthreads();
+              if (head && old_chunk < max_out)
+                for (unsigned e = t; e < head * RW; e += F_TPB) out[s_base * RW + e] = stage[e];
+              if (qn > head && s_chunk < max_out)
+                for (unsigned e = t; e < (qn - head) * RW; e += F_TPB) out[(u64) s_chunk * F_CH * RW + e] = stage[head * RW + e];
+              __syncthreads();
             }
-          __syncthreads();
-          if (head && old_chunk < max_out)
-            for (unsigned e = t; e < head; e += F_TPB) out[s_base + e] = stage[e];
-          if (qn > head && s_chunk < max_out)
-            for (unsigned e = t; e < qn - head; e += F_TPB) out[(u64) s_chunk * F_CH + e] = stage[head + e];
-          __syncthreads();
         }
     }
   if (t == 0)
@@ -829,8 +838,8 @@ kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, unsigned nbig, u64 *
           int64_t partner;
           big_block_scan<W>(A.keys, A.cnt, A.n, A.g, i, s_all, s_hi, partner, w2);
           A.code[i] = (uint8_t) make_code(s_all, partner - i, w2);
-          if (W == 1 && A.bmap && s_all == 1)             // a candidate: mark its block for the request filter
-            { const uint32_t id = (uint32_t) (A.keys[i] >> 32) >> A.bmsh;
+          if (W <= 2 && A.bmap && s_all == 1)             // a candidate: mark its block for the request filter
+            { const uint32_t id = (uint32_t) (A.keys[i * W] >> 32) >> A.bmsh;
               atomicOr(&A.bmap[id >> 5], 1u << (id & 31));
             }
           if (s_hi > 0)

@@ -767,6 +767,7 @@ static FastArgs make_fast(smg_engine *e)
 }
 
 static int bm_id_bits(int kmer);
+static bool filter_ok(const smg_engine *e) { return (e->W == 1 && e->rw == 1) || (e->W == 2 && e->rw == 3); }
 
 static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, char *errbuf, size_t errlen)
 { int rc;
@@ -790,7 +791,7 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
   const bool narrow = e->W <= 2;                       // k <= 64: kf_pass1_r (blocked register scan)
   e->bm_bits = 0;
   e->filtered = false;
-  if (e->W == 1 && e->rw == 1 && !emit_all && !getenv("SMG_NO_FILTER"))
+  if (filter_ok(e) && !emit_all && !getenv("SMG_NO_FILTER"))
     { const int nbits = bm_id_bits(e->kmer);
       const int64_t bytes = 4 * (((1ll << nbits) + 31) >> 5) + 4 * R_BMW + 64;
       if ((rc = grow(&e->bmap, &e->bmap_cap, bytes, errbuf, errlen))) return rc;
@@ -1010,14 +1011,14 @@ static int bm_id_bits(int kmer)
 // drop the requests whose target window block holds no candidate (kf_filter); map = NULL: this engine's own map
 static int fast_filter(smg_engine *e, const uint32_t *map, char *errbuf, size_t errlen)
 { int rc;
-  if (!(e->W == 1 && e->rw == 1) || e->n_chunks == 0) return SMG_OK;
+  if (!filter_ok(e) || e->n_chunks == 0) return SMG_OK;
   if (!map) map = e->bm_bits ? e->bmap : NULL;
   if (!map) return SMG_OK;
   const int nbits = bm_id_bits(e->kmer);
   unsigned grid = e->n_chunks < 2048 ? e->n_chunks : 2048;
   const unsigned maxout = e->n_chunks + grid + 16;
   // (the two chunk lists swap roles after every filter: keep them the same size, or pass 1 would reallocate)
-  { int64_t want = (int64_t) maxout * F_CH * (int64_t) sizeof(u64), wantf = (int64_t) maxout * 4 + 4;
+  { int64_t want = (int64_t) maxout * F_CH * (int64_t) sizeof(u64) * e->rw, wantf = (int64_t) maxout * 4 + 4;
     if (want < e->req_cap) want = e->req_cap;
     if (wantf < e->chunk_cap) wantf = e->chunk_cap;
     if ((rc = grow(&e->reqf, &e->reqf_cap, want, errbuf, errlen))) return rc;
@@ -1027,7 +1028,7 @@ static int fast_filter(smg_engine *e, const uint32_t *map, char *errbuf, size_t 
   const int64_t nslots = (int64_t) e->n_chunks * F_CH;
   int64_t sort_min = 1 << 22;               // below this the probes are too few to matter
   { const char *v = getenv("SMG_FILTER_SORT_MIN"); if (v) sort_min = atoll(v); if (sort_min < SORT_MIN) sort_min = SORT_MIN; }
-  if (nslots >= sort_min && e->kmer < 32 && !getenv("SMG_FILTER_UNSORTED"))
+  if (e->rw == 1 && nslots >= sort_min && e->kmer < 32 && !getenv("SMG_FILTER_UNSORTED"))
     { // long list: the probes of the 128 MB map are random 64-byte fetches (7 ms for the 4.3e8 requests of the
       // 1 Gbp table).  One radix pass on the leading 8 k-mer bits first (holes as sentinels, as for the look-ups)
       // keeps the map words that the resident workgroups probe inside the L2 caches.
@@ -1037,11 +1038,14 @@ static int fast_filter(smg_engine *e, const uint32_t *map, char *errbuf, size_t 
       HIPCHK(rocprim::radix_sort_keys<smg_sort_config>(nullptr, tmp, e->req, e->req2, (size_t) nslots, 56u, 64u, e->stream));
       if ((rc = grow((char **) &e->sort_tmp, &e->sort_tmp_cap, (int64_t) tmp + 16, errbuf, errlen))) return rc;
       HIPCHK(rocprim::radix_sort_keys<smg_sort_config>(e->sort_tmp, tmp, e->req, e->req2, (size_t) nslots, 56u, 64u, e->stream));
-      hipLaunchKernelGGL(kf_filter, dim3(grid), dim3(F_TPB), 0, e->stream, e->req2, (const uint32_t *) NULL, e->n_chunks, nslots,
+      hipLaunchKernelGGL(kf_filter<1>, dim3(grid), dim3(F_TPB), 0, e->stream, e->req2, (const uint32_t *) NULL, e->n_chunks, nslots,
                          map, 64 - nbits, e->reqf, e->chunk_fillf, maxout, &e->ctrl->fast);
     }
+  else if (e->rw == 1)
+    hipLaunchKernelGGL(kf_filter<1>, dim3(grid), dim3(F_TPB), 0, e->stream, e->req, e->chunk_fill, e->n_chunks, (int64_t) 0,
+                       map, 64 - nbits, e->reqf, e->chunk_fillf, maxout, &e->ctrl->fast);
   else
-    hipLaunchKernelGGL(kf_filter, dim3(grid), dim3(F_TPB), 0, e->stream, e->req, e->chunk_fill, e->n_chunks, (int64_t) 0,
+    hipLaunchKernelGGL(kf_filter<3>, dim3(grid), dim3(F_TPB), 0, e->stream, e->req, e->chunk_fill, e->n_chunks, (int64_t) 0,
                        map, 64 - nbits, e->reqf, e->chunk_fillf, maxout, &e->ctrl->fast);
   hipEventRecord(e->ev[5], e->stream);
   HIPCHK(hipGetLastError());
@@ -1187,7 +1191,7 @@ extern "C" int smg_engine_blockmap(smg_engine *e, int *id_bits, int64_t *nwords)
 extern "C" int smg_engine_blockmap_copy(smg_engine *e, int64_t word_lo, int64_t nw, uint32_t *d_dst,
                                         char *errbuf, size_t errlen)
 { NEED_FAST(e)
-  if (!e->prepared || !e->bm_bits) return fail(errbuf, errlen, SMG_EINVAL, "no block map: pass 1 (hash proof, k <= 32) has not run%s");
+  if (!e->prepared || !e->bm_bits) return fail(errbuf, errlen, SMG_EINVAL, "no block map: pass 1 (hash proof, k <= 64) has not run%s");
   const int64_t nwords = ((1ll << e->bm_bits) + 31) >> 5;
   if (word_lo < 0 || nw < 0 || word_lo + nw > nwords || (nw > 0 && !d_dst))
     return fail(errbuf, errlen, SMG_EINVAL, "block map range out of bounds%s");
@@ -1199,7 +1203,7 @@ extern "C" int smg_engine_blockmap_copy(smg_engine *e, int64_t word_lo, int64_t 
 extern "C" int smg_engine_filter(smg_engine *e, const uint32_t *d_map, int64_t *kept, char *errbuf, size_t errlen)
 { NEED_FAST(e)
   if (!e->prepared) return fail(errbuf, errlen, SMG_EINVAL, "filter before pass1%s");
-  if (e->rw != 1 || e->W != 1) return fail(errbuf, errlen, SMG_EINVAL, "the request filter needs key-only requests (hash proof, k <= 32)%s");
+  if (!filter_ok(e)) return fail(errbuf, errlen, SMG_EINVAL, "the request filter covers the hash proof at k <= 64%s");
   if (!d_map && !e->bm_bits) return fail(errbuf, errlen, SMG_EINVAL, "no block map to filter with%s");
   HIPCHK(hipSetDevice(e->device));
   int rc = e->filtered ? SMG_OK : fast_filter(e, d_map, errbuf, errlen);

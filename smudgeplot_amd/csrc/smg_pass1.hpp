@@ -45,6 +45,8 @@
 #ifndef R_D
 #define R_D     3                        // distances scanned in registers; farther partners: tail loop
 #endif
+// block ids of the request filter: the leading min(30, 2*p0) bits of the k-mer = hi32(word 0) >> r_bmsh
+// (one-word k-mers: pshift = 32 - 2*p0; two-word k-mers have p0 >= 16)
 #define R_BMF   4096                     // block ids per tile with a bit in LDS (request filter)
 #define R_BMW   (R_BMF / 32)             //   = words of the global bit map they cover
 #define R_QCAP  1280                     // LDS request queue (records); flushed when the next tile might not fit
@@ -63,6 +65,8 @@ struct GeoR
   u64  smask;        // low 2*(k-p0) bits
   int  mshift;       // odd k: suffix >> mshift != 0  <=> the top suffix base (position p0) differs
 };
+
+template <int W> SMG_DEV int r_bmsh(const GeoR &G) { return W == 1 ? (G.pshift > 2 ? G.pshift : 2) : 2; }
 
 SMG_DEV int r_popc(unsigned v) { return __popc(v); }
 SMG_DEV int r_popc(u64 v) { return __popcll(v); }
@@ -266,8 +270,9 @@ r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict_
   if (slot0 >= R_HALO)
     { unsigned codes = 0;
       uint32_t bcur = dir_bucket(A.dir, S.ent[slot0 * W]);
-      const int bmsh = G.pshift > 2 ? G.pshift : 2;
-      const uint32_t bmbase = (W == 1 && RW == 1) ? (((uint32_t) (S.ent[R_HALO * W] >> 32) >> bmsh) & ~31u) : 0u;
+      constexpr bool R_BM = (W == 1 && RW == 1) || (W == 2 && RW == 3);     // variants that feed the request filter
+      const int bmsh = r_bmsh<W>(G);
+      const uint32_t bmbase = R_BM ? (((uint32_t) (S.ent[R_HALO * W] >> 32) >> bmsh) & ~31u) : 0u;
 #pragma unroll 1
       for (int r = 0; r < 4; r++)
         { const int64_t i = i0 + r;
@@ -288,7 +293,7 @@ r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict_
               S.lcn[slot0 + r] = (uint16_t) (A.sigsh >= 32 ? xh >> (A.sigsh - 32) : __builtin_amdgcn_alignbit(xh, xl, A.sigsh));
             }
           if (ok && big) { bigmask |= 1u << r; atomicAdd(S.s_nbig, 1u); }
-          if (W == 1 && RW == 1 && count == 1 && A.bmap)
+          if (R_BM && count == 1 && A.bmap)
             { // request filter: a CANDIDATE (exactly one suffix-side pair; a deferred entry may be marked in vain, which
               // is harmless) sets the bit of its block id in the tile's LDS bit map -- word 0 is the map word of
               // the tile's first owned entry; the few ids beyond R_BMF (sparse tables) go straight to the global map
@@ -374,7 +379,8 @@ kf_pass1_r(FastArgs A, GeoR G, uint32_t *__restrict__ bstart, u64 *__restrict__ 
   __shared__ uint16_t lcn[R_SCAN + 4];
   __shared__ u64      sq[(RW == 1 ? R_QCAP : R_OWN) * RW];
   __shared__ u64      sfp[R_TPB / 64][2];
-  __shared__ unsigned bm[(W == 1 && RW == 1) ? R_BMW : 1];
+  constexpr bool R_BM = (W == 1 && RW == 1) || (W == 2 && RW == 3);
+  __shared__ unsigned bm[R_BM ? R_BMW : 1];
   __shared__ unsigned s_tn, s_qn, s_nbig, s_chunk, s_used, s_bigbase, s_bigcur;
   __shared__ u64      s_base, s_total;
 
@@ -387,7 +393,7 @@ kf_pass1_r(FastArgs A, GeoR G, uint32_t *__restrict__ bstart, u64 *__restrict__ 
   S.cred = cred; S.tailq = tailq; S.ent = ent; S.lcn = lcn; S.sq = sq;
   S.s_tn = &s_tn; S.s_qn = &s_qn; S.s_nbig = &s_nbig;
   S.bm = bm;
-  if (W == 1 && RW == 1 && t < R_BMW) bm[t] = 0;
+  if (R_BM && t < R_BMW) bm[t] = 0;
   for (int s = t; s < R_CRED; s += R_TPB) cred[s] = 0;
   if (t == 0) { s_chunk = F_NOCHUNK; s_used = 0; s_total = 0; s_tn = 0; s_qn = 0; s_nbig = 0; }
   lds_barrier();
@@ -401,10 +407,10 @@ kf_pass1_r(FastArgs A, GeoR G, uint32_t *__restrict__ bstart, u64 *__restrict__ 
         r_tile<W, RW, ODD, KF, false>(A, G, S, bstart, ctl, emit_all, want_fp, g0, t, fa, fb, fneg, bigmask);
       lds_barrier();
       //@mark P4_FLUSH
-      if (W == 1 && RW == 1 && A.bmap && t < R_BMW) // candidate-block bits of this tile -> global map
+      if (R_BM && A.bmap && t < R_BMW)              // candidate-block bits of this tile -> global map
         { const unsigned v = bm[t];
           if (v)
-            { const int bmsh = G.pshift > 2 ? G.pshift : 2;
+            { const int bmsh = r_bmsh<W>(G);
               atomicOr(&A.bmap[(((uint32_t) (ent[R_HALO * W] >> 32) >> bmsh) >> 5) + t], v);
               bm[t] = 0;
             }

@@ -242,9 +242,10 @@ def test_engine_object_with_torch_tensors_and_manual_two_shard_exchange():
     assert np.array_equal(total.cpu().numpy().reshape(1001, 501), want)
 
 
-@pytest.mark.parametrize("k,m,seed", [(31, 30000, 3), (21, 30000, 4), (12, 20000, 5), (32, 8000, 6)])
+@pytest.mark.parametrize("k,m,seed", [(31, 30000, 3), (21, 30000, 4), (12, 20000, 5), (32, 8000, 6), (33, 8000, 7),
+                                      (40, 20000, 8), (51, 6000, 9), (64, 5000, 10)])
 def test_request_filter_changes_nothing_but_the_request_count(k, m, seed, monkeypatch):
-    """hash proof, k <= 32: requests whose target block holds no candidate are dropped before the look-ups"""
+    """hash proof, k <= 64: requests whose target block holds no candidate are dropped before the look-ups"""
     packed, cnt = synth.adversarial_table(k, m, 4, seed, low_complexity=40, dense=1)
     want = brute.hetmers_plot(packed, cnt, k) if m * k <= 400000 else None
     tab = table_from(packed, cnt, k)
