@@ -82,7 +82,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force = os.environ.get("SMG_FORCE_EXCHANGE") == "1"     # diagnostics: the N > 1 protocol in a one-rank group
+    if world > 1 or force:
+        if force and "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
 
     # ---- workload: identical table on every rank, then keep this rank's prefix shard ----------
@@ -198,7 +201,7 @@ def main():
             "pairs_in_plot": int(plot.sum().item()),
         }
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -273,6 +273,7 @@ r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict_
       constexpr bool R_BM = (W == 1 && RW == 1) || (W == 2 && RW == 3);     // variants that feed the request filter
       const int bmsh = r_bmsh<W>(G);
       const uint32_t bmbase = R_BM ? (((uint32_t) (S.ent[R_HALO * W] >> 32) >> bmsh) & ~31u) : 0u;
+      unsigned farmask = 0;
 #pragma unroll 1
       for (int r = 0; r < 4; r++)
         { const int64_t i = i0 + r;
@@ -296,10 +297,10 @@ r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict_
           if (R_BM && count == 1 && A.bmap)
             { // request filter: a CANDIDATE (exactly one suffix-side pair; a deferred entry may be marked in vain, which
               // is harmless) sets the bit of its block id in the tile's LDS bit map -- word 0 is the map word of
-              // the tile's first owned entry; the few ids beyond R_BMF (sparse tables) go straight to the global map
-              const uint32_t id = (uint32_t) (x.w[0] >> 32) >> bmsh, rel = id - bmbase;
+              // the tile's first owned entry; the few ids beyond R_BMF (sparse tables) are marked after the loop
+              const uint32_t rel = ((uint32_t) (x.w[0] >> 32) >> bmsh) - bmbase;
               if (rel < R_BMF) atomicOr(&S.bm[rel >> 5], 1u << (rel & 31));
-              else atomicOr(&A.bmap[id >> 5], 1u << (id & 31));
+              else farmask |= 1u << r;
             }
           //@mark P3_DIR
           // order check + bucket directory: the first entry of every bucket stores its index
@@ -348,6 +349,11 @@ r_tile(const FastArgs &A, const GeoR &G, const RShared &S, uint32_t *__restrict_
                 }
             }
         }
+      if (R_BM && farmask)                         // sparse table: block ids outside the tile's LDS window
+        for (unsigned m = farmask; m; m &= m - 1)
+          { const uint32_t id = (uint32_t) (S.ent[(slot0 + __ffs(m) - 1) * W] >> 32) >> bmsh;
+            atomicOr(&A.bmap[id >> 5], 1u << (id & 31));
+          }
       //@mark P3_STORE
       { if (INNER || (vmask & 0xF) == 0xF)
             { *reinterpret_cast<unsigned *>(A.code + i0) = codes;
