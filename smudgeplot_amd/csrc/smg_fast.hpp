@@ -593,40 +593,52 @@ template <int W> __global__ void __launch_bounds__(P2_TPB)
 kf_pass2(FastArgs A, u64 *__restrict__ plot)
 { __shared__ unsigned tile[P2_CELLS];
   __shared__ unsigned queue[P2_QCAP];     // local index (14 bits) | code << 16
-  __shared__ unsigned s_qn;
+  __shared__ unsigned s_qn[2];            // queue fill of the even / odd tiles of this workgroup
   const int t = threadIdx.x;
   for (int c = t; c < P2_CELLS; c += P2_TPB) tile[c] = 0;
-  if (t == 0) s_qn = 0;
+  if (t == 0) { s_qn[0] = 0; s_qn[1] = 0; }
   lds_barrier();
 
   const int64_t step = (int64_t) gridDim.x * P2_TILE;
   int64_t c0 = (int64_t) blockIdx.x * P2_TILE;
   uint4 cv = make_uint4(0, 0, 0, 0);
   if (c0 + (int64_t) t * P2_VEC < A.n) cv = *reinterpret_cast<const uint4 *>(A.code + c0 + t * P2_VEC);
-  for (; c0 < A.n; c0 += step)
-    { // ---- phase A ----
+  for (unsigned it = 0; c0 < A.n; c0 += step, it ^= 1u)
+    { // ---- phase A: the candidates among this thread's 16 code bytes, found on the packed words --------------
+      // candidate <=> unique partner ahead (low six bits 32..62: bit 5 set, not all six) and no P flag (bit 7)
       const unsigned wv[4] = { cv.x, cv.y, cv.z, cv.w };
+      unsigned cm = 0;
 #pragma unroll
       for (int q = 0; q < 4; q++)
-        {
+        { const unsigned w = wv[q];
+          const unsigned all6 = ((w & 0x3F3F3F3Fu) + 0x01010101u) >> 6;           // bit 0 of a byte: low six bits == 63
+          const unsigned c = (w >> 5) & ~(w >> 7) & ~all6 & 0x01010101u;
+          cm |= ((c * 0x10204080u) >> 28) << (4 * q);                             // bit 0 of the four bytes -> a nibble
+        }
+      { const int64_t left = A.n - (c0 + (int64_t) t * P2_VEC);                  // ragged end of the table
+        if (left < P2_VEC) cm = left <= 0 ? 0u : cm & ((1u << left) - 1u);
+      }
+      // queue slots: exclusive prefix sum of the counts (<= 16) over the wave, bit plane by bit plane, then one
+      // LDS atomic per wave
+      const unsigned k = (unsigned) __popc(cm);
+      unsigned excl = 0, total = 0;
 #pragma unroll
-          for (int bb = 0; bb < 4; bb++)
-            { const unsigned ci = (wv[q] >> (8 * bb)) & 0xFF;
-              const unsigned lo6 = ci & 63;
-              const int li = t * P2_VEC + 4 * q + bb;
-              const bool cand = lo6 >= 32 && lo6 != CODE_MULTI && !(ci & CODE_P) && c0 + li < A.n;
-              const u64 m = __ballot(cand);
-              if (m)
-                { const int lane = t & 63, lead = __ffsll((long long) m) - 1;
-                  unsigned qb = 0;
-                  if (lane == lead) qb = atomicAdd(&s_qn, (unsigned) __popcll(m));
-                  qb = __shfl(qb, lead, 64);
-                  if (cand)
-                    { const unsigned slot = qb + __popcll(m & ((1ull << lane) - 1));
-                      if (slot < P2_QCAP) queue[slot] = (unsigned) li | (ci << 16);
-                      else p2_candidate<W>(A, tile, plot, c0 + li, ci);      // queue full: rare, done in place
-                    }
-                }
+      for (int b = 0; b < 5; b++)
+        { const u64 m = __ballot((k >> b) & 1u);
+          excl += (unsigned) __builtin_amdgcn_mbcnt_hi((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m, 0u)) << b;
+          total += (unsigned) __popcll(m) << b;
+        }
+      if (total)
+        { unsigned qb = 0;
+          if ((t & 63) == 0) qb = atomicAdd(&s_qn[it], total);
+          unsigned slot = (unsigned) __builtin_amdgcn_readfirstlane((int) qb) + excl;
+          const u64 lo = (u64) cv.x | ((u64) cv.y << 32), hi = (u64) cv.z | ((u64) cv.w << 32);
+          for (unsigned m = cm; m; m &= m - 1, slot++)
+            { const int j = __ffs(m) - 1;
+              const unsigned ci = (unsigned) ((j < 8 ? lo : hi) >> (8 * (j & 7))) & 0xFFu;
+              const int li = t * P2_VEC + j;
+              if (slot < P2_QCAP) queue[slot] = (unsigned) li | (ci << 16);
+              else p2_candidate<W>(A, tile, plot, c0 + li, ci);                    // queue full: rare, done in place
             }
         }
       // prefetch the next tile's codes while the queue is drained
@@ -635,13 +647,12 @@ kf_pass2(FastArgs A, u64 *__restrict__ plot)
       if (nx < A.n) cv = *reinterpret_cast<const uint4 *>(A.code + nx);
       lds_barrier();
       // ---- phase B ----
-      const unsigned qn = s_qn < P2_QCAP ? s_qn : P2_QCAP;
+      const unsigned qn = s_qn[it] < P2_QCAP ? s_qn[it] : P2_QCAP;
+      if (t == 0) s_qn[it ^ 1u] = 0;             // the other counter is idle until the next tile's phase A
       for (unsigned q = t; q < qn; q += P2_TPB)
         { const unsigned e = queue[q];
           p2_candidate<W>(A, tile, plot, c0 + (e & 0xFFFF), e >> 16);
         }
-      lds_barrier();
-      if (t == 0) s_qn = 0;
       lds_barrier();
     }
 
