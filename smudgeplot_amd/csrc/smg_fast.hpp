@@ -589,7 +589,8 @@ p2_candidate(const FastArgs &A, unsigned *tile, u64 *__restrict__ plot, int64_t 
   plot_bump(tile, plot, ni, nj, w2 ? 2u : 1u);
 }
 
-template <int W> __global__ void __launch_bounds__(P2_TPB)
+// (1024 threads = 4 waves per SIMD and workgroup: two workgroups per CU need <= 64 VGPRs)
+template <int W> __global__ void __launch_bounds__(P2_TPB) __attribute__((amdgpu_waves_per_eu(8, 8)))
 kf_pass2(FastArgs A, u64 *__restrict__ plot)
 { __shared__ unsigned tile[P2_CELLS];
   __shared__ unsigned queue[P2_QCAP];     // local index (14 bits) | code << 16
