@@ -83,7 +83,7 @@ class NumpyEngine:
     def blockmap(self):
         if self.symcheck != "hash":
             return 0, 0
-        bits = min(30, 2 * (self.k // 2))
+        bits = min(14, 2 * (self.k // 2))      # (the engine uses up to 30 bits = 128 MB; any width the ranks agree on works)
         return bits, ((1 << bits) + 31) >> 5
 
     def _own_map(self):
