@@ -414,6 +414,7 @@ struct smg_engine
   uint32_t    *bmap;   int64_t bmap_cap;     // candidate block map (request filter)
   int          bm_bits;                      //   leading k-mer bits per block id (0 = not built by the last pass 1)
   bool         filtered;                     //   the request list of the last pass 1 has been filtered
+  int          presorted;                    //   0 not decided, 1 req2 holds the list bucketed on its leading 8 bits, 2 left as it is
   u64         *reqf;   int64_t reqf_cap;     // filtered request chunks (swapped with req)
   uint32_t    *chunk_fillf; int64_t chunk_capf;
   uint32_t    *route_cnt;  int64_t route_cnt_cap;
@@ -790,7 +791,7 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
     }
   const bool narrow = e->W <= 2;                       // k <= 64: kf_pass1_r (blocked register scan)
   e->bm_bits = 0;
-  e->filtered = false;
+  e->filtered = false; e->presorted = 0;
   if (filter_ok(e) && !emit_all && !getenv("SMG_NO_FILTER"))
     { const int nbits = bm_id_bits(e->kmer);
       const int64_t bytes = 4 * (((1ll << nbits) + 31) >> 5) + 4 * R_BMW + 64;
@@ -1008,6 +1009,28 @@ static int bm_id_bits(int kmer)
   return nbits;
 }
 
+// first half of the request filter, which does not need the map (a sharded run overlaps it with the exchange of the
+// block maps): long key-only lists are bucketed on their leading 8 bits.  The probes of the 128 MB map are random
+// 64-byte fetches otherwise (7 ms for the 4.4e8 requests of the 1 Gbp table); one radix pass (holes of the chunk
+// array as sentinels, as for the look-ups) keeps the map words that the resident workgroups probe inside the L2s.
+static int filter_presort(smg_engine *e, char *errbuf, size_t errlen)
+{ int rc;
+  hipEventRecord(e->ev[4], e->stream);                      // start of the filter's time
+  e->presorted = 2;
+  const int64_t nslots = (int64_t) e->n_chunks * F_CH;
+  int64_t sort_min = 1 << 22;               // below this the probes are too few to matter
+  { const char *v = getenv("SMG_FILTER_SORT_MIN"); if (v) sort_min = atoll(v); if (sort_min < SORT_MIN) sort_min = SORT_MIN; }
+  if (!(e->rw == 1 && nslots >= sort_min && e->kmer < 32) || getenv("SMG_FILTER_UNSORTED")) return SMG_OK;
+  hipLaunchKernelGGL(kf_fill_holes, dim3(e->n_chunks), dim3(F_TPB), 0, e->stream, e->req, e->chunk_fill);
+  if ((rc = grow(&e->req2, &e->req2_cap, nslots * (int64_t) sizeof(u64), errbuf, errlen))) return rc;
+  size_t tmp = 0;
+  HIPCHK(rocprim::radix_sort_keys<smg_sort_config>(nullptr, tmp, e->req, e->req2, (size_t) nslots, 56u, 64u, e->stream));
+  if ((rc = grow((char **) &e->sort_tmp, &e->sort_tmp_cap, (int64_t) tmp + 16, errbuf, errlen))) return rc;
+  HIPCHK(rocprim::radix_sort_keys<smg_sort_config>(e->sort_tmp, tmp, e->req, e->req2, (size_t) nslots, 56u, 64u, e->stream));
+  e->presorted = 1;
+  return SMG_OK;
+}
+
 // drop the requests whose target window block holds no candidate (kf_filter); map = NULL: this engine's own map
 static int fast_filter(smg_engine *e, const uint32_t *map, char *errbuf, size_t errlen)
 { int rc;
@@ -1031,23 +1054,11 @@ static int fast_filter(smg_engine *e, const uint32_t *map, char *errbuf, size_t 
     if ((rc = grow(&e->reqf, &e->reqf_cap, want, errbuf, errlen))) return rc;
     if ((rc = grow(&e->chunk_fillf, &e->chunk_capf, wantf, errbuf, errlen))) return rc;
   }
-  hipEventRecord(e->ev[4], e->stream);
+  if (!e->presorted && (rc = filter_presort(e, errbuf, errlen))) return rc;
   const int64_t nslots = (int64_t) e->n_chunks * F_CH;
-  int64_t sort_min = 1 << 22;               // below this the probes are too few to matter
-  { const char *v = getenv("SMG_FILTER_SORT_MIN"); if (v) sort_min = atoll(v); if (sort_min < SORT_MIN) sort_min = SORT_MIN; }
-  if (e->rw == 1 && nslots >= sort_min && e->kmer < 32 && !getenv("SMG_FILTER_UNSORTED"))
-    { // long list: the probes of the 128 MB map are random 64-byte fetches (7 ms for the 4.3e8 requests of the
-      // 1 Gbp table).  One radix pass on the leading 8 k-mer bits first (holes as sentinels, as for the look-ups)
-      // keeps the map words that the resident workgroups probe inside the L2 caches.
-      hipLaunchKernelGGL(kf_fill_holes, dim3(e->n_chunks), dim3(F_TPB), 0, e->stream, e->req, e->chunk_fill);
-      if ((rc = grow(&e->req2, &e->req2_cap, nslots * (int64_t) sizeof(u64), errbuf, errlen))) return rc;
-      size_t tmp = 0;
-      HIPCHK(rocprim::radix_sort_keys<smg_sort_config>(nullptr, tmp, e->req, e->req2, (size_t) nslots, 56u, 64u, e->stream));
-      if ((rc = grow((char **) &e->sort_tmp, &e->sort_tmp_cap, (int64_t) tmp + 16, errbuf, errlen))) return rc;
-      HIPCHK(rocprim::radix_sort_keys<smg_sort_config>(e->sort_tmp, tmp, e->req, e->req2, (size_t) nslots, 56u, 64u, e->stream));
-      hipLaunchKernelGGL(kf_filter<1>, dim3(grid), dim3(F_TPB), 0, e->stream, e->req2, (const uint32_t *) NULL, e->n_chunks, nslots,
-                         map, 64 - nbits, e->reqf, e->chunk_fillf, maxout, &e->ctrl->fast);
-    }
+  if (e->presorted == 1)
+    hipLaunchKernelGGL(kf_filter<1>, dim3(grid), dim3(F_TPB), 0, e->stream, e->req2, (const uint32_t *) NULL, e->n_chunks, nslots,
+                       map, 64 - nbits, e->reqf, e->chunk_fillf, maxout, &e->ctrl->fast);
   else if (e->rw == 1)
     hipLaunchKernelGGL(kf_filter<1>, dim3(grid), dim3(F_TPB), 0, e->stream, e->req, e->chunk_fill, e->n_chunks, (int64_t) 0,
                        map, 64 - nbits, e->reqf, e->chunk_fillf, maxout, &e->ctrl->fast);
@@ -1205,6 +1216,14 @@ extern "C" int smg_engine_blockmap_copy(smg_engine *e, int64_t word_lo, int64_t 
   HIPCHK(hipSetDevice(e->device));
   if (nw > 0) HIPCHK(hipMemcpyAsync(d_dst, e->bmap + word_lo, (size_t) nw * 4, hipMemcpyDeviceToDevice, e->stream));
   return SMG_OK;
+}
+
+extern "C" int smg_engine_presort(smg_engine *e, char *errbuf, size_t errlen)
+{ NEED_FAST(e)
+  if (!e->prepared) return fail(errbuf, errlen, SMG_EINVAL, "presort before pass1%s");
+  if (!filter_ok(e) || !e->bm_bits || e->filtered || e->presorted || e->n_chunks == 0) return SMG_OK;
+  HIPCHK(hipSetDevice(e->device));
+  return filter_presort(e, errbuf, errlen);
 }
 
 extern "C" int smg_engine_filter(smg_engine *e, const uint32_t *d_map, int64_t *kept, char *errbuf, size_t errlen)

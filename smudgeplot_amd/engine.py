@@ -62,6 +62,7 @@ EXPORTS = [
     "smg_engine_decode", "smg_engine_bind", "smg_engine_condition", "smg_engine_run", "smg_engine_pass1",
     "smg_engine_nreq", "smg_engine_record_words", "smg_engine_route", "smg_engine_apply",
     "smg_engine_apply_own", "smg_engine_blockmap", "smg_engine_blockmap_copy", "smg_engine_filter",
+    "smg_engine_presort",
     "smg_engine_symhash", "smg_engine_pass2", "smg_engine_stats",
     "smg_engine_extract", "smg_hetmers_extract", "smg_free", "smg_condition_table", "smg_version",
 ]
@@ -126,6 +127,7 @@ def load_library():
     lib.smg_engine_blockmap.argtypes = [vp, C.POINTER(i32), C.POINTER(i64)]
     lib.smg_engine_blockmap_copy.argtypes = [vp, i64, i64, vp, *err]
     lib.smg_engine_filter.argtypes = [vp, vp, C.POINTER(i64), *err]
+    lib.smg_engine_presort.argtypes = [vp, *err]
     lib.smg_engine_symhash.argtypes = [vp, C.POINTER(C.c_uint64), *err]
     lib.smg_engine_pass2.argtypes = [vp, vp, *err]
     lib.smg_engine_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -317,6 +319,9 @@ class Engine:
 
     def blockmap_copy(self, word_lo: int, nw: int, dst_ptr: int):
         _check(self.lib.smg_engine_blockmap_copy(self.h, word_lo, nw, dst_ptr, self._buf, 512), self._buf)
+
+    def presort(self):
+        _check(self.lib.smg_engine_presort(self.h, self._buf, 512), self._buf)
 
     def filter(self, map_ptr=None) -> int:
         kept = C.c_int64(0)

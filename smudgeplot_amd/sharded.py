@@ -75,6 +75,9 @@ class TorchEngine:
     def blockmap_copy(self, word_lo, nw, dst):
         self.e.blockmap_copy(word_lo, nw, dst.data_ptr())
 
+    def presort(self):
+        self.e.presort()
+
     def filter(self, full_map=None):
         return self.e.filter(None if full_map is None else full_map.data_ptr())
 
@@ -187,7 +190,9 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
             mine = torch.zeros(width, dtype=torch.int32, device=dev)
             eng.blockmap_copy(wlo[rank], wlen[rank], mine)
             parts = torch.empty(world * width, dtype=torch.int32, device=dev)
-            dist.all_gather_into_tensor(parts, mine, group=group)
+            work = dist.all_gather_into_tensor(parts, mine, group=group, async_op=True)
+            eng.presort()          # the map-independent half of the filter runs while the maps are in flight
+            work.wait()
             full = torch.zeros(nwords, dtype=torch.int32, device=dev)
             for r in range(world):                  # ranges of neighbours share their boundary word: OR, not copy
                 full[wlo[r]: wlo[r] + wlen[r]] |= parts[r * width: r * width + wlen[r]]

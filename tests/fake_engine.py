@@ -96,6 +96,9 @@ class NumpyEngine:
     def blockmap_copy(self, word_lo, nw, dst):
         dst[:nw] = torch.from_numpy(self._own_map()[word_lo: word_lo + nw].view(np.int32).copy())
 
+    def presort(self):
+        pass
+
     def filter(self, full_map=None):
         bits, _ = self.blockmap()
         m = self._own_map() if full_map is None else full_map.cpu().numpy().view(np.uint32)
