@@ -781,15 +781,8 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
   const int64_t pbytes = ((e->n + 15) & ~15ll) + 32;
   if (e->W <= 2 && (rc = grow(&e->sig, &e->sig_cap, 2 * pbytes, errbuf, errlen))) return rc;
   if ((rc = dir_geometry(e, errbuf, errlen))) return rc;
-  if (e->n > 0)
-    HIPCHK(hipMemsetAsync(e->bstart, 0xFF, sizeof(uint32_t) * ((size_t) e->dir.nb + 2), e->stream));
-  if (e->n == 0)
-    { HIPCHK(hipMemsetAsync(e->bstart, 0, sizeof(uint32_t) * ((size_t) e->dir.nb + 2), e->stream));
-      e->n_chunks = 0; e->prepared = true;
-      memset(e->fp, 0, sizeof(e->fp));
-      return SMG_OK;
-    }
-  const bool narrow = e->W <= 2;                       // k <= 64: kf_pass1_r (blocked register scan)
+  // request filter: the candidate block map (an empty shard has one too -- all zero -- so that every rank of a
+  // sharded run reports the same geometry and takes part in the exchange of the maps)
   e->bm_bits = 0;
   e->filtered = false; e->presorted = 0;
   if (filter_ok(e) && !emit_all && !getenv("SMG_NO_FILTER"))
@@ -799,6 +792,15 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
       HIPCHK(hipMemsetAsync(e->bmap, 0, (size_t) bytes, e->stream));
       e->bm_bits = nbits;
     }
+  if (e->n > 0)
+    HIPCHK(hipMemsetAsync(e->bstart, 0xFF, sizeof(uint32_t) * ((size_t) e->dir.nb + 2), e->stream));
+  if (e->n == 0)
+    { HIPCHK(hipMemsetAsync(e->bstart, 0, sizeof(uint32_t) * ((size_t) e->dir.nb + 2), e->stream));
+      e->n_chunks = 0; e->prepared = true;
+      memset(e->fp, 0, sizeof(e->fp));
+      return SMG_OK;
+    }
+  const bool narrow = e->W <= 2;                       // k <= 64: kf_pass1_r (blocked register scan)
   const int64_t ntiles = narrow ? (e->n + R_OWN - 1) / R_OWN : (e->n + F_TILE - 1) / F_TILE;
   GeoR gr;
   { const int p0 = e->kmer / 2, sbits = 2 * (e->kmer - p0);

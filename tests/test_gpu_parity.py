@@ -367,7 +367,8 @@ def _manual_sharded(k, tk, tc, cuts, dev, symcheck="hash"):
     world = len(cuts) - 1
     keys_np = None
     engs, sends, counts = [], [], []
-    firsts = [tk[c:c + 1].cpu().numpy().view(np.uint64) for c in cuts[1:-1]]
+    ntab = tc.numel()                          # (an empty trailing shard starts at +infinity)
+    firsts = [tk[c:c + 1].cpu().numpy().view(np.uint64) if c < ntab else np.array([~np.uint64(0)]) for c in cuts[1:-1]]
     split = np.concatenate(firsts) if firsts else np.zeros(0, np.uint64)
     for r in range(world):
         en = sharded.TorchEngine(dev)
@@ -375,6 +376,7 @@ def _manual_sharded(k, tk, tc, cuts, dev, symcheck="hash"):
         en.pass1(symcheck)
         engs.append(en)
     bits, nwords = engs[0].blockmap()
+    assert all(en.blockmap() == (bits, nwords) for en in engs)        # empty shards included
     emitted = sum(en.nreq() for en in engs)
     if bits:                                   # request filter: the exchange of the candidate block maps, by hand
         wlo, wlen = sharded.blockmap_ranges(split, 1, world, bits)
@@ -410,6 +412,26 @@ def _manual_sharded(k, tk, tc, cuts, dev, symcheck="hash"):
     torch.cuda.synchronize()
     assert sum(sum(c) for c in counts) <= emitted
     return total, emitted
+
+
+@pytest.mark.parametrize("k", [12, 31, 40])
+def test_manual_shards_with_an_empty_shard(k):
+    """a rank that owns nothing still reports the block-map geometry of the others and joins the exchange"""
+    import torch
+    packed, cnt = synth.adversarial_table(k, 5000, 4, 33, low_complexity=20, dense=1)
+    want, _ = engine.hetmers_run(table_from(packed, cnt, k), symcheck="hash")
+    if k > 32:
+        pytest.skip("_manual_sharded routes one-word k-mers")
+    keys = ktab.packed_to_u64(packed)
+    dev = torch.device("cuda:0")
+    tk = torch.from_numpy(keys.view(np.int64)).to(dev)
+    tc = torch.from_numpy(cnt.view(np.int16)).to(dev)
+    n = len(cnt)
+    from smudgeplot_amd import sharded
+    cut = sharded.fix_cut(keys, 1, k, n // 2)
+    for cuts in ([0, 0, cut, n], [0, cut, cut, n], [0, cut, n, n]):
+        tot, _ = _manual_sharded(k, tk, tc, cuts, dev)
+        assert np.array_equal(tot.cpu().numpy().reshape(1001, 501), want), cuts
 
 
 def test_full_size_config3_properties():
