@@ -143,3 +143,24 @@ def test_hetmers_conditioning_decision_and_no_cpu_fallback(tmp_path):
     assert "  Making table symmetric\n" in r.stderr
     with pytest.raises(engine.EngineError):
         engine.Engine(0)
+
+
+def test_blockmap_ranges_cover_the_map_and_share_only_boundary_words():
+    """sharded.blockmap_ranges: the word ranges of the ranks' k-mer ranges tile the candidate block map"""
+    from smudgeplot_amd import sharded
+    rng = np.random.default_rng(5)
+    for bits in (4, 12, 30):
+        nwords = ((1 << bits) + 31) >> 5
+        for world in (1, 2, 3, 8):
+            firsts = np.sort(rng.integers(0, 2 ** 63, size=world - 1, dtype=np.uint64) << np.uint64(1))
+            if world > 2:
+                firsts[1] = firsts[0]                       # an empty shard inherits its successor's first k-mer
+            wlo, wlen = sharded.blockmap_ranges(firsts, 1, world, bits)
+            assert wlo[0] == 0 and wlo[-1] + wlen[-1] == nwords
+            for r in range(world):
+                assert wlen[r] >= 1 and 0 <= wlo[r] and wlo[r] + wlen[r] <= nwords
+                if r:
+                    prev_end = wlo[r - 1] + wlen[r - 1]     # neighbours overlap in exactly their boundary word
+                    assert prev_end - 1 == wlo[r]
+                    # the id of rank r's first k-mer falls into that shared word
+                    assert (int(firsts[r - 1]) >> (64 - bits)) >> 5 == wlo[r]

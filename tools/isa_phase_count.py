@@ -22,11 +22,16 @@ s = open(out).read()
 m = re.search(r'\n' + re.escape(sys.argv[1]) + r'[^\n]*:\s*;[^\n]*\n', s)
 body = s[m.end():]
 body = body[:body.index('.Lfunc_end')]
-cur, cnt = 'PRE', collections.OrderedDict()
+# a marker that occurs several times (a template instantiated twice inside one kernel: interior and edge tiles) is
+# numbered per occurrence: P3_RC, P3_RC#2, ...
+cur, cnt, seen = 'PRE', collections.OrderedDict(), collections.Counter()
 for l in body.split('\n'):
     l = l.strip()
     if l.startswith('; ##'):
-        cur = l[4:]; continue
+        name = l[4:]
+        seen[name] += 1
+        cur = name if seen[name] == 1 else f"{name}#{seen[name]}"
+        continue
     if not l or l.startswith((';', '.')) or l.endswith(':'):
         continue
     op = l.split()[0]
