@@ -1084,60 +1084,48 @@ static int fast_filter(smg_engine *e, const uint32_t *map, char *errbuf, size_t 
   return SMG_OK;
 }
 
+// squeeze the request chunks (ragged fills) into the dense array e->dense: exclusive scan of the fills + one copy
+static int compact_chunks(smg_engine *e, int64_t nreq, char *errbuf, size_t errlen)
+{ int rc;
+  if ((rc = grow(&e->dense, &e->dense_cap, nreq * (int64_t) sizeof(u64) * e->rw, errbuf, errlen))) return rc;
+  if ((rc = grow(&e->chunk_off, &e->chunk_off_cap, (int64_t) e->n_chunks * 4 + 4, errbuf, errlen))) return rc;
+  size_t tmp = 0;
+  HIPCHK(rocprim::exclusive_scan(nullptr, tmp, e->chunk_fill, e->chunk_off, 0u, (size_t) e->n_chunks,
+                                 rocprim::plus<uint32_t>(), e->stream));
+  if ((rc = grow((char **) &e->sort_tmp, &e->sort_tmp_cap, (int64_t) tmp + 16, errbuf, errlen))) return rc;
+  HIPCHK(rocprim::exclusive_scan(e->sort_tmp, tmp, e->chunk_fill, e->chunk_off, 0u, (size_t) e->n_chunks,
+                                 rocprim::plus<uint32_t>(), e->stream));
+  hipLaunchKernelGGL(kf_compact, dim3(e->n_chunks), dim3(F_TPB), 0, e->stream, e->req, e->chunk_fill, e->chunk_off, e->rw, e->dense);
+  return SMG_OK;
+}
+
+// look-ups of this engine's own request chunks (flat = NULL; filtered first if a block map was built) or of a flat
+// array of received records
 static int fast_apply(smg_engine *e, const u64 *flat, int64_t nflat, int check_count, int64_t *missing,
                       char *errbuf, size_t errlen)
-{ int rc;
+{ int rc = SMG_OK;
   if (!flat && e->bm_bits && !e->filtered && (rc = fast_filter(e, NULL, errbuf, errlen))) return rc;
   hipEventRecord(e->ev[4], e->stream);
-  if (e->W == 1 && e->rw == 1)
-    { if (!flat)
-        { // squeeze the per-workgroup chunks into one dense array, then sort + look up in order
-          const int64_t nreq = e->st.nrequests;
-          const int64_t nslots = (int64_t) e->n_chunks * F_CH;
-          if (nreq > 0 && e->n_chunks > 0 && nslots <= nreq + nreq / 8 && nslots >= SORT_MIN && e->kmer < 32)
-            { // nearly every chunk is full (kf_pass1_r splits its batches): sort the chunk array in place of a
-              // compaction pass, holes as sentinels behind the requests
-              hipLaunchKernelGGL(kf_fill_holes, dim3(e->n_chunks), dim3(F_TPB), 0, e->stream, e->req, e->chunk_fill);
-              rc = apply_sorted(e, e->req, nslots, 1, errbuf, errlen);
-            }
-          else if (nreq > 0 && e->n_chunks > 0)
-            { if ((rc = grow(&e->dense, &e->dense_cap, nreq * (int64_t) sizeof(u64), errbuf, errlen))) return rc;
-              if ((rc = grow(&e->chunk_off, &e->chunk_off_cap, (int64_t) e->n_chunks * 4 + 4, errbuf, errlen))) return rc;
-              size_t tmp = 0;
-              HIPCHK(rocprim::exclusive_scan(nullptr, tmp, e->chunk_fill, e->chunk_off, 0u, (size_t) e->n_chunks,
-                                             rocprim::plus<uint32_t>(), e->stream));
-              if ((rc = grow((char **) &e->sort_tmp, &e->sort_tmp_cap, (int64_t) tmp + 16, errbuf, errlen))) return rc;
-              HIPCHK(rocprim::exclusive_scan(e->sort_tmp, tmp, e->chunk_fill, e->chunk_off, 0u, (size_t) e->n_chunks,
-                                             rocprim::plus<uint32_t>(), e->stream));
-              hipLaunchKernelGGL(kf_compact, dim3(e->n_chunks), dim3(F_TPB), 0, e->stream, e->req, e->chunk_fill,
-                                 e->chunk_off, 1, e->dense);
-              rc = apply_sorted(e, e->dense, nreq, 0, errbuf, errlen);
-            }
-          else rc = SMG_OK;
+  const bool keys_only = e->W == 1 && e->rw == 1;
+  const int64_t nreq = e->st.nrequests;
+  if (flat)
+    { if (nflat > 0) rc = keys_only ? apply_sorted(e, flat, nflat, 0, errbuf, errlen) : apply_indexed(e, flat, nflat, check_count, errbuf, errlen); }
+  else if (nreq > 0 && e->n_chunks > 0)
+    { const int64_t nslots = (int64_t) e->n_chunks * F_CH;
+      if (keys_only && nslots <= nreq + nreq / 8 && nslots >= SORT_MIN && e->kmer < 32)
+        { // nearly every chunk is full (pass 1 and the filter split their batches): sort the chunk array as it is,
+          // holes as sentinels behind the requests, instead of compacting it first
+          hipLaunchKernelGGL(kf_fill_holes, dim3(e->n_chunks), dim3(F_TPB), 0, e->stream, e->req, e->chunk_fill);
+          rc = apply_sorted(e, e->req, nslots, 1, errbuf, errlen);
         }
-      else rc = apply_sorted(e, flat, nflat, 0, errbuf, errlen);
-      if (rc) return rc;
-    }
-  else if (!flat && e->n_chunks > 0)
-    { // records with a count/flag word (W > 1, exact proof): compact the chunks, then index-sorted look-ups
-      const int64_t nreq = e->st.nrequests;
-      if (nreq > 0)
-        { const int rw = e->rw;
-          if ((rc = grow(&e->dense, &e->dense_cap, nreq * (int64_t) sizeof(u64) * rw, errbuf, errlen))) return rc;
-          if ((rc = grow(&e->chunk_off, &e->chunk_off_cap, (int64_t) e->n_chunks * 4 + 4, errbuf, errlen))) return rc;
-          size_t tmp = 0;
-          HIPCHK(rocprim::exclusive_scan(nullptr, tmp, e->chunk_fill, e->chunk_off, 0u, (size_t) e->n_chunks,
-                                         rocprim::plus<uint32_t>(), e->stream));
-          if ((rc = grow((char **) &e->sort_tmp, &e->sort_tmp_cap, (int64_t) tmp + 16, errbuf, errlen))) return rc;
-          HIPCHK(rocprim::exclusive_scan(e->sort_tmp, tmp, e->chunk_fill, e->chunk_off, 0u, (size_t) e->n_chunks,
-                                         rocprim::plus<uint32_t>(), e->stream));
-          hipLaunchKernelGGL(kf_compact, dim3(e->n_chunks), dim3(F_TPB), 0, e->stream, e->req, e->chunk_fill,
-                             e->chunk_off, rw, e->dense);
-          if ((rc = apply_indexed(e, e->dense, nreq, check_count, errbuf, errlen))) return rc;
+      else
+        { // ragged chunks, k = 32 (the all-T k-mer equals the sentinel) or records with a count/flag word
+          // (W > 1, exact proof): compact, then sorted (keys) or index-sorted (records) look-ups
+          if ((rc = compact_chunks(e, nreq, errbuf, errlen))) return rc;
+          rc = keys_only ? apply_sorted(e, e->dense, nreq, 0, errbuf, errlen) : apply_indexed(e, e->dense, nreq, check_count, errbuf, errlen);
         }
     }
-  else if (flat && nflat > 0)
-    { if ((rc = apply_indexed(e, flat, nflat, check_count, errbuf, errlen))) return rc; }
+  if (rc) return rc;
   hipEventRecord(e->ev[5], e->stream);
   HIPCHK(hipGetLastError());
   rc = read_ctrl(e, errbuf, errlen);
