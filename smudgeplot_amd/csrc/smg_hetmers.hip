@@ -768,7 +768,8 @@ static FastArgs make_fast(smg_engine *e)
 }
 
 static int bm_id_bits(int kmer);
-static bool filter_ok(const smg_engine *e) { return (e->W == 1 && e->rw == 1) || (e->W == 2 && e->rw == 3); }
+// (k = 1 has no prefix bases to name a block by)
+static bool filter_ok(const smg_engine *e) { return e->kmer >= 2 && ((e->W == 1 && e->rw == 1) || (e->W == 2 && e->rw == 3)); }
 
 static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, char *errbuf, size_t errlen)
 { int rc;
