@@ -436,10 +436,10 @@ kf_filter(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill, 
           __syncthreads();
           // append the survivors to the workgroup's output chunk, split so that chunks fill to the brim
           const unsigned qn = s_n;
+          const unsigned old_chunk = s_chunk, old_used = s_used;      // read by every thread BEFORE thread 0 moves them on
           __syncthreads();
           if (qn)
-            { const unsigned old_chunk = s_chunk, old_used = s_used;
-              const unsigned room = old_chunk == F_NOCHUNK ? 0u : F_CH - old_used;
+            { const unsigned room = old_chunk == F_NOCHUNK ? 0u : F_CH - old_used;
               const unsigned head = qn < room ? qn : room;
               if (t == 0)
                 { s_base = (u64) old_chunk * F_CH + old_used;
