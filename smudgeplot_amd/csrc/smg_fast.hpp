@@ -297,8 +297,10 @@ kf_pass1(FastArgs A, uint32_t *__restrict__ bstart, u64 *__restrict__ req,
 
 // index of the entry whose k-mer is y, or -1: directory bucket, bisection on the bucket's signatures, k-mer
 // comparison only among entries that share the signature.  A single matching signature is taken for the
-// complement (see kf_apply_sorted); without signatures (W = 3) the k-mers are bisected directly.
-template <int W> SMG_DEV int64_t sig_find(const FastArgs &A, const Key<W> &y)
+// complement ONLY when the closure of the table is proven by other means (the fingerprint of the hash proof, see
+// kf_apply_sorted); `verify` (the exact proof, where the look-up IS the proof) compares the k-mer of every hit.
+// Without signatures (W = 3) the k-mers are bisected directly.
+template <int W> SMG_DEV int64_t sig_find(const FastArgs &A, const Key<W> &y, bool verify)
 { if (A.sig == NULL) return find_key<W>(A.keys, A.dir, y);
   const Dir d = A.dir;
   const uint32_t hb = (uint32_t) (y.w[0] >> 32) >> d.dsh;
@@ -322,6 +324,7 @@ template <int W> SMG_DEV int64_t sig_find(const FastArgs &A, const Key<W> &y)
       j = lower_bound_key<W>(A.keys, j, e2, y);
       if (j >= e2 || !key_eq<W>(load_key<W>(A.keys, j), y)) return -1;
     }
+  else if (verify && !key_eq<W>(load_key<W>(A.keys, j), y)) return -1;
   return j;
 }
 
@@ -345,7 +348,7 @@ kf_apply(FastArgs A, const u64 *__restrict__ req, const uint32_t *__restrict__ c
 #pragma unroll
       for (int w = 0; w < W; w++) y.w[w] = q[w];
       const u64 meta = q[W];
-      const int64_t j = sig_find<W>(A, y);
+      const int64_t j = sig_find<W>(A, y, check_count != 0);
       bool bad = j < 0;
       if (!bad && check_count) bad = A.cnt[j] != (unsigned) (meta & 0xFFFF);
       if (bad) { if (ctl->missing == 0) ctl->missing = 1; continue; }
@@ -504,7 +507,7 @@ kf_apply_sorted(FastArgs A, const u64 *__restrict__ keys_sorted, int64_t nreq, i
 #pragma unroll
       for (int w = 0; w < W; w++) y.w[w] = keys_sorted[r * W + w];
       if (skip_sentinels && y.w[0] == ~0ull) continue;
-      const int64_t j = sig_find<W>(A, y);
+      const int64_t j = sig_find<W>(A, y, false);
       if (j < 0) { if (ctl->missing == 0) ctl->missing = 1; continue; }
       SET_P(A, j);
     }
@@ -532,7 +535,7 @@ kf_apply_indexed(FastArgs A, const u64 *__restrict__ rec, const uint32_t *__rest
 #pragma unroll
       for (int w = 0; w < W; w++) y.w[w] = q[w];
       const u64 meta = q[W];
-      const int64_t j = sig_find<W>(A, y);
+      const int64_t j = sig_find<W>(A, y, check_count != 0);
       bool bad = j < 0;
       if (!bad && check_count) bad = A.cnt[j] != (unsigned) (meta & 0xFFFF);
       if (bad) { if (ctl->missing == 0) ctl->missing = 1; continue; }

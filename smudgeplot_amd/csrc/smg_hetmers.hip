@@ -35,7 +35,7 @@
 #include "smg_hetmers.h"
 #include "smg_device.hpp"
 #include "smg_fast.hpp"
-#include "smg_pass1.hpp"
+#include "smg_pass1d.hpp"
 
 #define WIN_LIM   32          // window blocks up to this many entries are walked linearly
 #define TPB       256
@@ -420,6 +420,8 @@ struct smg_engine
   uint32_t    *route_cnt;  int64_t route_cnt_cap;
   u64         *route_off;  int64_t route_off_cap;
   u64         *partials;   // [P1_MAXGRID][4]
+  P1Cold      *p1cold;     // rarely used arguments of kf_pass1_d (device copy)
+  P1Cold      *h_p1cold;   // pinned staging
   u64         *d_split;
   Ctrl        *ctrl;
   Ctrl        *h_ctrl;        // pinned mirror
@@ -428,7 +430,7 @@ struct smg_engine
   Dir          dir;
   bool         prepared;      // pass 1 of the current table has run
   bool         fast;          // fast path in use
-  unsigned     p1_grid[2][3]; // resident workgroups of kf_pass1_r<W, RW, ..> by [W-1][RW-1] (0 = not asked yet)
+  unsigned     p1_grid[2][3]; // resident workgroups of kf_pass1_d<W, RW, ..> by [W-1][RW-1] (0 = not asked yet)
   unsigned     n_chunks;
   u64          fp[4];
   smg_stats    st;
@@ -479,7 +481,9 @@ extern "C" smg_engine *smg_engine_create(int device, void *stream, char *errbuf,
       || hipHostMalloc(&e->h_ctrl, sizeof(Ctrl)) != hipSuccess
       || hipMalloc(&e->partials, sizeof(u64) * 4 * P1_MAXGRID) != hipSuccess
       || hipHostMalloc(&e->h_partials, sizeof(u64) * 4 * P1_MAXGRID) != hipSuccess
-      || hipMalloc(&e->d_split, sizeof(u64) * 16 * 4) != hipSuccess)
+      || hipMalloc(&e->d_split, sizeof(u64) * 16 * 4) != hipSuccess
+      || hipMalloc(&e->p1cold, sizeof(P1Cold)) != hipSuccess
+      || hipHostMalloc(&e->h_p1cold, sizeof(P1Cold)) != hipSuccess)
     { fail(errbuf, errlen, SMG_ENOMEM, "cannot allocate the control block%s");
       delete e; return NULL;
     }
@@ -493,8 +497,8 @@ extern "C" void smg_engine_destroy(smg_engine *e)
   hipStreamSynchronize(e->stream);
   hipFree(e->own_keys); hipFree(e->own_cnt); hipFree(e->deg); hipFree(e->sig); hipFree(e->bstart);
   hipFree(e->req); hipFree(e->req2); hipFree(e->sort_tmp); hipFree(e->dense); hipFree(e->chunk_off); hipFree(e->skey[0]); hipFree(e->skey[1]); hipFree(e->sidx[0]); hipFree(e->sidx[1]); hipFree(e->biglist); hipFree(e->chunk_fill); hipFree(e->bmap); hipFree(e->reqf); hipFree(e->chunk_fillf); hipFree(e->route_cnt); hipFree(e->route_off);
-  hipFree(e->partials); hipFree(e->ctrl); hipFree(e->d_split);
-  hipHostFree(e->h_ctrl); hipHostFree(e->h_partials);
+  hipFree(e->partials); hipFree(e->ctrl); hipFree(e->d_split); hipFree(e->p1cold);
+  hipHostFree(e->h_ctrl); hipHostFree(e->h_partials); hipHostFree(e->h_p1cold);
   for (int i = 0; i < 10; i++) hipEventDestroy(e->ev[i]);
   delete e;
 }
@@ -788,7 +792,7 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
   e->filtered = false; e->presorted = 0;
   if (filter_ok(e) && !emit_all && !getenv("SMG_NO_FILTER"))
     { const int nbits = bm_id_bits(e->kmer);
-      const int64_t bytes = 4 * (((1ll << nbits) + 31) >> 5) + 4 * R_BMW + 64;
+      const int64_t bytes = 4 * (((1ll << nbits) + 31) >> 5) + 4 * D_BMW + 64;
       if ((rc = grow(&e->bmap, &e->bmap_cap, bytes, errbuf, errlen))) return rc;
       HIPCHK(hipMemsetAsync(e->bmap, 0, (size_t) bytes, e->stream));
       e->bm_bits = nbits;
@@ -801,8 +805,8 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
       memset(e->fp, 0, sizeof(e->fp));
       return SMG_OK;
     }
-  const bool narrow = e->W <= 2;                       // k <= 64: kf_pass1_r (blocked register scan)
-  const int64_t ntiles = narrow ? (e->n + R_OWN - 1) / R_OWN : (e->n + F_TILE - 1) / F_TILE;
+  const bool narrow = e->W <= 2;                       // k <= 64: kf_pass1_d (blocked register scan)
+  const int64_t ntiles = narrow ? (e->n + D_OWN - 1) / D_OWN : (e->n + F_TILE - 1) / F_TILE;
   GeoR gr;
   { const int p0 = e->kmer / 2, sbits = 2 * (e->kmer - p0);
     gr.k = e->kmer;
@@ -826,9 +830,9 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
         { int nb = 0, cus = 0;
           hipError_t he;
           // (the ODD / KF variants of one (W, RW) class use the same registers and LDS: ask for one of them)
-          if (e->W == 1 && e->rw == 1) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kf_pass1_r<1, 1, true, true>, R_TPB, 0);
-          else if (e->W == 1)          he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kf_pass1_r<1, 2, true, true>, R_TPB, 0);
-          else                         he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kf_pass1_r<2, 3, true, false>, R_TPB, 0);
+          if (e->W == 1 && e->rw == 1) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kf_pass1_d<1, 1, true, true>, D_TPB, 0);
+          else if (e->W == 1)          he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kf_pass1_d<1, 2, true, true>, D_TPB, 0);
+          else                         he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kf_pass1_d<2, 3, true, false>, D_TPB, 0);
           if (he != hipSuccess || nb < 1) nb = 3;
           if (nb > 8) nb = 8;
           if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || cus < 1) cus = 256;
@@ -857,9 +861,17 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
       hipEventRecord(e->ev[2], e->stream);
       if (narrow)
         {
-#define LAUNCH_R(W_, RW_, ODD_, KF_) hipLaunchKernelGGL((kf_pass1_r<W_, RW_, ODD_, KF_>), dim3(grid), dim3(R_TPB), 0, e->stream, a, gr, \
-                              e->bstart, e->req, e->chunk_fill, maxc, e->biglist, (unsigned) big_cap, emit_all, want_fp, \
-                              e->partials, &e->ctrl->fast, ntiles)
+          P1Hot hot;
+          hot.keys = a.keys; hot.cnt = a.cnt; hot.n = a.n; hot.code = a.code; hot.sig = a.sig; hot.bstart = e->bstart;
+          hot.bmap = a.bmap; hot.b0 = e->dir.b0; hot.nb = e->dir.nb; hot.shifts = (unsigned) e->dir.dsh | ((unsigned) a.sigsh << 6) | (((unsigned) a.bmsh & 31u) << 12)
+                       | ((emit_all ? 1u : 0u) << 18) | ((want_fp ? 1u : 0u) << 19);
+          hot.G = gr; hot.ntiles = ntiles;
+          e->h_p1cold->req = e->req; e->h_p1cold->chunk_fill = e->chunk_fill; e->h_p1cold->biglist = e->biglist;
+          e->h_p1cold->partials = e->partials; e->h_p1cold->ctl = &e->ctrl->fast; e->h_p1cold->max_chunks = maxc;
+          e->h_p1cold->big_cap = (unsigned) big_cap;
+          HIPCHK(hipMemcpyAsync(e->p1cold, e->h_p1cold, sizeof(P1Cold), hipMemcpyHostToDevice, e->stream));
+#define LAUNCH_R(W_, RW_, ODD_, KF_) hipLaunchKernelGGL((kf_pass1_d<W_, RW_, ODD_, KF_>), dim3(grid), dim3(D_TPB), 0, e->stream, hot, \
+                              (const P1Cold *) e->p1cold)
 #define LAUNCH_R2(RW_, ODD_) { if (kf) LAUNCH_R(1, RW_, ODD_, true); else LAUNCH_R(1, RW_, ODD_, false); }
           const bool kf = gr.pshift < 32 && gr.kshift < 32;          // 17 <= k <= 32
           if (e->W == 2)       { if (odd) LAUNCH_R(2, 3, true, false); else LAUNCH_R(2, 3, false, false); }
@@ -1007,8 +1019,11 @@ static int apply_indexed(smg_engine *e, const u64 *rec, int64_t n, int check_cou
 // block ids of the request filter = the leading bm_id_bits(k) bits of a k-mer (a function of k alone, so that the
 // maps of all the shards of a table line up): window blocks, coarsened to 2^30 ids (128 MB of bits) at most
 static int bm_id_bits(int kmer)
-{ int nbits = 2 * (kmer / 2);
-  if (nbits > 30) nbits = 30;
+{ int nbits = 2 * (kmer / 2), cap = 30;
+  { const char *v = getenv("SMG_BM_BITS");        // tuning: finer ids (<= 32: an id is a prefix of the leading 32 k-mer bits)
+    if (v && atoi(v) >= 8 && atoi(v) <= 32) { cap = atoi(v); if (nbits < cap) nbits = 2 * kmer < cap ? 2 * kmer : cap; }
+  }
+  if (nbits > cap) nbits = cap;
   return nbits;
 }
 

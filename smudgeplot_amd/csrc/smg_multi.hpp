@@ -101,6 +101,16 @@ static hipError_t multi_h2d_records(const smg_table_view *tv, int pbyte, int64_t
 static int decode_at(smg_engine *e, int kmer, int ibyte, int64_t nels, int64_t ibase, const uint8_t *d_records,
                      const int64_t *d_prefix_index, char *errbuf, size_t errlen);
 
+// Every rank takes part in a collective (or in the peer copies of the virtual mode) or none does: the failure flag is
+// read between two barriers, where nobody writes it, so all ranks see the same value.  (A rank that failed after
+// the previous barrier would otherwise skip its ncclSend/ncclRecv while its peers block in theirs for ever.)
+static bool multi_agree(MultiCtx *c)
+{ pthread_barrier_wait(&c->bar);
+  const bool ok = !c->failed;
+  pthread_barrier_wait(&c->bar);
+  return ok;
+}
+
 #define MFAIL(code, msg) do { c->rc[r] = fail(c->err[r], sizeof(c->err[r]), code, msg "%s"); c->failed = 1; } while (0)
 #define MOK (!c->failed)
 
@@ -217,7 +227,11 @@ static void *multi_worker(void *argp)
       for (int s = 0; s < n; s++) nrecv += c->counts[s][r];
       if (hipMalloc(&recv, sizeof(uint64_t) * (size_t) (nrecv > 0 ? nrecv : 1) * rw) != hipSuccess)
         MFAIL(SMG_ENOMEM, "out of device memory for the request exchange");
-      if (MOK && c->virt)
+    }
+  const bool go_exchange = multi_agree(c);                                               // B2: all in, or all out
+  if (go_exchange)
+    { const int rw = c->rw;
+      if (c->virt)
         { int64_t roff = 0;
           for (int s = 0; s < n && MOK; s++)
             { int64_t soff = 0;
@@ -229,7 +243,7 @@ static void *multi_worker(void *argp)
               roff += cnt;
             }
         }
-      else if (MOK)
+      else
         { ncclResult_t nr = c->api.GroupStart();
           int64_t soff = 0, roff = 0;
           for (int p = 0; p < n && nr == ncclSuccess; p++)
@@ -265,12 +279,13 @@ static void *multi_worker(void *argp)
                            "a multi-GPU run needs a conditioned table (use one GPU for this one)");
     }
   if (MOK && (c->rc[r] = smg_engine_pass2(e, d_plot, eb, el))) c->failed = 1;
-  if (MOK && c->virt)
+  const bool go_reduce = multi_agree(c);                                                 // C2: all in, or all out
+  if (go_reduce && c->virt)
     { c->h_plot[r] = (int64_t *) malloc(sizeof(int64_t) * SMG_PLOT_CELLS);
       if (!c->h_plot[r] || hipMemcpy(c->h_plot[r], d_plot, sizeof(int64_t) * SMG_PLOT_CELLS, hipMemcpyDeviceToHost) != hipSuccess)
         MFAIL(SMG_ENODEV, "device to host copy failed");
     }
-  else if (MOK)
+  else if (go_reduce)
     { const ncclResult_t nr = c->api.AllReduce(d_plot, d_plot, SMG_PLOT_CELLS, ncclInt64, ncclSum, c->comm[r], e->stream);
       if (nr != ncclSuccess || hipStreamSynchronize(e->stream) != hipSuccess)
         { c->rc[r] = fail(eb, el, SMG_ENODEV, "RCCL all-reduce of the histograms failed: %s",

@@ -1,0 +1,716 @@
+// smg_pass1d.hpp -- kf_pass1_d: pass 1 for k <= 64 (W = 1 or 2 64-bit words per k-mer); W = 1 is the headline kernel.
+//
+// Successor of kf_pass1_r (round 1, 222 vector instructions per table entry at 78 % of the VALU issue rate:
+// one wave64 integer VALU instruction per 4 cycles and SIMD, tools/valu_rates.hip).  The instruction count is
+// the only lever, so this version is built around three observations:
+//
+//   * LANE MASKS INSTEAD OF COUNTERS.  The result of a one-away test is one bit per lane = an SGPR pair.
+//     "entry e has a pair / has several pairs / has its pair on the self-mirrored position" are then scalar
+//     and/or chains over those masks -- SALU instructions, which issue beside the VALU ones -- and the hand-over
+//     of a result to the neighbouring lane (entry a of lane l pairs with entry b of lane l+1) is a scalar shift
+//     of the mask by one bit.  No credit words, no LDS atomics (7 per thread and tile, 4-way bank conflicted, in
+//     kf_pass1_r), no packed-counter arithmetic: a test costs 5 VALU instructions (was 12).
+//   * DPP INSTEAD OF REDUNDANT LOADS.  A thread owns 4 CONSECUTIVE entries and needs the next 3 for the
+//     distances 1..3: they are its right neighbour's registers (v_xor_b32_dpp wave_shl:1 -- folded into the
+//     test's xor, no extra instruction).  Lane 0 and lane 63 of every wave are halo lanes (they repeat the last /
+//     first scanned thread of the neighbouring wave), so nothing crosses a wave through memory: 62 x 4 entries
+//     per wave, 992 per tile, of which the first 32 repeat the previous tile's tail (far pairs across the seam).
+//   * THE EPILOGUE STAYS IN REGISTERS: the four entries of a thread are finished with straight-line code (code
+//     byte from a select chain over the masks, signature, directory, fingerprint, request), the requests of a
+//     wave get their queue slots from one LDS atomic per wave + mbcnt.
+//
+// Entries whose window block goes on past distance 3 (~6 % on the diploid table) are finished from an LDS copy
+// of the tile by a short tail loop (distances 4..30) that hands its (rare) hits over as packed counters in one
+// LDS word per entry; blocks longer than that go to kf_bigfix.
+//
+// The fingerprint mixer is two dependent 32x32->64 multiply-adds (v_mad_u64_u32 is full rate on gfx950) and one
+// ChaCha quarter round: same avalanche as the three quarter rounds it replaces (tests/test_mixer.py), 21
+// instead of 39 instructions.
+//
+// Semantics are those of kf_pass1_s / kf_pass1_r (smg_fast.hpp: code byte, request protocol), including the
+// relaxation that an entry with >= 2 pairs always sends a request.
+
+#pragma once
+#include "smg_fast.hpp"
+
+#define D_TPB    256
+#define D_WL     62                        // scanned lanes per wave (lanes 1..62; 0 and 63 are halo lanes)
+#define D_SCAN   (4 * 4 * D_WL)            // 992 scanned entries per tile
+#define D_HALO   32                        // the first 32 of them are owned by the previous tile
+#define D_OWN    (D_SCAN - D_HALO)         // 960
+#define D_SLOTS  (D_SCAN + 8)              // staged entries: scanned + the two outer halo threads
+#define D_LEAD   (D_HALO + 4)              // staged entries in front of the first owned one
+#define D_WIN    30                        // partners are searched within +-30 entries
+#define D_CRED   (D_SLOTS + 32)
+#define D_BIG    0x80000000u
+#ifndef D_BMF
+#define D_BMF    4096                      // block ids per tile with a bit in LDS (request filter)
+#endif
+#define D_BMW    (D_BMF / 32)
+#define D_QCAP   1280                      // LDS request queue (records); flushed when the next tile might not fit
+// nothing is scheduled across this point: keeps the live ranges of the lane masks (SGPR pairs) short -- the machine
+// scheduler otherwise hoists every test's compare to the front and the kernel spills scalars by the dozen
+#ifndef D_NOFENCE
+#define D_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define D_SCHED_FENCE()
+#endif
+#ifndef D_ABL
+#define D_ABL    0                         // ablation mask (timing experiments only; results are WRONG when non-zero):
+#endif                                     //   1 fingerprint, 2 directory, 4 signatures, 8 block map, 16 requests, 32 tail, 64 scan
+
+template <int W> struct DWord;
+template <> struct DWord<1> { typedef unsigned type; };
+template <> struct DWord<2> { typedef u64 type; };
+
+struct GeoR
+{ int  k;
+  int  pshift;       // W=1: pre = hi32 >> pshift (32 - 2*p0; 32 means "no prefix": k == 1);  W=2: pre = w0 >> pshift (64 - 2*p0)
+  int  kshift;       // W=1: 64 - 2k;  W=2: 128 - 2k  (the k-mer is left aligned in W words)
+  u64  smask;        // low 2*(k-p0) bits
+  int  mshift;       // odd k: suffix >> mshift != 0  <=> the top suffix base (position p0) differs
+};
+
+SMG_DEV int d_popc(unsigned v) { return __popc(v); }
+SMG_DEV int d_popc(u64 v) { return __popcll(v); }
+
+// value of the right neighbour lane (lane 63 reads 0)
+SMG_DEV unsigned d_next(unsigned v) { return (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, 0x130, 0xf, 0xf, false); }   // wave_shl:1
+SMG_DEV u64 d_next(u64 v) { return (u64) d_next((unsigned) v) | ((u64) d_next((unsigned) (v >> 32)) << 32); }
+
+SMG_DEV bool d_lane(u64 mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }       // scalar mask -> per-lane predicate, free
+
+template <int W, bool KF> SMG_DEV void
+d_unpack(const Key<W> &x, const GeoR &G, typename DWord<W>::type &pre, typename DWord<W>::type &suf)
+{ if constexpr (W == 1)
+    { const unsigned hi = (unsigned) (x.w[0] >> 32), lo = (unsigned) x.w[0];
+      if (KF)                               // 17 <= k <= 32: the k-mer straddles both 32-bit halves, no selects
+        { pre = hi >> G.pshift;
+          suf = __builtin_amdgcn_alignbit(hi, lo, G.kshift) & (unsigned) G.smask;
+        }
+      else
+        { pre = G.pshift < 32 ? hi >> G.pshift : 0u;
+          suf = (G.kshift >= 32 ? hi >> (G.kshift - 32) : __builtin_amdgcn_alignbit(hi, lo, G.kshift)) & (unsigned) G.smask;
+        }
+    }
+  else
+    { pre = x.w[0] >> G.pshift;                                     // pshift = 64 - 2*p0 in 0..32
+      suf = (G.kshift ? (x.w[1] >> G.kshift) | (x.w[0] << (64 - G.kshift)) : x.w[1]) & G.smask;
+    }
+}
+
+// 128-bit mixing of (k-mer, count): two dependent 32x32+64 multiply-adds, then one ChaCha quarter round over
+// (q, p ^ count).  Every input bit flips every output bit with probability 0.5 +- 0.01 (tests/test_mixer.py).
+SMG_DEV u64 d_mad(unsigned a, unsigned b, u64 c) { return (u64) a * (u64) b + c; }       // v_mad_u64_u32
+
+template <int W> SMG_DEV void mix_hash(const Key<W> &x, unsigned cnt, u64 &ha, u64 &hb)
+{ const unsigned lo = (unsigned) x.w[0], hi = (unsigned) (x.w[0] >> 32);
+  u64 p = d_mad(lo ^ 0x9E3779B9u, hi ^ 0x85EBCA6Bu, (u64) (cnt << 20));
+  if constexpr (W == 2)                     // absorb the second word
+    { const unsigned l1 = (unsigned) x.w[1], h1 = (unsigned) (x.w[1] >> 32);
+      p = d_mad(l1 ^ (unsigned) p ^ 0x165667B1u, h1 ^ (unsigned) (p >> 32) ^ 0xD3A2646Cu, p);
+    }
+  const unsigned pl = (unsigned) p, ph = (unsigned) (p >> 32);
+  const u64 q = d_mad(pl ^ hi, ph ^ lo ^ 0xC2B2AE35u, p);
+  unsigned a = (unsigned) q, b = (unsigned) (q >> 32), c = pl ^ cnt, d = ph;
+  arx_qr(a, b, c, d);
+  ha = (u64) a | ((u64) b << 32);
+  hb = (u64) c | ((u64) d << 32);
+}
+
+struct P1Hot                              // kernel argument: what every tile touches (stays in SGPRs)
+{ const u64      *keys;
+  const uint16_t *cnt;
+  int64_t         n;
+  uint8_t        *code;
+  uint16_t       *sig;           // sig[i] = (uint16_t) (keys[i] >> sigsh): the 16 k-mer bits below the directory's bucket bits
+  uint32_t       *bstart;        // bucket directory: bucket(x) = (hi32(x) >> dsh) - b0
+  uint32_t       *bmap;          // candidate block map (or NULL): bit (hi32(x) >> bmsh)
+  uint32_t        b0, nb;
+  unsigned        shifts;        // dsh | sigsh << 6 | bmsh << 12 | emit_all << 18 | want_fp << 19  (one register instead of five)
+  GeoR            G;
+  int64_t         ntiles;
+  SMG_DEV int dsh() const { return (int) (shifts & 63u); }
+  SMG_DEV int sigsh() const { return (int) ((shifts >> 6) & 63u); }
+  SMG_DEV int bmsh() const { return (int) ((shifts >> 12) & 31u); }
+  SMG_DEV bool emit_all() const { return (shifts >> 18 & 1u) != 0; }
+  SMG_DEV bool want_fp() const { return (shifts >> 19 & 1u) != 0; }
+};
+
+struct P1Cold                             // in device memory: what only a flush touches (kept out of the register file)
+{ u64      *req;
+  uint32_t *chunk_fill;
+  uint32_t *biglist;
+  u64      *partials;
+  FastCtl  *ctl;
+  unsigned  max_chunks, big_cap;
+};
+
+struct DShared                            // the workgroup's LDS arrays (pointers: the tile body is a function)
+{ unsigned *cred; uint16_t *tailq; u64 *ent; uint16_t *lcn; u64 *sq;
+  unsigned *s_tn, *s_qn, *s_nbig, *s_unsorted;
+  unsigned *bm;                          // candidate-block bits of this tile: D_BMW words (request filter)
+};
+
+// The 12 one-away tests of a thread (distances 1..3; entries 4..6 are the right neighbour's 0..2), aggregated on the
+// fly.  Straight-line code: every test is a handful of instructions whose result mask dies at once.
+template <typename WT, bool ODD, bool CHECK> SMG_DEV void
+d_tests(const WT (&sx)[7], const unsigned (&cn)[4], const u64 (&Sm)[7], const GeoR &G,
+        unsigned (&code)[4], unsigned (&npair)[4], u64 (&midM)[4])
+{ const WT AA = (WT) 0xAAAAAAAAAAAAAAAAull;
+  const WT TOPV = (WT) 1 << (ODD ? G.mshift : 0);
+  unsigned cx[7] = { cn[0], cn[1], cn[2], cn[3], 0, 0, 0 };
+  if (CHECK)
+    {
+#pragma unroll
+      for (int e = 0; e < 3; e++) cx[4 + e] = d_next(cn[e]);
+    }
+  u64 Tm[6];                               // odd k: the top suffix bases (the self-mirrored position) of e and e+1 differ
+  if (ODD)
+    {
+#pragma unroll
+      for (int e = 0; e < 4; e++) Tm[e] = __ballot((sx[e] ^ sx[e + 1]) >= TOPV);
+      Tm[4] = Tm[0] >> 1; Tm[5] = Tm[1] >> 1;
+    }
+#pragma unroll
+  for (int a = 3; a >= 0; a--)               // descending: the neighbour's masks (indices 4..6) die first
+    {
+#pragma unroll
+      for (int d = 1; d <= 3; d++)
+        { const int b = a + d, eb = b & 3;
+          const WT dd = sx[a] ^ sx[b];
+          const WT tt = ((dd << 1) | dd) & AA;
+          u64 h = __ballot(d_popc(tt) == 1);
+          h &= Sm[a];
+          if (d >= 2) h &= Sm[a + 1];
+          if (d >= 3) h &= Sm[a + 2];
+          if (CHECK) h &= __ballot(cx[a] + cx[b] <= SMG_SMAX);
+          const u64 hb = b < 4 ? h : h << 1;
+          npair[a] += d_lane(h) ? 1u : 0u;
+          npair[eb] += d_lane(hb) ? 1u : 0u;
+          if (ODD)
+            { u64 ms = Tm[a];
+              if (d >= 2) ms |= Tm[a + 1];
+              if (d >= 3) ms |= Tm[a + 2];
+              const u64 hm = h & ms;
+              midM[a] |= hm;
+              midM[eb] |= b < 4 ? hm : hm << 1;
+            }
+          const unsigned w2c = ODD ? 0u : (unsigned) CODE_W2;
+          code[a] = d_lane(h) ? ((unsigned) (31 + d) | w2c) : code[a];
+          code[eb] = d_lane(hb) ? ((unsigned) (31 - d) | w2c) : code[eb];
+          D_SCHED_FENCE();
+        }
+    }
+}
+
+// queue slots for the requests of a wave: E[e] = lanes whose entry e sends; one LDS atomic per wave
+template <int W, int RW> SMG_DEV void
+d_emit(const DShared &S, const u64 (&E)[4], const Key<W> (&rc)[4], const unsigned (&cn)[4], const u64 (&hiM)[4], int lane)
+{ const unsigned cnt_w = (unsigned) (__popcll(E[0]) + __popcll(E[1]) + __popcll(E[2]) + __popcll(E[3]));
+  if (cnt_w == 0) return;
+  unsigned base = 0;
+  if (lane == 0) base = atomicAdd(S.s_qn, cnt_w);
+  base = (unsigned) __builtin_amdgcn_readfirstlane((int) base);
+#pragma unroll
+  for (int e = 0; e < 4; e++)
+    { if (d_lane(E[e]))
+        { const unsigned q = __builtin_amdgcn_mbcnt_hi((unsigned) (E[e] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) E[e], base));
+#pragma unroll
+          for (int w = 0; w < W; w++) S.sq[q * RW + w] = rc[e].w[w];
+          if (RW > W) S.sq[q * RW + W] = (u64) cn[e] | (d_lane(hiM[e]) ? 1ull << 16 : 0ull);
+        }
+      base += (unsigned) __popcll(E[e]);
+    }
+}
+
+// code byte -> "owns a pair at p > k-1-p" (several pairs, or one that is not self-mirrored) / "exactly one pair";
+// CODE_DEFER (0xFF) is neither
+SMG_DEV bool d_code_hi(unsigned c) { return c - 63u < 65u; }                    // 63 .. 127
+SMG_DEV bool d_code_uq(unsigned c) { return ((c & 63u) - 1u) < 62u && c < 128u; }
+
+// One tile.  INNER tiles lie completely inside the table: vector loads, no bounds checks, no table-end cases.
+// RW = 64-bit words per request record: W (the complement k-mer) or W + 1 (+ count | has-hi-pair << 16).
+template <int W, int RW, bool ODD, bool KF, bool INNER> SMG_DEV void
+d_tile(const P1Hot &A, const DShared &S, int64_t g0, int t, u64 &fa, u64 &fb, unsigned &fneg, unsigned &bigmask)
+{ typedef typename DWord<W>::type WT;
+  constexpr bool D_BM = (W == 1 && RW == 1) || (W == 2 && RW == 3);     // variants that feed the request filter
+  const GeoR &G = A.G;
+  const int lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);       // the wave number is uniform: keep it scalar
+  const int slot0 = (wv * D_WL + lane) * 4;
+  const int64_t i0 = g0 + slot0;
+  const int64_t n = A.n;
+  const u64 scanM = 0x7FFFFFFFFFFFFFFEull;                   // lanes 1..62
+  const u64 ownM = wv == 0 ? scanM & ~((1ull << (D_LEAD / 4)) - 1ull) : scanM;
+  const bool owned = d_lane(ownM);
+  bigmask = 0;
+
+  // ---- loads ----------------------------------------------------------------------------------------------
+  //@mark D_LOAD
+  Key<W> kk[4]; unsigned cn[4];
+  unsigned vmask = 0xF;                    // entries i0 .. i0+3 inside the table?
+  if (INNER)
+    { if constexpr (W == 1)
+        { const ulonglong2 v0 = *reinterpret_cast<const ulonglong2 *>(A.keys + i0);
+          const ulonglong2 v1 = *reinterpret_cast<const ulonglong2 *>(A.keys + i0 + 2);
+          kk[0].w[0] = v0.x; kk[1].w[0] = v0.y; kk[2].w[0] = v1.x; kk[3].w[0] = v1.y;
+        }
+      else
+        {
+#pragma unroll
+          for (int e = 0; e < 4; e++) kk[e] = load_key<W>(A.keys, i0 + e);
+        }
+      const ushort4 v = *reinterpret_cast<const ushort4 *>(A.cnt + i0);
+      cn[0] = v.x; cn[1] = v.y; cn[2] = v.z; cn[3] = v.w;
+    }
+  else
+    { vmask = 0;
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        { const int64_t i = i0 + e;
+          const bool ok = i >= 0 && i < n;
+          vmask |= (unsigned) ok << e;
+          const Key<W> kx = load_key<W>(A.keys, ok ? i : 0);
+#pragma unroll
+          for (int w = 0; w < W; w++) kk[e].w[w] = ok ? kx.w[w] : 0ull;
+          cn[e] = ok ? (unsigned) A.cnt[i] : 0xFFFFu;
+        }
+    }
+  // LDS copy for the tail loop (halo lanes store what their twin in the neighbouring wave stores)
+  if constexpr (W == 1)
+    { ulonglong2 w0, w1;
+      w0.x = kk[0].w[0]; w0.y = kk[1].w[0]; w1.x = kk[2].w[0]; w1.y = kk[3].w[0];
+      *reinterpret_cast<ulonglong2 *>(&S.ent[slot0]) = w0;
+      *reinterpret_cast<ulonglong2 *>(&S.ent[slot0 + 2]) = w1;
+    }
+  else
+    {
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        { ulonglong2 v; v.x = kk[r].w[0]; v.y = kk[r].w[1];
+          *reinterpret_cast<ulonglong2 *>(&S.ent[(slot0 + r) * W]) = v;
+        }
+    }
+  *reinterpret_cast<ushort4 *>(&S.lcn[slot0]) = make_ushort4((unsigned short) cn[0], (unsigned short) cn[1],
+                                                           (unsigned short) cn[2], (unsigned short) cn[3]);
+
+  //@mark D_UNPACK
+  WT pre[4], sx[7];                        // sx[4..6]: the suffixes of the right neighbour's entries 0..2
+#pragma unroll
+  for (int e = 0; e < 4; e++) d_unpack<W, KF>(kk[e], G, pre[e], sx[e]);
+  const WT npre0 = d_next(pre[0]);
+#pragma unroll
+  for (int e = 0; e < 3; e++) sx[4 + e] = d_next(sx[e]);
+
+  // entry e exists (edge tiles only; V[4..6] are the neighbour's)
+  u64 V[7];
+  if (!INNER)
+    {
+#pragma unroll
+      for (int e = 0; e < 4; e++) V[e] = __ballot((vmask >> e) & 1u);
+      V[4] = V[0] >> 1; V[5] = V[1] >> 1; V[6] = V[2] >> 1;
+    }
+
+  // ---- order check + bucket directory (the first entry of every bucket stores its index) ------------------
+  //@mark D_DIR
+  D_SCHED_FENCE();
+  if (!(D_ABL & 2))
+    { Key<W> nk0;
+#pragma unroll
+      for (int w = 0; w < W; w++) nk0.w[w] = d_next(kk[0].w[w]);
+      const Key<W> nxt[4] = { kk[1], kk[2], kk[3], nk0 };
+      u64 bad = 0;
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        { u64 b = __ballot(!key_lt<W>(kk[e], nxt[e]));
+          if (!INNER) b &= V[e] & V[e + 1];
+          bad |= b;
+        }
+      if (bad & scanM) *S.s_unsorted = 1u;
+      // raw bucket numbers; the offset and the bound are applied on the (rare) store path only
+      uint32_t bq[5];
+#pragma unroll
+      for (int e = 0; e < 4; e++) bq[e] = (uint32_t) (kk[e].w[0] >> 32) >> A.dsh();
+      bq[4] = (uint32_t) (nk0.w[0] >> 32) >> A.dsh();
+      if (owned)
+        { if (!INNER && i0 == 0) A.bstart[0] = 0u;             // (the first bucket of the shard is bucket b0)
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+            { bool st = bq[e + 1] != bq[e];
+              if (!INNER) st = st && ((vmask >> e) & 1u) && i0 + e + 1 < n;
+              if (st)
+                { const uint32_t br = bq[e + 1] - A.b0;
+                  if (br < A.nb) A.bstart[br] = (uint32_t) (i0 + e + 1);
+                }
+              if (!INNER && ((vmask >> e) & 1u) && i0 + e + 1 == n) A.bstart[A.nb] = (uint32_t) n;
+            }
+        }
+    }
+
+  // ---- window-block structure as lane masks ---------------------------------------------------------------
+  //@mark D_MASKS
+  D_SCHED_FENCE();
+  // Sm[e]: entries e and e+1 share their first p0 bases (e = 4..6: the neighbour's 0..2)
+  u64 Sm[7];
+#pragma unroll
+  for (int e = 0; e < 3; e++) Sm[e] = __ballot(pre[e] == pre[e + 1]);
+  Sm[3] = __ballot(pre[3] == npre0);
+  if (!INNER)
+    {
+#pragma unroll
+      for (int e = 0; e < 4; e++) Sm[e] &= V[e] & V[e + 1];
+    }
+  Sm[4] = Sm[0] >> 1; Sm[5] = Sm[1] >> 1; Sm[6] = Sm[2] >> 1;
+
+  // entries whose block continues past distance 3: tail items (scanned lanes only)
+  if (!(D_ABL & 32))
+    { u64 Al[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) Al[e] = Sm[e] & Sm[e + 1] & Sm[e + 2] & Sm[e + 3] & scanM;
+      const u64 anyA = Al[0] | Al[1] | Al[2] | Al[3];
+      if (anyA)
+        { unsigned base = 0;
+          if (lane == 0) base = atomicAdd(S.s_tn, (unsigned) __popcll(anyA));
+          base = (unsigned) __builtin_amdgcn_readfirstlane((int) base);
+          if (d_lane(anyA))
+            { const unsigned m = (d_lane(Al[0]) ? 1u : 0u) | (d_lane(Al[1]) ? 2u : 0u) | (d_lane(Al[2]) ? 4u : 0u) | (d_lane(Al[3]) ? 8u : 0u);
+              const unsigned q = __builtin_amdgcn_mbcnt_hi((unsigned) (anyA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) anyA, base));
+              S.tailq[q] = (uint16_t) (t | (m << 8));
+            }
+        }
+    }
+
+  // ---- the 12 one-away tests of a thread (distances 1..3), aggregated on the fly -----------------------------
+  //@mark D_TESTS
+  D_SCHED_FENCE();
+  // per entry e of a lane: npair[e] pairs seen (a carry-in add per hit mask), code[e]: delta code of the last pair seen
+  // (the only one if the entry is unique), midM "has a pair on the self-mirrored position".  The b side of a test
+  // with b >= 4 is entry b - 4 of the right neighbour lane: the same mask, shifted up by one lane.
+  unsigned code[4] = { CODE_NONE, CODE_NONE, CODE_NONE, CODE_NONE };
+  unsigned npair[4] = { 0, 0, 0, 0 };
+  u64 midM[4] = { 0, 0, 0, 0 };
+  if (!(D_ABL & 64))
+    { unsigned mx = cn[0] > cn[1] ? cn[0] : cn[1];
+      { const unsigned m2 = cn[2] > cn[3] ? cn[2] : cn[3]; mx = mx > m2 ? mx : m2; }
+      // count sums can only exceed 1000 next to a count > 500: one wave-uniform branch, two straight-line variants
+      if (__ballot(mx > SMG_FMAX) == 0) d_tests<WT, ODD, false>(sx, cn, Sm, G, code, npair, midM);
+      else                             d_tests<WT, ODD, true>(sx, cn, Sm, G, code, npair, midM);
+    }
+  u64 uniqM[4], hiM[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++)
+    { const u64 mulM = __ballot(npair[e] >= 2u);
+      code[e] = d_lane(mulM) ? (unsigned) CODE_MULTI : code[e];
+      uniqM[e] = __ballot(npair[e] == 1u);
+      if (ODD)
+        { const u64 w2 = uniqM[e] & ~midM[e];
+          code[e] = d_lane(w2) ? (code[e] | (unsigned) CODE_W2) : code[e];
+          hiM[e] = mulM | w2;                          // owns a pair at p > k-1-p
+        }
+      else hiM[e] = mulM | uniqM[e];
+    }
+
+  // ---- request filter: a CANDIDATE (exactly one suffix-side pair) sets the bit of its block id -------------------
+  //@mark D_BMAP
+  D_SCHED_FENCE();
+  const int bmsh = A.bmsh();
+  // word 0 of the tile's LDS bit map = the map word of the tile's first owned entry (a uniform, scalar load)
+  const uint32_t bmbase = D_BM ? (((uint32_t) (A.keys[(g0 + D_LEAD) * W] >> 32) >> bmsh) & ~31u) : 0u;
+  if (D_BM && A.bmap && !(D_ABL & 8))
+    {
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        { u64 cm = uniqM[e] & ownM;
+          if (!INNER) cm &= V[e];
+          if (cm)
+            { const uint32_t id = (uint32_t) (kk[e].w[0] >> 32) >> bmsh;
+              const uint32_t rel = id - bmbase;
+              const u64 nearM = __ballot(rel < D_BMF) & cm;
+              if (d_lane(nearM)) atomicOr(&S.bm[rel >> 5], 1u << (rel & 31));
+              const u64 farM = cm & ~nearM;                                      // sparse table: outside the tile's LDS window
+              if (farM) { if (d_lane(farM)) atomicOr(&A.bmap[id >> 5], 1u << (id & 31)); }
+            }
+        }
+    }
+
+  // ---- complement, fingerprint, requests ---------------------------------------------------------------------------
+  //@mark D_RC
+  D_SCHED_FENCE();
+  { Key<W> rc[4];
+    if (!(D_ABL & 16) || A.want_fp())
+      {
+#pragma unroll
+        for (int e = 0; e < 4; e++) rc[e] = revcomp<W>(kk[e], G.k);
+      }
+    if (A.want_fp() && !(D_ABL & 1) && owned)
+      {
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          { const bool lt = key_lt<W>(kk[e], rc[e]);
+            const bool gt = ODD ? !lt : key_lt<W>(rc[e], kk[e]);   // odd k: no k-mer is its own complement
+            u64 ha, hb;
+            mix_hash<W>(lt ? kk[e] : rc[e], cn[e], ha, hb);
+            const u64 sg = gt ? ~0ull : 0ull;                    // -h == (h ^ ~0) + 1
+            if (ODD && INNER) { fa += ha ^ sg; fb += hb ^ sg; fneg += gt; }
+            else
+              { u64 keep = ~0ull;
+                if (!ODD) keep = (lt || gt) ? ~0ull : 0ull;      // self-complementary: no term
+                if (!INNER) keep = ((vmask >> e) & 1u) ? keep : 0ull;
+                fa += (ha ^ sg) & keep; fb += (hb ^ sg) & keep; fneg += (gt && keep) ? 1u : 0u;
+              }
+          }
+      }
+    //@mark D_EMIT
+  D_SCHED_FENCE();
+    // hash proof: rc(x) of every owned entry that owns a pair at p > k-1-p.  (The tail can only ADD pairs: an entry
+    // that gets its first hi-side pair there sends late, below.  The exact proof sends everything after the tail.)
+    if (!A.emit_all() && !(D_ABL & 16))
+      { u64 E[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) { E[e] = hiM[e] & ownM; if (!INNER) E[e] &= V[e]; }
+        d_emit<W, RW>(S, E, rc, cn, hiM, lane);
+      }
+  }
+
+  // ---- signatures ---------------------------------------------------------------------------------------------------
+  //@mark D_SIG
+  D_SCHED_FENCE();
+  if (W <= 2 && !(D_ABL & 4) && owned)
+    { unsigned sg[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        sg[e] = (unsigned) (kk[e].w[0] >> A.sigsh()) & 0xFFFFu;            // v_lshrrev_b64 is full rate
+      if (INNER || vmask == 0xF)
+        *reinterpret_cast<uint2 *>(A.sig + i0) = make_uint2(sg[0] | (sg[1] << 16), sg[2] | (sg[3] << 16));
+      else
+        for (int e = 0; e < 4; e++)
+          if (vmask >> e & 1) A.sig[i0 + e] = (uint16_t) sg[e];
+    }
+  unsigned codes = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
+  lds_barrier();
+
+  //@mark D_TAIL
+  // ---- tail: distances 4..30 from the LDS copy (global memory past the staged range); rare --------------------
+  { const unsigned tn = *S.s_tn;
+    for (unsigned q = (unsigned) t; q < tn; q += D_TPB)
+      { const unsigned item = S.tailq[q];
+        const int th = (int) (item & 0xFF);
+        const int ts = ((th >> 6) * D_WL + (th & 63)) * 4;
+        for (unsigned m = item >> 8; m; m &= m - 1)
+          { const int sa = ts + __ffs(m) - 1;
+            WT pa, sfa, pb, sfb;
+            d_unpack<W, KF>(lds_key<W>(S.ent, sa), G, pa, sfa);
+            const unsigned ca = S.lcn[sa];
+            for (int d = 4; d <= D_WIN + 1; d++)
+              { const int sb = sa + d;
+                unsigned cb;
+                if (!INNER && g0 + sb >= n) break;
+                if (sb < D_SLOTS) { d_unpack<W, KF>(lds_key<W>(S.ent, sb), G, pb, sfb); cb = S.lcn[sb]; }
+                else              { d_unpack<W, KF>(load_key<W>(A.keys, g0 + sb), G, pb, sfb); cb = A.cnt[g0 + sb]; }
+                if (pb != pa) break;
+                if (d > D_WIN) { atomicOr(&S.cred[sa], D_BIG); atomicOr(&S.cred[sb], D_BIG); break; }
+                const WT dd = sfa ^ sfb;
+                const WT tt = ((dd << 1) | dd) & (WT) 0xAAAAAAAAAAAAAAAAull;
+                if (d_popc(tt) == 1 && ca + cb <= SMG_SMAX)
+                  { // count 1 | delta code << 8 | mid << 24: with exactly one pair the delta field IS the code byte
+                    unsigned v = 1u | ((unsigned) (31 + d) << 8);
+                    if (ODD) v += (unsigned) (dd >> G.mshift) << 24;
+                    atomicAdd(&S.cred[sa], v);
+                    atomicAdd(&S.cred[sb], v - ((unsigned) (2 * d) << 8));
+                  }
+              }
+          }
+      }
+  }
+  lds_barrier();
+
+  // ---- merge the tail's hand-overs (rare: a wave-uniform branch per entry), store the code bytes ------------------
+  //@mark D_MERGE
+  D_SCHED_FENCE();
+  { const uint4 rv = *reinterpret_cast<const uint4 *>(&S.cred[slot0]);
+    const unsigned R[4] = { rv.x, rv.y, rv.z, rv.w };
+    u64 VL[4] = { ~0ull, ~0ull, ~0ull, ~0ull };
+    if (!INNER)
+      {
+#pragma unroll
+        for (int e = 0; e < 4; e++) VL[e] = __ballot((vmask >> e) & 1u);
+      }
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+      { const u64 tM = __ballot(R[e] != 0u) & ownM & VL[e];
+        if (tM)
+          { const bool touched = d_lane(tM);
+            const unsigned oc = (codes >> (8 * e)) & 0xFFu;
+            const unsigned cnt_t = R[e] & 0xFFu;
+            const bool big = (R[e] & D_BIG) != 0u;
+            const bool w2 = !ODD || ((R[e] >> 24) & 0x7Fu) == 0u;
+            unsigned nc = ((oc & 63u) != 0u || cnt_t >= 2u) ? (unsigned) CODE_MULTI
+                                                          : (((R[e] >> 8) & 0x7Fu) | (w2 ? (unsigned) CODE_W2 : 0u));
+            if (cnt_t == 0u) nc = oc;                                                // BIG flag only
+            if (big) nc = CODE_DEFER;
+            if (touched)
+              { codes = (codes & ~(0xFFu << (8 * e))) | (nc << (8 * e));
+                if (big) { bigmask |= 1u << e; atomicAdd(S.s_nbig, 1u); }
+                if (D_BM && A.bmap && d_code_uq(nc) && !d_code_uq(oc))              // a candidate only now
+                  { const uint32_t id = (uint32_t) (S.ent[(slot0 + e) * W] >> 32) >> bmsh;
+                    const uint32_t rel = id - bmbase;
+                    if (rel < D_BMF) atomicOr(&S.bm[rel >> 5], 1u << (rel & 31));
+                    else atomicOr(&A.bmap[id >> 5], 1u << (id & 31));
+                  }
+                if (!A.emit_all() && d_code_hi(nc) && !d_code_hi(oc) && !(D_ABL & 16))  // its first hi-side pair: send late
+                  { const Key<W> x = lds_key<W>(S.ent, slot0 + e);
+                    const Key<W> r = revcomp<W>(x, G.k);
+                    const unsigned q = atomicAdd(S.s_qn, 1u);
+#pragma unroll
+                    for (int w = 0; w < W; w++) S.sq[q * RW + w] = r.w[w];
+                    if (RW > W) S.sq[q * RW + W] = (u64) S.lcn[slot0 + e] | (1ull << 16);
+                  }
+              }
+          }
+      }
+    if (owned)
+      { if (INNER || vmask == 0xF) *reinterpret_cast<unsigned *>(A.code + i0) = codes;
+        else
+          for (int e = 0; e < 4; e++)
+            if (vmask >> e & 1) A.code[i0 + e] = (uint8_t) (codes >> (8 * e));
+      }
+    // exact proof: every owned entry sends (rc(x), count | hi << 16), with the final hi flag
+    if (A.emit_all() && !(D_ABL & 16))
+      { Key<W> rc[4]; unsigned c2[4]; u64 E[4], hM[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          { const unsigned ce = (codes >> (8 * e)) & 0xFFu;
+            rc[e] = revcomp<W>(lds_key<W>(S.ent, slot0 + e), G.k);
+            c2[e] = S.lcn[slot0 + e];
+            hM[e] = __ballot(d_code_hi(ce));
+            E[e] = ownM & VL[e] & ~__ballot(ce == (unsigned) CODE_DEFER);        // deferred entries send from kf_bigfix
+          }
+        d_emit<W, RW>(S, E, rc, c2, hM, lane);
+      }
+  }
+}
+
+#ifndef D_WAVES_PER_EU
+#define D_WAVES_PER_EU 6
+#endif
+
+template <int W, int RW, bool ODD, bool KF> __global__ void __launch_bounds__(D_TPB)
+__attribute__((amdgpu_waves_per_eu(W == 2 ? 3 : (RW == 1 ? D_WAVES_PER_EU : 5), W == 2 ? 3 : (RW == 1 ? D_WAVES_PER_EU : 5))))
+kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
+{ __shared__ unsigned cred[D_CRED];      // tail hand-overs per entry: count | delta code << 8 | mid << 24 | BIG
+  __shared__ uint16_t tailq[D_TPB];      // thread | alive mask << 8
+  __shared__ u64      ent[D_SLOTS * W];  // the staged k-mers
+  __shared__ uint16_t lcn[D_SLOTS];
+  __shared__ u64      sq[(RW == 1 ? D_QCAP : D_OWN) * RW];
+  __shared__ u64      sfp[D_TPB / 64][2];
+  constexpr bool D_BM = (W == 1 && RW == 1) || (W == 2 && RW == 3);
+  __shared__ unsigned bm[D_BM ? D_BMW : 1];
+  __shared__ unsigned s_tn, s_qn, s_nbig, s_unsorted, s_chunk, s_used, s_bigbase, s_bigcur;
+  __shared__ u64      s_base, s_total;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wv = t >> 6;
+  const int slot0 = (wv * D_WL + lane) * 4;
+  const int64_t n = A.n;
+  u64 fa = 0, fb = 0;                      // fingerprint: sum of (h ^ sign); the -1's are added at the end
+  unsigned fneg = 0;
+  DShared S;
+  S.cred = cred; S.tailq = tailq; S.ent = ent; S.lcn = lcn; S.sq = sq;
+  S.s_tn = &s_tn; S.s_qn = &s_qn; S.s_nbig = &s_nbig; S.s_unsorted = &s_unsorted;
+  S.bm = bm;
+  if (D_BM) for (int w = t; w < D_BMW; w += D_TPB) bm[w] = 0;
+  for (int s = t; s < D_CRED; s += D_TPB) cred[s] = 0;
+  if (t == 0) { s_chunk = F_NOCHUNK; s_used = 0; s_total = 0; s_tn = 0; s_qn = 0; s_nbig = 0; s_unsorted = 0; }
+  lds_barrier();
+
+  for (int64_t tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x)
+    { const int64_t g0 = tile * D_OWN - D_LEAD;
+      unsigned bigmask;
+      if (g0 >= 0 && g0 + D_SLOTS + 32 <= n)
+        d_tile<W, RW, ODD, KF, true>(A, S, g0, t, fa, fb, fneg, bigmask);
+      else
+        d_tile<W, RW, ODD, KF, false>(A, S, g0, t, fa, fb, fneg, bigmask);
+      lds_barrier();
+      //@mark D_FLUSH
+      if (D_BM && A.bmap)                           // candidate-block bits of this tile -> global map
+        for (int w = t; w < D_BMW; w += D_TPB)
+          { const unsigned v = bm[w];
+            if (v)
+              { atomicOr(&A.bmap[(((uint32_t) (ent[D_LEAD * W] >> 32) >> A.bmsh()) >> 5) + w], v);
+                bm[w] = 0;
+              }
+          }
+      // zero the hand-over words for the next tile (every thread its own four; the tail past the staged range)
+      *reinterpret_cast<uint4 *>(&cred[slot0]) = make_uint4(0, 0, 0, 0);
+      if (t < (D_CRED - D_SLOTS) / 4) *reinterpret_cast<uint4 *>(&cred[D_SLOTS + 4 * t]) = make_uint4(0, 0, 0, 0);
+
+      // ---- flush the request queue into this workgroup's chunk; publish deferred entries -----------------
+      // (RW == 1: only when the next tile might overflow the queue, or after this workgroup's last tile --
+      //  the barriers and the chunk bookkeeping of a flush cost as much as the copy itself)
+      const unsigned qn = s_qn;
+      const unsigned qcap = RW == 1 ? D_QCAP : D_OWN;
+      if (qn > 0 && (qn + D_OWN > qcap || tile + gridDim.x >= A.ntiles))
+        { // a batch that does not fit is SPLIT: its head fills the current chunk to the brim, the rest opens a new
+          // one -- every chunk but a workgroup's last is full, so the host can sort the chunk array as it is
+          // (holes filled with a sentinel) instead of compacting it first
+          const unsigned max_chunks = cold->max_chunks;
+          u64 *req = cold->req;
+          const unsigned old_chunk = s_chunk, old_used = s_used;
+          const unsigned room = old_chunk == F_NOCHUNK ? 0u : F_CH - old_used;
+          const unsigned head = qn < room ? qn : room;
+          lds_barrier();
+          if (t == 0)
+            { s_base = (u64) old_chunk * F_CH + old_used;          // only used when head > 0
+              if (qn > head)
+                { if (old_chunk != F_NOCHUNK && old_chunk < max_chunks) cold->chunk_fill[old_chunk] = F_CH;
+                  s_chunk = atomicAdd(&cold->ctl->n_chunks, 1u);
+                  s_used = qn - head;
+                }
+              else s_used = old_used + qn;
+              s_total += qn;
+              s_qn = 0;
+            }
+          lds_barrier();
+          if (head && old_chunk < max_chunks)
+            { u64 *o = req + s_base * RW;
+              for (unsigned e = t; e < head * RW; e += D_TPB) o[e] = sq[e];
+            }
+          if (qn > head && s_chunk < max_chunks)
+            { u64 *o = req + (u64) s_chunk * F_CH * RW;
+              for (unsigned e = t; e < (qn - head) * RW; e += D_TPB) o[e] = sq[head * RW + e];
+            }
+        }
+      const unsigned nb = s_nbig;
+      if (nb > 0)                                   // rare: list the deferred entries (the k-mer copy is free now)
+        { uint32_t *list = reinterpret_cast<uint32_t *>(ent);
+          lds_barrier();
+          if (t == 0) { s_bigbase = atomicAdd(&cold->ctl->nbig, nb); s_nbig = 0; s_bigcur = 0; }
+          lds_barrier();
+          for (unsigned m = bigmask; m; m &= m - 1)
+            list[atomicAdd(&s_bigcur, 1u)] = (uint32_t) (g0 + slot0 + __ffs(m) - 1);
+          lds_barrier();
+          for (unsigned e = t; e < nb; e += D_TPB)
+            if (s_bigbase + e < cold->big_cap) cold->biglist[s_bigbase + e] = list[e];
+        }
+      if (t == 0) s_tn = 0;
+      lds_barrier();
+    }
+
+  if (t == 0)
+    { if (s_chunk != F_NOCHUNK && s_chunk < cold->max_chunks) cold->chunk_fill[s_chunk] = s_used;
+      if (s_total) atomicAdd(&cold->ctl->nreq, s_total);
+      if (s_unsorted) cold->ctl->unsorted = 1;
+    }
+  if (A.want_fp())
+    { fa = wave_sum_u64(fa + (u64) fneg);
+      fb = wave_sum_u64(fb + (u64) fneg);
+      if ((t & 63) == 0) { sfp[t >> 6][0] = fa; sfp[t >> 6][1] = fb; }
+      lds_barrier();
+      if (t < 2)
+        { u64 s = 0;
+          for (int w2 = 0; w2 < D_TPB / 64; w2++) s += sfp[w2][t];
+          cold->partials[(size_t) blockIdx.x * 4 + t] = s;
+          cold->partials[(size_t) blockIdx.x * 4 + 2 + t] = 0;
+        }
+    }
+}

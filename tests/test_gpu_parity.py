@@ -498,9 +498,11 @@ def test_small_and_even_k_vs_oracle(k, m, seed):
         assert st["path"] == (2 if mode == "none" else 1)
 
 
-@pytest.mark.parametrize("n_target", [991, 992, 993, 1023, 1024, 1025, 1983, 1984, 1985, 2976 + 32, 4 * 992 + 1])
+@pytest.mark.parametrize("n_target", [959, 960, 961, 963, 964, 965, 991, 992, 993, 995, 996, 997, 1000, 1023, 1024, 1025, 1031, 1032,
+                                      1033, 1919, 1920, 1921, 1924, 1956, 2880 + 36, 4 * 960 + 1, 4 * 960 + 37])
 def test_table_sizes_around_the_pass1_tile(n_target):
-    """entry counts on and next to the tile edges of kf_pass1_r (992 owned + 32 halo entries)"""
+    """entry counts on and next to the tile edges of kf_pass1_d (960 owned entries per tile, scanned with 36 staged
+    entries in front and 4 behind; a tile is 'inner' when 1032 entries from its first staged one exist)"""
     k = 31
     keys, cnt = synth.diploid_table_u64(1500, k=k, seed=n_target, het_frac=0.5, cov=30, L=5)
     assert len(cnt) > n_target
