@@ -118,6 +118,24 @@ template <int W> SMG_DEV void mix_hash(const Key<W> &x, unsigned cnt, u64 &ha, u
   hb = (u64) c | ((u64) d << 32);
 }
 
+// the 4 entries of a thread, loaded one tile ahead
+template <int W> struct DPrefetch
+{ Key<W> k[4]; ushort4 c; bool valid;
+  SMG_DEV void load(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, int64_t i0)
+  { if constexpr (W == 1)
+      { const ulonglong2 v0 = *reinterpret_cast<const ulonglong2 *>(keys + i0);
+        const ulonglong2 v1 = *reinterpret_cast<const ulonglong2 *>(keys + i0 + 2);
+        k[0].w[0] = v0.x; k[1].w[0] = v0.y; k[2].w[0] = v1.x; k[3].w[0] = v1.y;
+      }
+    else
+      {
+#pragma unroll
+        for (int e = 0; e < 4; e++) k[e] = load_key<W>(keys, i0 + e);
+      }
+    c = *reinterpret_cast<const ushort4 *>(cnt + i0);
+  }
+};
+
 struct P1Hot                              // kernel argument: what every tile touches (stays in SGPRs)
 { const u64      *keys;
   const uint16_t *cnt;
@@ -158,20 +176,16 @@ template <typename WT, bool ODD, bool CHECK> SMG_DEV void
 d_tests(const WT (&sx)[7], const unsigned (&cn)[4], const u64 (&Sm)[7], const GeoR &G,
         unsigned (&code)[4], unsigned (&npair)[4], u64 (&midM)[4])
 { const WT AA = (WT) 0xAAAAAAAAAAAAAAAAull;
-  const WT TOPV = (WT) 1 << (ODD ? G.mshift : 0);
   unsigned cx[7] = { cn[0], cn[1], cn[2], cn[3], 0, 0, 0 };
   if (CHECK)
     {
 #pragma unroll
       for (int e = 0; e < 3; e++) cx[4 + e] = d_next(cn[e]);
     }
-  u64 Tm[6];                               // odd k: the top suffix bases (the self-mirrored position) of e and e+1 differ
-  if (ODD)
-    {
-#pragma unroll
-      for (int e = 0; e < 4; e++) Tm[e] = __ballot((sx[e] ^ sx[e + 1]) >= TOPV);
-      Tm[4] = Tm[0] >> 1; Tm[5] = Tm[1] >> 1;
-    }
+  // odd k: a pair sits on the self-mirrored position (the top suffix base) iff the one differing 2-bit group is the
+  // top one: tt >= TOPB (one more compare per test; keeping "top bases of e and e+1 differ" masks instead costs
+  // twelve more scalar registers than the kernel has)
+  const WT TOPB = (WT) 2 << (ODD ? G.mshift : 0);
 #pragma unroll
   for (int a = 3; a >= 0; a--)               // descending: the neighbour's masks (indices 4..6) die first
     {
@@ -189,10 +203,7 @@ d_tests(const WT (&sx)[7], const unsigned (&cn)[4], const u64 (&Sm)[7], const Ge
           npair[a] += d_lane(h) ? 1u : 0u;
           npair[eb] += d_lane(hb) ? 1u : 0u;
           if (ODD)
-            { u64 ms = Tm[a];
-              if (d >= 2) ms |= Tm[a + 1];
-              if (d >= 3) ms |= Tm[a + 2];
-              const u64 hm = h & ms;
+            { const u64 hm = h & __ballot(tt >= TOPB);
               midM[a] |= hm;
               midM[eb] |= b < 4 ? hm : hm << 1;
             }
@@ -232,7 +243,8 @@ SMG_DEV bool d_code_uq(unsigned c) { return ((c & 63u) - 1u) < 62u && c < 128u; 
 // One tile.  INNER tiles lie completely inside the table: vector loads, no bounds checks, no table-end cases.
 // RW = 64-bit words per request record: W (the complement k-mer) or W + 1 (+ count | has-hi-pair << 16).
 template <int W, int RW, bool ODD, bool KF, bool INNER> SMG_DEV void
-d_tile(const P1Hot &A, const DShared &S, int64_t g0, int t, u64 &fa, u64 &fb, unsigned &fneg, unsigned &bigmask)
+d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64 &fa, u64 &fb, unsigned &fneg,
+       unsigned &bigmask, DPrefetch<W> &pf)
 { typedef typename DWord<W>::type WT;
   constexpr bool D_BM = (W == 1 && RW == 1) || (W == 2 && RW == 3);     // variants that feed the request filter
   const GeoR &G = A.G;
@@ -250,18 +262,10 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int t, u64 &fa, u64 &fb, un
   Key<W> kk[4]; unsigned cn[4];
   unsigned vmask = 0xF;                    // entries i0 .. i0+3 inside the table?
   if (INNER)
-    { if constexpr (W == 1)
-        { const ulonglong2 v0 = *reinterpret_cast<const ulonglong2 *>(A.keys + i0);
-          const ulonglong2 v1 = *reinterpret_cast<const ulonglong2 *>(A.keys + i0 + 2);
-          kk[0].w[0] = v0.x; kk[1].w[0] = v0.y; kk[2].w[0] = v1.x; kk[3].w[0] = v1.y;
-        }
-      else
-        {
+    { if (!pf.valid) pf.load(A.keys, A.cnt, i0);        // (the first tile of a workgroup, or the one after an edge tile)
 #pragma unroll
-          for (int e = 0; e < 4; e++) kk[e] = load_key<W>(A.keys, i0 + e);
-        }
-      const ushort4 v = *reinterpret_cast<const ushort4 *>(A.cnt + i0);
-      cn[0] = v.x; cn[1] = v.y; cn[2] = v.z; cn[3] = v.w;
+      for (int e = 0; e < 4; e++) kk[e] = pf.k[e];
+      cn[0] = pf.c.x; cn[1] = pf.c.y; cn[2] = pf.c.z; cn[3] = pf.c.w;
     }
   else
     { vmask = 0;
@@ -347,6 +351,26 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int t, u64 &fa, u64 &fb, un
         }
     }
 
+  // ---- signatures ---------------------------------------------------------------------------------------------------
+  //@mark D_SIG
+  D_SCHED_FENCE();
+  if (W <= 2 && !(D_ABL & 4) && owned)
+    { unsigned sg[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        sg[e] = (unsigned) (kk[e].w[0] >> A.sigsh()) & 0xFFFFu;            // v_lshrrev_b64 is full rate
+      if (INNER || vmask == 0xF)
+        *reinterpret_cast<uint2 *>(A.sig + i0) = make_uint2(sg[0] | (sg[1] << 16), sg[2] | (sg[3] << 16));
+      else
+        for (int e = 0; e < 4; e++)
+          if (vmask >> e & 1) A.sig[i0 + e] = (uint16_t) sg[e];
+    }
+  // block ids for the request filter (the k-mers themselves are not needed past this point)
+  const int bmsh = A.bmsh();
+  uint32_t idv[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) idv[e] = (uint32_t) (kk[e].w[0] >> 32) >> bmsh;
+
   // ---- window-block structure as lane masks ---------------------------------------------------------------
   //@mark D_MASKS
   D_SCHED_FENCE();
@@ -367,18 +391,28 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int t, u64 &fa, u64 &fb, un
     { u64 Al[4];
 #pragma unroll
       for (int e = 0; e < 4; e++) Al[e] = Sm[e] & Sm[e + 1] & Sm[e + 2] & Sm[e + 3] & scanM;
-      const u64 anyA = Al[0] | Al[1] | Al[2] | Al[3];
-      if (anyA)
+      // one queue entry per ENTRY (its slot), so that the tail runs with every lane busy: a wave pays for the whole
+      // tail body whenever one of its lanes has work
+      const unsigned na = (unsigned) (__popcll(Al[0]) + __popcll(Al[1]) + __popcll(Al[2]) + __popcll(Al[3]));
+      if (na)
         { unsigned base = 0;
-          if (lane == 0) base = atomicAdd(S.s_tn, (unsigned) __popcll(anyA));
+          if (lane == 0) base = atomicAdd(S.s_tn, na);
           base = (unsigned) __builtin_amdgcn_readfirstlane((int) base);
-          if (d_lane(anyA))
-            { const unsigned m = (d_lane(Al[0]) ? 1u : 0u) | (d_lane(Al[1]) ? 2u : 0u) | (d_lane(Al[2]) ? 4u : 0u) | (d_lane(Al[3]) ? 8u : 0u);
-              const unsigned q = __builtin_amdgcn_mbcnt_hi((unsigned) (anyA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) anyA, base));
-              S.tailq[q] = (uint16_t) (t | (m << 8));
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+            { if (d_lane(Al[e]))
+                { const unsigned q = __builtin_amdgcn_mbcnt_hi((unsigned) (Al[e] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) Al[e], base));
+                  S.tailq[q] = (uint16_t) (slot0 + e);
+                }
+              base += (unsigned) __popcll(Al[e]);
             }
         }
     }
+
+  // The staged copy and the tail queue are complete for every wave from here on.  The tail itself runs at the END of
+  // this phase, without a barrier of its own: between two barriers every wave has the same long stretch of work (tests,
+  // fingerprints, requests) plus its share of the tail items, instead of three waves idling while one walks the queue.
+  lds_barrier();
 
   // ---- the 12 one-away tests of a thread (distances 1..3), aggregated on the fly -----------------------------
   //@mark D_TESTS
@@ -413,7 +447,6 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int t, u64 &fa, u64 &fb, un
   // ---- request filter: a CANDIDATE (exactly one suffix-side pair) sets the bit of its block id -------------------
   //@mark D_BMAP
   D_SCHED_FENCE();
-  const int bmsh = A.bmsh();
   // word 0 of the tile's LDS bit map = the map word of the tile's first owned entry (a uniform, scalar load)
   const uint32_t bmbase = D_BM ? (((uint32_t) (A.keys[(g0 + D_LEAD) * W] >> 32) >> bmsh) & ~31u) : 0u;
   if (D_BM && A.bmap && !(D_ABL & 8))
@@ -423,7 +456,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int t, u64 &fa, u64 &fb, un
         { u64 cm = uniqM[e] & ownM;
           if (!INNER) cm &= V[e];
           if (cm)
-            { const uint32_t id = (uint32_t) (kk[e].w[0] >> 32) >> bmsh;
+            { const uint32_t id = idv[e];
               const uint32_t rel = id - bmbase;
               const u64 nearM = __ballot(rel < D_BMF) & cm;
               if (d_lane(nearM)) atomicOr(&S.bm[rel >> 5], 1u << (rel & 31));
@@ -434,90 +467,114 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int t, u64 &fa, u64 &fb, un
     }
 
   // ---- complement, fingerprint, requests ---------------------------------------------------------------------------
+  unsigned codes = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
+
+  // ---- complement, fingerprint, requests: one entry at a time from the thread's own LDS copy ----------------------
+  // (a rolled loop: the four entries interleaved need ~30 more vector registers than the kernel has at six waves
+  //  per SIMD; the masks rotate through one register pair)
   //@mark D_RC
   D_SCHED_FENCE();
-  { Key<W> rc[4];
-    if (!(D_ABL & 16) || A.want_fp())
-      {
-#pragma unroll
-        for (int e = 0; e < 4; e++) rc[e] = revcomp<W>(kk[e], G.k);
-      }
-    if (A.want_fp() && !(D_ABL & 1) && owned)
-      {
-#pragma unroll
-        for (int e = 0; e < 4; e++)
-          { const bool lt = key_lt<W>(kk[e], rc[e]);
-            const bool gt = ODD ? !lt : key_lt<W>(rc[e], kk[e]);   // odd k: no k-mer is its own complement
-            u64 ha, hb;
-            mix_hash<W>(lt ? kk[e] : rc[e], cn[e], ha, hb);
-            const u64 sg = gt ? ~0ull : 0ull;                    // -h == (h ^ ~0) + 1
-            if (ODD && INNER) { fa += ha ^ sg; fb += hb ^ sg; fneg += gt; }
-            else
-              { u64 keep = ~0ull;
-                if (!ODD) keep = (lt || gt) ? ~0ull : 0ull;      // self-complementary: no term
-                if (!INNER) keep = ((vmask >> e) & 1u) ? keep : 0ull;
-                fa += (ha ^ sg) & keep; fb += (hb ^ sg) & keep; fneg += (gt && keep) ? 1u : 0u;
-              }
-          }
-      }
-    //@mark D_EMIT
-  D_SCHED_FENCE();
-    // hash proof: rc(x) of every owned entry that owns a pair at p > k-1-p.  (The tail can only ADD pairs: an entry
-    // that gets its first hi-side pair there sends late, below.  The exact proof sends everything after the tail.)
-    if (!A.emit_all() && !(D_ABL & 16))
-      { u64 E[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) { E[e] = hiM[e] & ownM; if (!INNER) E[e] &= V[e]; }
-        d_emit<W, RW>(S, E, rc, cn, hiM, lane);
-      }
-  }
-
-  // ---- signatures ---------------------------------------------------------------------------------------------------
-  //@mark D_SIG
-  D_SCHED_FENCE();
-  if (W <= 2 && !(D_ABL & 4) && owned)
-    { unsigned sg[4];
-#pragma unroll
+  if (!(D_ABL & 16) || A.want_fp())
+    { // hash proof: rc(x) of every owned entry that owns a pair at p > k-1-p.  (The tail can only ADD pairs: an entry
+      // that gets its first hi-side pair there sends late, below.  The exact proof sends everything after the tail.)
+      u64 E0 = 0, E1 = 0, E2 = 0, E3 = 0;
+      if (!A.emit_all() && !(D_ABL & 16))
+        { E0 = hiM[0] & ownM; E1 = hiM[1] & ownM; E2 = hiM[2] & ownM; E3 = hiM[3] & ownM;
+          if (!INNER) { E0 &= V[0]; E1 &= V[1]; E2 &= V[2]; E3 &= V[3]; }
+        }
+      const unsigned cnt_w = (unsigned) (__popcll(E0) + __popcll(E1) + __popcll(E2) + __popcll(E3));
+      unsigned base = 0;
+      if (cnt_w)
+        { if (lane == 0) base = atomicAdd(S.s_qn, cnt_w);
+          base = (unsigned) __builtin_amdgcn_readfirstlane((int) base);
+        }
+      const bool fp = A.want_fp() && !(D_ABL & 1);
+#pragma unroll 1
       for (int e = 0; e < 4; e++)
-        sg[e] = (unsigned) (kk[e].w[0] >> A.sigsh()) & 0xFFFFu;            // v_lshrrev_b64 is full rate
-      if (INNER || vmask == 0xF)
-        *reinterpret_cast<uint2 *>(A.sig + i0) = make_uint2(sg[0] | (sg[1] << 16), sg[2] | (sg[3] << 16));
-      else
-        for (int e = 0; e < 4; e++)
-          if (vmask >> e & 1) A.sig[i0 + e] = (uint16_t) sg[e];
+        { const Key<W> x = lds_key<W>(S.ent, slot0 + e);
+          const unsigned c = S.lcn[slot0 + e];
+          const Key<W> rc = revcomp<W>(x, G.k);
+          if (fp && owned)
+            { const bool lt = key_lt<W>(x, rc);
+              const bool gt = ODD ? !lt : key_lt<W>(rc, x);          // odd k: no k-mer is its own complement
+              u64 ha, hb;
+              mix_hash<W>(lt ? x : rc, c, ha, hb);
+              const u64 sg = gt ? ~0ull : 0ull;                      // -h == (h ^ ~0) + 1
+              if (ODD && INNER) { fa += ha ^ sg; fb += hb ^ sg; fneg += gt; }
+              else
+                { u64 keep = ~0ull;
+                  if (!ODD) keep = (lt || gt) ? ~0ull : 0ull;        // self-complementary: no term
+                  if (!INNER) keep = ((vmask >> e) & 1u) ? keep : 0ull;
+                  fa += (ha ^ sg) & keep; fb += (hb ^ sg) & keep; fneg += (gt && keep) ? 1u : 0u;
+                }
+            }
+          //@mark D_EMIT
+          if (E0)
+            { if (d_lane(E0))
+                { const unsigned q = __builtin_amdgcn_mbcnt_hi((unsigned) (E0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) E0, base));
+#pragma unroll
+                  for (int w = 0; w < W; w++) S.sq[q * RW + w] = rc.w[w];
+                  if (RW > W) S.sq[q * RW + W] = (u64) c | (1ull << 16);     // (hash proof: only hi entries send)
+                }
+              base += (unsigned) __popcll(E0);
+            }
+          const u64 r0 = E0; E0 = E1; E1 = E2; E2 = E3; E3 = r0;
+        }
     }
-  unsigned codes = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
-  lds_barrier();
+  // the next tile's entries: issued here, used after the flush -- the latency of the loads (a few thousand cycles on a
+  // busy chip) disappears behind the tail, the merge and the barriers instead of stalling the head of the next tile
+  pf.valid = false;
+  if (g0_next >= 0) { pf.load(A.keys, A.cnt, g0_next + slot0); pf.valid = true; }
 
   //@mark D_TAIL
   // ---- tail: distances 4..30 from the LDS copy (global memory past the staged range); rare --------------------
+  // One lane per queued entry, the partners at distances 4..7 fetched in ONE batch (a loop that walked the partners
+  // one LDS round trip at a time cost 5.6 of 19.4 ms; four sparsely filled waves instead of one or two dense ones 3).
   { const unsigned tn = *S.s_tn;
-    for (unsigned q = (unsigned) t; q < tn; q += D_TPB)
-      { const unsigned item = S.tailq[q];
-        const int th = (int) (item & 0xFF);
-        const int ts = ((th >> 6) * D_WL + (th & 63)) * 4;
-        for (unsigned m = item >> 8; m; m &= m - 1)
-          { const int sa = ts + __ffs(m) - 1;
-            WT pa, sfa, pb, sfb;
-            d_unpack<W, KF>(lds_key<W>(S.ent, sa), G, pa, sfa);
-            const unsigned ca = S.lcn[sa];
-            for (int d = 4; d <= D_WIN + 1; d++)
-              { const int sb = sa + d;
-                unsigned cb;
-                if (!INNER && g0 + sb >= n) break;
-                if (sb < D_SLOTS) { d_unpack<W, KF>(lds_key<W>(S.ent, sb), G, pb, sfb); cb = S.lcn[sb]; }
-                else              { d_unpack<W, KF>(load_key<W>(A.keys, g0 + sb), G, pb, sfb); cb = A.cnt[g0 + sb]; }
-                if (pb != pa) break;
-                if (d > D_WIN) { atomicOr(&S.cred[sa], D_BIG); atomicOr(&S.cred[sb], D_BIG); break; }
+    for (unsigned q = (unsigned) t; q < tn && !(D_ABL & 512); q += D_TPB)
+      { const int sa = (int) S.tailq[q];
+        WT pa, sfa;
+        d_unpack<W, KF>(lds_key<W>(S.ent, sa), G, pa, sfa);
+        const unsigned ca = S.lcn[sa];
+        int d = 4;
+        if (sa + 7 < D_SLOTS)                   // the usual case: distances 4..7 are staged
+          { Key<W> kb[4]; unsigned cb[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { kb[j] = lds_key<W>(S.ent, sa + 4 + j); cb[j] = S.lcn[sa + 4 + j]; }
+            bool same = true;                   // (the entry at distance 4 shares the prefix: that is why sa is queued)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+              { WT pb, sfb;
+                d_unpack<W, KF>(kb[j], G, pb, sfb);
+                same = same && pb == pa && (INNER || g0 + sa + 4 + j < n);
                 const WT dd = sfa ^ sfb;
                 const WT tt = ((dd << 1) | dd) & (WT) 0xAAAAAAAAAAAAAAAAull;
-                if (d_popc(tt) == 1 && ca + cb <= SMG_SMAX)
-                  { // count 1 | delta code << 8 | mid << 24: with exactly one pair the delta field IS the code byte
-                    unsigned v = 1u | ((unsigned) (31 + d) << 8);
+                if (same && d_popc(tt) == 1 && ca + cb[j] <= SMG_SMAX)
+                  { unsigned v = 1u | ((unsigned) (31 + 4 + j) << 8);
                     if (ODD) v += (unsigned) (dd >> G.mshift) << 24;
                     atomicAdd(&S.cred[sa], v);
-                    atomicAdd(&S.cred[sb], v - ((unsigned) (2 * d) << 8));
+                    atomicAdd(&S.cred[sa + 4 + j], v - ((unsigned) (2 * (4 + j)) << 8));
                   }
+              }
+            if (!same || (D_ABL & 256)) continue;
+            d = 8;
+          }
+        for (; d <= D_WIN + 1; d++)             // longer blocks, and entries next to the end of the staged range
+          { const int sb = sa + d;
+            WT pb, sfb; unsigned cb;
+            if (!INNER && g0 + sb >= n) break;
+            if (sb < D_SLOTS) { d_unpack<W, KF>(lds_key<W>(S.ent, sb), G, pb, sfb); cb = S.lcn[sb]; }
+            else              { d_unpack<W, KF>(load_key<W>(A.keys, g0 + sb), G, pb, sfb); cb = A.cnt[g0 + sb]; }
+            if (pb != pa) break;
+            if (d > D_WIN) { atomicOr(&S.cred[sa], D_BIG); atomicOr(&S.cred[sb], D_BIG); break; }
+            const WT dd = sfa ^ sfb;
+            const WT tt = ((dd << 1) | dd) & (WT) 0xAAAAAAAAAAAAAAAAull;
+            if (d_popc(tt) == 1 && ca + cb <= SMG_SMAX)
+              { // count 1 | delta code << 8 | mid << 24: with exactly one pair the delta field IS the code byte
+                unsigned v = 1u | ((unsigned) (31 + d) << 8);
+                if (ODD) v += (unsigned) (dd >> G.mshift) << 24;
+                atomicAdd(&S.cred[sa], v);
+                atomicAdd(&S.cred[sb], v - ((unsigned) (2 * d) << 8));
               }
           }
       }
@@ -591,14 +648,14 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int t, u64 &fa, u64 &fb, un
 }
 
 #ifndef D_WAVES_PER_EU
-#define D_WAVES_PER_EU 6
+#define D_WAVES_PER_EU 5
 #endif
 
 template <int W, int RW, bool ODD, bool KF> __global__ void __launch_bounds__(D_TPB)
 __attribute__((amdgpu_waves_per_eu(W == 2 ? 3 : (RW == 1 ? D_WAVES_PER_EU : 5), W == 2 ? 3 : (RW == 1 ? D_WAVES_PER_EU : 5))))
 kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
 { __shared__ unsigned cred[D_CRED];      // tail hand-overs per entry: count | delta code << 8 | mid << 24 | BIG
-  __shared__ uint16_t tailq[D_TPB];      // thread | alive mask << 8
+  __shared__ uint16_t tailq[D_SCAN];     // slots of the entries whose window block goes on past distance 3
   __shared__ u64      ent[D_SLOTS * W];  // the staged k-mers
   __shared__ uint16_t lcn[D_SLOTS];
   __shared__ u64      sq[(RW == 1 ? D_QCAP : D_OWN) * RW];
@@ -623,13 +680,18 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
   if (t == 0) { s_chunk = F_NOCHUNK; s_used = 0; s_total = 0; s_tn = 0; s_qn = 0; s_nbig = 0; s_unsorted = 0; }
   lds_barrier();
 
+  DPrefetch<W> pf;
+  pf.valid = false;
   for (int64_t tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x)
     { const int64_t g0 = tile * D_OWN - D_LEAD;
+      // the tile after this one, if it is an inner tile too (-1: none, or an edge tile, which loads for itself)
+      int64_t g0n = g0 + (int64_t) gridDim.x * D_OWN;
+      if (tile + gridDim.x >= A.ntiles || g0n + D_SLOTS + 32 > n) g0n = -1;
       unsigned bigmask;
       if (g0 >= 0 && g0 + D_SLOTS + 32 <= n)
-        d_tile<W, RW, ODD, KF, true>(A, S, g0, t, fa, fb, fneg, bigmask);
+        d_tile<W, RW, ODD, KF, true>(A, S, g0, g0n, t, fa, fb, fneg, bigmask, pf);
       else
-        d_tile<W, RW, ODD, KF, false>(A, S, g0, t, fa, fb, fneg, bigmask);
+        d_tile<W, RW, ODD, KF, false>(A, S, g0, g0n, t, fa, fb, fneg, bigmask, pf);
       lds_barrier();
       //@mark D_FLUSH
       if (D_BM && A.bmap)                           // candidate-block bits of this tile -> global map
