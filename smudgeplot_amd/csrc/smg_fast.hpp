@@ -771,14 +771,14 @@ kf_extract(FastArgs A, const uint16_t *__restrict__ labels, u64 *__restrict__ ou
 __global__ void __launch_bounds__(1024) kf_plot_sum(const u64 *__restrict__ plot, u64 *__restrict__ out)
 { __shared__ u64 part[16];
   u64 s = 0;
-  for (int c = threadIdx.x; c < SMG_PLOT_CELLS; c += 1024) s += plot[c];
+  for (int c = blockIdx.x * 1024 + threadIdx.x; c < SMG_PLOT_CELLS; c += gridDim.x * 1024) s += plot[c];
   s = wave_sum_u64(s);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0)
     { u64 tot = 0;
       for (int w = 0; w < 16; w++) tot += part[w];
-      *out = tot;
+      if (tot) atomicAdd(out, tot);                    // (*out is zeroed by the host; a few dozen workgroups)
     }
 }
 
@@ -837,7 +837,8 @@ kf_route_scatter(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk
 // One chunk per workgroup iteration batch, same chunk list as pass 1.
 template <int W, int RW> __global__ void __launch_bounds__(F_TPB)
 kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, unsigned nbig, u64 *__restrict__ req,
-          uint32_t *__restrict__ chunk_fill, unsigned max_chunks, FastCtl *__restrict__ ctl)
+          uint32_t *__restrict__ chunk_fill, unsigned max_chunks, FastCtl *__restrict__ ctl,
+          unsigned *__restrict__ ghist, int hbits)
 { constexpr int rw = RW;
   __shared__ u64      sq[F_TPB * RW];
   __shared__ unsigned s_qn, s_chunk, s_used;
@@ -864,6 +865,7 @@ kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, unsigned nbig, u64 *
 #pragma unroll
               for (int w = 0; w < W; w++) sq[q * rw + w] = rc.w[w];
               if (rw > W) sq[q * rw + W] = (u64) A.cnt[i] | (1ull << 16);
+              if (ghist && hbits) atomicAdd(&ghist[(unsigned) (rc.w[0] >> 32) >> (32 - hbits)], 1u);    // (rare path)
             }
         }
       __syncthreads();

@@ -36,6 +36,7 @@
 #include "smg_device.hpp"
 #include "smg_fast.hpp"
 #include "smg_pass1d.hpp"
+#include "smg_lookup.hpp"
 
 #define WIN_LIM   32          // window blocks up to this many entries are walked linearly
 #define TPB       256
@@ -420,6 +421,10 @@ struct smg_engine
   uint32_t    *route_cnt;  int64_t route_cnt_cap;
   u64         *route_off;  int64_t route_off_cap;
   u64         *partials;   // [P1_MAXGRID][4]
+  unsigned    *ghist;      // look-up chain: requests per bucket [L_BK], bucket cursor `bnext` behind it
+  u64         *boff;       //   bucket offsets [L_BK + 1] and scatter cursors [L_BK] behind them
+  LookupGeo    lg;         //   geometry of the current run (lg.nb = 0: the round-1 chain is used)
+  int          bm_cap;     //   id bits of the block map: 32 on one GPU, 30 when the maps of several shards are exchanged
   P1Cold      *p1cold;     // rarely used arguments of kf_pass1_d (device copy)
   P1Cold      *h_p1cold;   // pinned staging
   u64         *d_split;
@@ -477,12 +482,15 @@ extern "C" smg_engine *smg_engine_create(int device, void *stream, char *errbuf,
   memset(e, 0, sizeof(*e));
   e->device = device;
   e->stream = (hipStream_t) stream;
+  e->bm_cap = 30;
   if (hipMalloc(&e->ctrl, sizeof(Ctrl)) != hipSuccess
       || hipHostMalloc(&e->h_ctrl, sizeof(Ctrl)) != hipSuccess
       || hipMalloc(&e->partials, sizeof(u64) * 4 * P1_MAXGRID) != hipSuccess
       || hipHostMalloc(&e->h_partials, sizeof(u64) * 4 * P1_MAXGRID) != hipSuccess
       || hipMalloc(&e->d_split, sizeof(u64) * 16 * 4) != hipSuccess
       || hipMalloc(&e->p1cold, sizeof(P1Cold)) != hipSuccess
+      || hipMalloc(&e->ghist, sizeof(unsigned) * (L_BK + 4)) != hipSuccess
+      || hipMalloc(&e->boff, sizeof(u64) * (2 * L_BK + 4)) != hipSuccess
       || hipHostMalloc(&e->h_p1cold, sizeof(P1Cold)) != hipSuccess)
     { fail(errbuf, errlen, SMG_ENOMEM, "cannot allocate the control block%s");
       delete e; return NULL;
@@ -497,7 +505,7 @@ extern "C" void smg_engine_destroy(smg_engine *e)
   hipStreamSynchronize(e->stream);
   hipFree(e->own_keys); hipFree(e->own_cnt); hipFree(e->deg); hipFree(e->sig); hipFree(e->bstart);
   hipFree(e->req); hipFree(e->req2); hipFree(e->sort_tmp); hipFree(e->dense); hipFree(e->chunk_off); hipFree(e->skey[0]); hipFree(e->skey[1]); hipFree(e->sidx[0]); hipFree(e->sidx[1]); hipFree(e->biglist); hipFree(e->chunk_fill); hipFree(e->bmap); hipFree(e->reqf); hipFree(e->chunk_fillf); hipFree(e->route_cnt); hipFree(e->route_off);
-  hipFree(e->partials); hipFree(e->ctrl); hipFree(e->d_split); hipFree(e->p1cold);
+  hipFree(e->partials); hipFree(e->ctrl); hipFree(e->d_split); hipFree(e->p1cold); hipFree(e->ghist); hipFree(e->boff);
   hipHostFree(e->h_ctrl); hipHostFree(e->h_partials); hipHostFree(e->h_p1cold);
   for (int i = 0; i < 10; i++) hipEventDestroy(e->ev[i]);
   delete e;
@@ -644,7 +652,8 @@ static int counted_prepare(smg_engine *e, char *errbuf, size_t errlen)
 }
 
 static int plot_sum(smg_engine *e, int64_t *d_plot, char *errbuf, size_t errlen)
-{ hipLaunchKernelGGL(kf_plot_sum, dim3(1), dim3(1024), 0, e->stream, (const u64 *) d_plot, &e->ctrl->plot_sum);
+{ HIPCHK(hipMemsetAsync(&e->ctrl->plot_sum, 0, sizeof(u64), e->stream));
+  hipLaunchKernelGGL(kf_plot_sum, dim3(64), dim3(1024), 0, e->stream, (const u64 *) d_plot, &e->ctrl->plot_sum);
   int rc = read_ctrl(e, errbuf, errlen);
   if (rc) return rc;
   e->st.npairs = (int64_t) e->h_ctrl->plot_sum;
@@ -771,7 +780,7 @@ static FastArgs make_fast(smg_engine *e)
   return a;
 }
 
-static int bm_id_bits(int kmer);
+static int bm_id_bits(int kmer, int cap);
 // (k = 1 has no prefix bases to name a block by)
 static bool filter_ok(const smg_engine *e) { return e->kmer >= 2 && ((e->W == 1 && e->rw == 1) || (e->W == 2 && e->rw == 3)); }
 
@@ -791,12 +800,15 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
   e->bm_bits = 0;
   e->filtered = false; e->presorted = 0;
   if (filter_ok(e) && !emit_all && !getenv("SMG_NO_FILTER"))
-    { const int nbits = bm_id_bits(e->kmer);
+    { const int nbits = bm_id_bits(e->kmer, e->bm_cap);
       const int64_t bytes = 4 * (((1ll << nbits) + 31) >> 5) + 4 * D_BMW + 64;
       if ((rc = grow(&e->bmap, &e->bmap_cap, bytes, errbuf, errlen))) return rc;
       HIPCHK(hipMemsetAsync(e->bmap, 0, (size_t) bytes, e->stream));
       e->bm_bits = nbits;
     }
+  // the look-up chain of smg_lookup.hpp: one-word k-mers, key-only records, a map of >= 12 id bits
+  e->lg.nb = 0;
+  if (e->bm_bits >= 12 && e->W == 1 && e->rw == 1 && !getenv("SMG_OLD_LOOKUP")) e->lg = lookup_geo(e->bm_bits);
   if (e->n > 0)
     HIPCHK(hipMemsetAsync(e->bstart, 0xFF, sizeof(uint32_t) * ((size_t) e->dir.nb + 2), e->stream));
   if (e->n == 0)
@@ -858,16 +870,17 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
       e->max_chunks = maxc;
       if ((rc = grow(&e->biglist, &e->biglist_cap, big_cap * 4, errbuf, errlen))) return rc;
       FastArgs a = make_fast(e);
+      if (e->lg.nb) HIPCHK(hipMemsetAsync(e->ghist, 0, sizeof(unsigned) * (L_BK + 4), e->stream));
       hipEventRecord(e->ev[2], e->stream);
       if (narrow)
         {
           P1Hot hot;
           hot.keys = a.keys; hot.cnt = a.cnt; hot.n = a.n; hot.code = a.code; hot.sig = a.sig; hot.bstart = e->bstart;
           hot.bmap = a.bmap; hot.b0 = e->dir.b0; hot.nb = e->dir.nb; hot.shifts = (unsigned) e->dir.dsh | ((unsigned) a.sigsh << 6) | (((unsigned) a.bmsh & 31u) << 12)
-                       | ((emit_all ? 1u : 0u) << 18) | ((want_fp ? 1u : 0u) << 19);
+                       | ((emit_all ? 1u : 0u) << 18) | ((want_fp ? 1u : 0u) << 19) | ((unsigned) e->lg.nb << 20);
           hot.G = gr; hot.ntiles = ntiles;
           e->h_p1cold->req = e->req; e->h_p1cold->chunk_fill = e->chunk_fill; e->h_p1cold->biglist = e->biglist;
-          e->h_p1cold->partials = e->partials; e->h_p1cold->ctl = &e->ctrl->fast; e->h_p1cold->max_chunks = maxc;
+          e->h_p1cold->partials = e->partials; e->h_p1cold->ctl = &e->ctrl->fast; e->h_p1cold->max_chunks = maxc; e->h_p1cold->ghist = e->ghist;
           e->h_p1cold->big_cap = (unsigned) big_cap;
           HIPCHK(hipMemcpyAsync(e->p1cold, e->h_p1cold, sizeof(P1Cold), hipMemcpyHostToDevice, e->stream));
 #define LAUNCH_R(W_, RW_, ODD_, KF_) hipLaunchKernelGGL((kf_pass1_d<W_, RW_, ODD_, KF_>), dim3(grid), dim3(D_TPB), 0, e->stream, hot, \
@@ -912,7 +925,7 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
           unsigned fb = (nbig + F_TPB - 1) / F_TPB;
           if (fb > 256) fb = 256;
 #define BIGFIX(W_, RW_) hipLaunchKernelGGL((kf_bigfix<W_, RW_>), dim3(fb), dim3(F_TPB), 0, e->stream, a, e->biglist, nbig, e->req, \
-                              e->chunk_fill, maxc, &e->ctrl->fast)
+                              e->chunk_fill, maxc, &e->ctrl->fast, e->lg.nb ? e->ghist : (unsigned *) NULL, e->lg.nb)
           if (e->W == 2) BIGFIX(2, 3); else if (e->rw == 1) BIGFIX(1, 1); else BIGFIX(1, 2);
 #undef BIGFIX
           hipEventRecord(e->ev[3], e->stream);
@@ -1018,11 +1031,12 @@ static int apply_indexed(smg_engine *e, const u64 *rec, int64_t n, int check_cou
 
 // block ids of the request filter = the leading bm_id_bits(k) bits of a k-mer (a function of k alone, so that the
 // maps of all the shards of a table line up): window blocks, coarsened to 2^30 ids (128 MB of bits) at most
-static int bm_id_bits(int kmer)
-{ int nbits = 2 * (kmer / 2), cap = 30;
-  { const char *v = getenv("SMG_BM_BITS");        // tuning: finer ids (<= 32: an id is a prefix of the leading 32 k-mer bits)
-    if (v && atoi(v) >= 8 && atoi(v) <= 32) { cap = atoi(v); if (nbits < cap) nbits = 2 * kmer < cap ? 2 * kmer : cap; }
-  }
+// cap: 30 when the maps of several shards are exchanged (128 MB in total), 32 on one GPU, where the probes of the
+// first 30 bits are LDS reads (smg_lookup.hpp) and a finer map only costs its memset; SMG_BM_BITS overrides (8..32).
+// An id never runs past the k-mer (2k bits) nor past its leading 32 bits.
+static int bm_id_bits(int kmer, int cap)
+{ { const char *v = getenv("SMG_BM_BITS"); if (v && atoi(v) >= 8 && atoi(v) <= 32) cap = atoi(v); }
+  int nbits = cap > 30 ? 2 * kmer : 2 * (kmer / 2);
   if (nbits > cap) nbits = cap;
   return nbits;
 }
@@ -1034,6 +1048,24 @@ static int bm_id_bits(int kmer)
 static int filter_presort(smg_engine *e, char *errbuf, size_t errlen)
 { int rc;
   hipEventRecord(e->ev[4], e->stream);                      // start of the filter's time
+  if (e->lg.nb)
+    { // smg_lookup.hpp: bucket offsets from pass 1's histogram, one-pass partition into the dense array req2
+      const int64_t nreq = e->st.nrequests;
+      if ((rc = grow(&e->req2, &e->req2_cap, (nreq > 0 ? nreq : 1) * (int64_t) sizeof(u64), errbuf, errlen))) return rc;
+      const int nbk = 1 << e->lg.nb;
+      hipLaunchKernelGGL(kl_scan, dim3(1), dim3(L_BK), 0, e->stream, e->ghist, nbk, e->boff, e->boff + L_BK + 2, e->ghist + L_BK);
+      unsigned grid = 512;
+      { int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) == hipSuccess && cus > 0) grid = 2u * (unsigned) cus;
+      }
+      const unsigned nbatch = (e->n_chunks + PT_CH - 1) / PT_CH;
+      if (grid > nbatch) grid = nbatch;
+      if (grid) hipLaunchKernelGGL(kl_part, dim3(grid), dim3(PT_TPB), 0, e->stream, e->req, e->chunk_fill, e->n_chunks, e->lg.nb,
+                                   e->boff + L_BK + 2, e->req2);
+      HIPCHK(hipGetLastError());
+      e->presorted = 3;
+      return SMG_OK;
+    }
   e->presorted = 2;
   const int64_t nslots = (int64_t) e->n_chunks * F_CH;
   int64_t sort_min = 1 << 22;               // below this the probes are too few to matter
@@ -1049,13 +1081,32 @@ static int filter_presort(smg_engine *e, char *errbuf, size_t errlen)
   return SMG_OK;
 }
 
+// smg_lookup.hpp: filter the partitioned requests against `map`; list = false: look the survivors up at once
+static int lookup_probe(smg_engine *e, const uint32_t *map, bool list, unsigned maxout, char *errbuf, size_t errlen)
+{ unsigned grid = 256;
+  { int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) == hipSuccess && cus > 0) grid = (unsigned) cus;
+  }
+  const unsigned nbk = 1u << e->lg.nb;
+  if (grid > nbk) grid = nbk;
+  FastArgs a = make_fast(e);
+  if (list)
+    hipLaunchKernelGGL(kl_probe<true>, dim3(grid), dim3(PB_TPB), 0, e->stream, a, (const u64 *) e->req2, (const u64 *) e->boff, map, e->lg,
+                       e->ghist + L_BK, e->reqf, e->chunk_fillf, maxout, &e->ctrl->fast);
+  else
+    hipLaunchKernelGGL(kl_probe<false>, dim3(grid), dim3(PB_TPB), 0, e->stream, a, (const u64 *) e->req2, (const u64 *) e->boff, map, e->lg,
+                       e->ghist + L_BK, (u64 *) NULL, (uint32_t *) NULL, 0u, &e->ctrl->fast);
+  HIPCHK(hipGetLastError());
+  return SMG_OK;
+}
+
 // drop the requests whose target window block holds no candidate (kf_filter); map = NULL: this engine's own map
 static int fast_filter(smg_engine *e, const uint32_t *map, char *errbuf, size_t errlen)
 { int rc;
   if (!filter_ok(e) || e->n_chunks == 0) return SMG_OK;
   if (!map) map = e->bm_bits ? e->bmap : NULL;
   if (!map) return SMG_OK;
-  const int nbits = bm_id_bits(e->kmer);
+  const int nbits = bm_id_bits(e->kmer, e->bm_cap);
   // two workgroups per CU, chunks dealt round-robin: the chunks in flight then span one or two of the 256 sorted
   // buckets, i.e. <= 1 MB of the map (measured: 512 workgroups 3.0 ms, 256 / 1024 / 2048 workgroups 3.4-3.7 ms)
   unsigned grid = 512;
@@ -1064,7 +1115,8 @@ static int fast_filter(smg_engine *e, const uint32_t *map, char *errbuf, size_t 
     const char *v = getenv("SMG_FILTER_GRID"); if (v && atoi(v) > 0) grid = (unsigned) atoi(v);
   }
   if (grid > e->n_chunks) grid = e->n_chunks;
-  const unsigned maxout = e->n_chunks + grid + 16;
+  unsigned maxout = e->n_chunks + grid + 16;
+  if (e->lg.nb) maxout = e->n_chunks + 256 * PB_WAVES + 16;          // kl_probe: every wave fills chunks of its own
   // (the two chunk lists swap roles after every filter: keep them the same size, or pass 1 would reallocate)
   { int64_t want = (int64_t) maxout * F_CH * (int64_t) sizeof(u64) * e->rw, wantf = (int64_t) maxout * 4 + 4;
     if (want < e->req_cap) want = e->req_cap;
@@ -1074,7 +1126,9 @@ static int fast_filter(smg_engine *e, const uint32_t *map, char *errbuf, size_t 
   }
   if (!e->presorted && (rc = filter_presort(e, errbuf, errlen))) return rc;
   const int64_t nslots = (int64_t) e->n_chunks * F_CH;
-  if (e->presorted == 1)
+  if (e->presorted == 3)
+    { if ((rc = lookup_probe(e, map, true, maxout, errbuf, errlen))) return rc; }
+  else if (e->presorted == 1)
     hipLaunchKernelGGL(kf_filter<1>, dim3(grid), dim3(F_TPB), 0, e->stream, e->req2, (const uint32_t *) NULL, e->n_chunks, nslots,
                        map, 64 - nbits, e->reqf, e->chunk_fillf, maxout, &e->ctrl->fast);
   else if (e->rw == 1)
@@ -1120,6 +1174,24 @@ static int compact_chunks(smg_engine *e, int64_t nreq, char *errbuf, size_t errl
 static int fast_apply(smg_engine *e, const u64 *flat, int64_t nflat, int check_count, int64_t *missing,
                       char *errbuf, size_t errlen)
 { int rc = SMG_OK;
+  if (!flat && e->lg.nb && e->bm_bits && !e->filtered && !getenv("SMG_LOOKUP_SPLIT"))
+    { // own requests, own map: partition, then filter and look-ups in one kernel (no survivor list, no sort)
+      if (e->n_chunks == 0 || e->st.nrequests == 0) { if (missing) *missing = 0; return SMG_OK; }
+      if (!e->presorted && (rc = filter_presort(e, errbuf, errlen))) return rc;
+      hipEvent_t mid = e->ev[6];                                  // (free until pass 2)
+      hipEventRecord(mid, e->stream);
+      if ((rc = lookup_probe(e, e->bmap, false, 0u, errbuf, errlen))) return rc;
+      hipEventRecord(e->ev[5], e->stream);
+      if ((rc = read_ctrl(e, errbuf, errlen))) return rc;
+      float ms = 0;
+      hipEventElapsedTime(&ms, e->ev[4], mid); e->st.ms_filter = ms;       // scan + partition
+      hipEventElapsedTime(&ms, e->ev[4], e->ev[5]); e->st.ms_rclookup += ms;
+      e->st.nrequests = (int64_t) e->h_ctrl->fast.nf_req;
+      e->filtered = true;
+      e->n_chunks = 0;                                            // nothing left to route or to look up
+      if (missing) *missing = e->h_ctrl->fast.missing;
+      return SMG_OK;
+    }
   if (!flat && e->bm_bits && !e->filtered && (rc = fast_filter(e, NULL, errbuf, errlen))) return rc;
   hipEventRecord(e->ev[4], e->stream);
   const bool keys_only = e->W == 1 && e->rw == 1;
@@ -1184,6 +1256,7 @@ extern "C" int smg_engine_pass1(smg_engine *e, int symcheck, char *errbuf, size_
 { NEED_FAST(e)
   HIPCHK(hipSetDevice(e->device));
   e->st.ms_rclookup = 0;
+  e->bm_cap = 30;                            // the maps of the shards are exchanged: 128 MB in total
   return fast_pass1(e, symcheck == SMG_SYM_EXACT, symcheck == SMG_SYM_EXACT, symcheck == SMG_SYM_HASH, errbuf, errlen);
 }
 
@@ -1325,6 +1398,7 @@ extern "C" int smg_engine_run(smg_engine *e, int symcheck, int64_t *d_plot, smg_
       // exact: EVERY entry sends (rc(kmer), count) and the look-up compares the count -- the same records the
       //        sharded protocol exchanges, index-sorted look-ups (kf_apply_indexed)
       const int exact = symcheck == SMG_SYM_EXACT;
+      e->bm_cap = 32;
       rc = fast_pass1(e, exact, exact, symcheck == SMG_SYM_HASH, errbuf, errlen);
       if (rc) return rc;
       int64_t missing = 0;

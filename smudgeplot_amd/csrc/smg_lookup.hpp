@@ -1,0 +1,256 @@
+// smg_lookup.hpp -- the look-up chain of the hash proof for one-word k-mers (k <= 32): requests -> P flags.
+//
+// Round 1: sentinel fill, rocPRIM Onesweep histogram + scatter on the leading 8 bits (3.5 ms on the 1 Gbp table),
+// kf_filter probing the block map through the L2s (3.0), Onesweep on 24 bits of the survivors (1.1), in-order look-ups
+// (1.75): 9.3 ms for 4.4e8 requests.  Now three kernels:
+//
+//   kl_scan   bucket offsets from the histogram that PASS 1 keeps of its requests (leading NB <= 10 bits of rc(x):
+//             one LDS add per request there, which replaces a 1.5 ms pass over the 3.5 GB request list);
+//   kl_part   one pass partition of the chunk list into a dense, bucket-ordered array: 8192 records staged in LDS,
+//             one global atomic per non-empty (batch, bucket), records scattered in 64-byte runs; no sentinels;
+//   kl_probe  one 1024-thread workgroup per CU takes whole buckets.  The part of the block map that a bucket can hit
+//             is folded 4:1 into 128 KB of LDS (a "coarse" bit = four neighbouring block ids), so the first test of
+//             every request is an LDS read (the 128-512 MB map itself is read exactly once, as a stream); the ~20 %
+//             that pass probe the full-resolution map in global memory, and the ~6 % that pass that too are queued in
+//             LDS and looked up in batches of up to 1024 with every lane busy (directory bucket, bisection on the
+//             signatures, P flag) -- inside their bucket, i.e. inside 1/1024 of the table, without being sorted first.
+//             In a sharded run the same kernel appends the survivors to a chunk list instead (they have to travel).
+//
+// The map resolution went from 30 to 32 id bits (5.7 % instead of 20 % of the requests survive) once the filter no
+// longer had to keep the map words of the resident workgroups inside the L2s.
+
+#pragma once
+#include "smg_fast.hpp"
+
+#define L_NB_MAX   10                      // request buckets: leading NB bits of the target k-mer
+#define L_BK       (1 << L_NB_MAX)
+#define L_SLICE_LG 20                      // coarse map bits per bucket in LDS (128 KB)
+
+struct LookupGeo
+{ int fb;          // id bits of the block map: bit (key >> (64 - fb))
+  int cb;          // coarse ids: fb - 2 bits
+  int nb;          // bucket bits: 1 .. 10, cb - nb <= 20
+};
+
+static inline LookupGeo lookup_geo(int fb)
+{ LookupGeo g;
+  g.fb = fb; g.cb = fb - 2;
+  g.nb = g.cb - L_SLICE_LG;
+  if (g.nb < 1) g.nb = 1;
+  if (g.nb > L_NB_MAX) g.nb = L_NB_MAX;
+  return g;
+}
+
+// ---- bucket offsets: exclusive scan of <= 1024 counts ----------------------------------------------------------
+__global__ void __launch_bounds__(L_BK)
+kl_scan(const unsigned *__restrict__ ghist, int nbk, u64 *__restrict__ boff /* [nbk + 1] */, u64 *__restrict__ bcur /* [nbk] */,
+        unsigned *__restrict__ bnext)
+{ __shared__ u64 s[L_BK];
+  const int t = threadIdx.x;
+  const u64 v = t < nbk ? (u64) ghist[t] : 0ull;
+  s[t] = v;
+  __syncthreads();
+  for (int o = 1; o < L_BK; o <<= 1)
+    { const u64 a = t >= o ? s[t - o] : 0ull;
+      __syncthreads();
+      s[t] += a;
+      __syncthreads();
+    }
+  if (t < nbk) { boff[t] = s[t] - v; bcur[t] = s[t] - v; }
+  if (t == nbk - 1) boff[nbk] = s[t];
+  if (t == 0) *bnext = 0;
+}
+
+// ---- partition ---------------------------------------------------------------------------------------------------
+// A batch of 8192 records is counted, sorted by bucket INSIDE LDS and copied out in order: neighbouring lanes then write
+// neighbouring addresses (runs of ~8 records per bucket and batch).  Scattering the records straight from registers --
+// 64 lanes, 64 buckets, 64 separate 8-byte writes per instruction -- ran at a third of the speed (4.6 ms for 3.5 GB).
+#define PT_TPB    512
+#define PT_CH     2                        // chunks per batch
+#define PT_BATCH  (PT_CH * F_CH)           // 8192 records = 64 KB of LDS
+#define PT_PER    (PT_BATCH / PT_TPB)      // 16 records per thread, held in registers between the phases
+
+__global__ void __launch_bounds__(PT_TPB)
+kl_part(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill, unsigned n_chunks, int nb,
+        u64 *__restrict__ bcur, u64 *__restrict__ out)
+{ __shared__ u64      sorted[PT_BATCH];
+  __shared__ unsigned cur[L_BK];           // phase A: counts; phase C: cursors
+  __shared__ unsigned lbase[L_BK];         // first slot of the bucket in `sorted`
+  __shared__ unsigned gbase[L_BK];         // first slot of this batch's run in the output (low 32 bits suffice: nreq < 2^32)
+  __shared__ unsigned wsum[PT_TPB / 64];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int hsh = 32 - nb, nbk = 1 << nb;
+  for (int b = t; b < L_BK; b += PT_TPB) cur[b] = 0;
+  __syncthreads();
+  const unsigned nbatch = (n_chunks + PT_CH - 1) / PT_CH;
+  for (unsigned bt = blockIdx.x; bt < nbatch; bt += gridDim.x)
+    { // A: load (16 records per thread), count per bucket
+      u64 y[PT_PER]; bool ok[PT_PER];
+#pragma unroll
+      for (int j = 0; j < PT_PER; j++)
+        { const unsigned c = (unsigned) j / (PT_PER / PT_CH), r = ((unsigned) j % (PT_PER / PT_CH)) * PT_TPB + t;
+          const unsigned ch = bt * PT_CH + c;
+          const unsigned fill = ch < n_chunks ? chunk_fill[ch] : 0u;
+          ok[j] = r < fill;
+          y[j] = ok[j] ? req[(size_t) ch * F_CH + r] : 0ull;
+        }
+#pragma unroll
+      for (int j = 0; j < PT_PER; j++)
+        if (ok[j]) atomicAdd(&cur[(unsigned) (y[j] >> 32) >> hsh], 1u);
+      __syncthreads();
+      // B: exclusive scan of the counts (two buckets per thread), one global atomic per non-empty bucket
+      { const unsigned c0 = cur[2 * t], c1 = cur[2 * t + 1];
+        unsigned incl = c0 + c1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1)
+          { const unsigned v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+          }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        unsigned woff = 0;
+        for (int w = 0; w < wv; w++) woff += wsum[w];
+        const unsigned ex = woff + incl - (c0 + c1);
+        lbase[2 * t] = ex; lbase[2 * t + 1] = ex + c0;
+        cur[2 * t] = ex; cur[2 * t + 1] = ex + c0;
+        if (c0 && 2 * t < nbk) gbase[2 * t] = (unsigned) atomicAdd(&bcur[2 * t], (u64) c0);
+        if (c1 && 2 * t + 1 < nbk) gbase[2 * t + 1] = (unsigned) atomicAdd(&bcur[2 * t + 1], (u64) c1);
+      }
+      __syncthreads();
+      const unsigned total = wsum[0] + wsum[1] + wsum[2] + wsum[3] + wsum[4] + wsum[5] + wsum[6] + wsum[7];
+      // C: sort inside LDS (the order inside a bucket is arbitrary)
+#pragma unroll
+      for (int j = 0; j < PT_PER; j++)
+        if (ok[j]) sorted[atomicAdd(&cur[(unsigned) (y[j] >> 32) >> hsh], 1u)] = y[j];
+      __syncthreads();
+      // D: copy out in order
+      for (unsigned i = t; i < total; i += PT_TPB)
+        { const u64 v = sorted[i];
+          const unsigned b = (unsigned) (v >> 32) >> hsh;
+          out[(size_t) gbase[b] + (i - lbase[b])] = v;
+        }
+      __syncthreads();
+      for (int b = t; b < L_BK; b += PT_TPB) cur[b] = 0;
+      __syncthreads();
+    }
+}
+
+// ---- probe: block-map filter (LDS coarse slice, then the full map) + look-ups or survivor list ------------------------
+// One 1024-thread workgroup per CU owns a bucket at a time and keeps the bucket's part of the map, folded 4:1, in LDS.
+// Inside a bucket its 16 waves work on their own: a wave streams its share of the records, queues its survivors in its
+// own corner of LDS and, whenever 64 have gathered, looks them up with every lane busy.  No workgroup barrier inside a
+// bucket: the first version synchronised the workgroup five times per 8192 records and spent most of its 4.2 ms waiting.
+#define PB_TPB    1024
+#define PB_WAVES  (PB_TPB / 64)
+#define PB_PER    8                        // records per lane and iteration
+#define PB_WQ     192                      // queue slots per wave: < 64 left over + two wave-instructions
+#define PB_SLICEW (1 << (L_SLICE_LG - 5))  // 32768 words
+
+// 32 map bits -> 8 coarse bits (bit j = OR of the bits 4j .. 4j+3)
+SMG_DEV unsigned pb_fold(unsigned f)
+{ unsigned c = f | (f >> 1);
+  c = (c | (c >> 2)) & 0x11111111u;
+  c = (c | (c >> 3)) & 0x03030303u;
+  c = (c | (c >> 6)) & 0x000F000Fu;
+  return (c | (c >> 12)) & 0xFFu;
+}
+
+// LIST = false: look the survivors up and set their P flags.  LIST = true: append them to the chunk list `out`
+// (every wave fills chunks of its own).
+template <bool LIST> __global__ void __launch_bounds__(PB_TPB)
+kl_probe(FastArgs A, const u64 *__restrict__ recs, const u64 *__restrict__ boff, const uint32_t *__restrict__ fmap,
+         LookupGeo g, unsigned *__restrict__ bnext, u64 *__restrict__ out, uint32_t *__restrict__ out_fill,
+         unsigned max_out, FastCtl *__restrict__ ctl)
+{ __shared__ unsigned cmap[PB_SLICEW];
+  __shared__ u64      wq[PB_WAVES][PB_WQ];
+  __shared__ unsigned s_b;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int nbk = 1 << g.nb;
+  const int slice_lg = g.cb - g.nb;                  // coarse bits per bucket: 9 .. 20
+  const unsigned ncw = 1u << (slice_lg - 5);         // coarse words per bucket
+  const unsigned smask = (1u << slice_lg) - 1u;
+  u64 *q = wq[wv];
+  unsigned qn = 0;                                   // this wave's queue fill (uniform)
+  unsigned chunk = F_NOCHUNK, used = 0;              // LIST: this wave's output chunk
+  u64 kept = 0;
+
+  // the last `take` (<= 64) survivors of this wave's queue
+  auto drain = [&](unsigned take)
+  { const u64 yv = q[qn - take + ((unsigned) lane < take ? lane : 0)];
+    if (!LIST)
+      { if ((unsigned) lane < take)
+          { Key<1> y; y.w[0] = yv;
+            const int64_t j = sig_find<1>(A, y, false);
+            if (j < 0) { if (ctl->missing == 0) ctl->missing = 1; }
+            else SET_P(A, j);
+          }
+      }
+    else
+      { if (chunk == F_NOCHUNK || used + take > F_CH)
+          { if (chunk != F_NOCHUNK && chunk < max_out && lane == 0) out_fill[chunk] = used;
+            unsigned c = 0;
+            if (lane == 0) c = atomicAdd(&ctl->nf_chunks, 1u);
+            chunk = (unsigned) __builtin_amdgcn_readfirstlane((int) c);
+            used = 0;
+          }
+        if ((unsigned) lane < take && chunk < max_out) out[(size_t) chunk * F_CH + used + lane] = yv;
+        used += take;
+      }
+    qn -= take; kept += take;
+  };
+
+  for (;;)
+    { __syncthreads();
+      if (t == 0) s_b = atomicAdd(bnext, 1u);
+      __syncthreads();
+      const unsigned b = s_b;
+      if (b >= (unsigned) nbk) break;
+      const u64 r0 = boff[b], r1 = boff[b + 1];
+      if (r0 == r1) continue;
+      // the bucket's part of the map, folded 4:1 into LDS  (fb >= 12: at least 2^9 coarse bits per bucket)
+      { const uint32_t *fw = fmap + ((size_t) b << (g.fb - g.nb - 5));
+        for (unsigned cw = t; cw < ncw; cw += PB_TPB)
+          { const uint4 f = *reinterpret_cast<const uint4 *>(fw + 4 * cw);
+            cmap[cw] = pb_fold(f.x) | (pb_fold(f.y) << 8) | (pb_fold(f.z) << 16) | (pb_fold(f.w) << 24);
+          }
+      }
+      __syncthreads();
+      for (u64 i0 = r0 + (u64) wv * (64 * PB_PER); i0 < r1; i0 += (u64) PB_WAVES * 64 * PB_PER)
+        { u64 y[PB_PER]; bool keep[PB_PER]; unsigned fwd[PB_PER];
+#pragma unroll
+          for (int j = 0; j < PB_PER; j++)
+            { const u64 i = i0 + (u64) j * 64 + lane;
+              keep[j] = i < r1;
+              y[j] = keep[j] ? recs[i] : 0ull;
+            }
+#pragma unroll
+          for (int j = 0; j < PB_PER; j++)
+            { const unsigned cid = (unsigned) (y[j] >> (64 - g.cb)) & smask;
+              keep[j] = keep[j] && ((cmap[cid >> 5] >> (cid & 31)) & 1u);
+            }
+#pragma unroll
+          for (int j = 0; j < PB_PER; j++)                     // the full-resolution map: global memory, ~20 % of the lanes
+            { const unsigned fid = (unsigned) (y[j] >> (64 - g.fb));
+              fwd[j] = keep[j] ? fmap[fid >> 5] : 0u;
+            }
+#pragma unroll
+          for (int j = 0; j < PB_PER; j++)
+            { const unsigned fid = (unsigned) (y[j] >> (64 - g.fb));
+              keep[j] = keep[j] && ((fwd[j] >> (fid & 31)) & 1u);
+            }
+#pragma unroll
+          for (int j = 0; j < PB_PER; j += 2)                  // queue two wave-instructions' worth, drain to below 64
+            { const u64 m0 = __ballot(keep[j]), m1 = __ballot(keep[j + 1]);
+              const unsigned n0 = (unsigned) __popcll(m0), n1 = (unsigned) __popcll(m1);
+              if (keep[j]) q[qn + __builtin_amdgcn_mbcnt_hi((unsigned) (m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m0, 0u))] = y[j];
+              if (keep[j + 1]) q[qn + n0 + __builtin_amdgcn_mbcnt_hi((unsigned) (m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m1, 0u))] = y[j + 1];
+              qn += n0 + n1;
+              while (qn >= 64) drain(64);
+            }
+        }
+      if (qn) drain(qn);                                       // (the look-ups of a bucket stay inside its 1/2^nb of the table)
+    }
+  if (LIST && chunk != F_NOCHUNK && chunk < max_out && lane == 0) out_fill[chunk] = used;
+  if (kept && lane == 0) atomicAdd(&ctl->nf_req, kept);
+}

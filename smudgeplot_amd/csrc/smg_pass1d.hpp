@@ -47,6 +47,7 @@
 #define D_BMF    4096                      // block ids per tile with a bit in LDS (request filter)
 #endif
 #define D_BMW    (D_BMF / 32)
+#define D_HB     1024                      // bins of the request histogram (smg_lookup.hpp: L_BK)
 #define D_QCAP   1280                      // LDS request queue (records); flushed when the next tile might not fit
 // nothing is scheduled across this point: keeps the live ranges of the lane masks (SGPR pairs) short -- the machine
 // scheduler otherwise hoists every test's compare to the front and the kernel spills scalars by the dozen
@@ -145,7 +146,7 @@ struct P1Hot                              // kernel argument: what every tile to
   uint32_t       *bstart;        // bucket directory: bucket(x) = (hi32(x) >> dsh) - b0
   uint32_t       *bmap;          // candidate block map (or NULL): bit (hi32(x) >> bmsh)
   uint32_t        b0, nb;
-  unsigned        shifts;        // dsh | sigsh << 6 | bmsh << 12 | emit_all << 18 | want_fp << 19  (one register instead of five)
+  unsigned        shifts;        // dsh | sigsh << 6 | bmsh << 12 | emit_all << 18 | want_fp << 19 | hbits << 20  (one register)
   GeoR            G;
   int64_t         ntiles;
   SMG_DEV int dsh() const { return (int) (shifts & 63u); }
@@ -153,6 +154,7 @@ struct P1Hot                              // kernel argument: what every tile to
   SMG_DEV int bmsh() const { return (int) ((shifts >> 12) & 31u); }
   SMG_DEV bool emit_all() const { return (shifts >> 18 & 1u) != 0; }
   SMG_DEV bool want_fp() const { return (shifts >> 19 & 1u) != 0; }
+  SMG_DEV int hbits() const { return (int) ((shifts >> 20) & 15u); }    // request histogram on the leading hbits bits (0: none)
 };
 
 struct P1Cold                             // in device memory: what only a flush touches (kept out of the register file)
@@ -161,6 +163,7 @@ struct P1Cold                             // in device memory: what only a flush
   uint32_t *biglist;
   u64      *partials;
   FastCtl  *ctl;
+  unsigned *ghist;               // requests per bucket (leading hbits bits of the target), summed over the workgroups
   unsigned  max_chunks, big_cap;
 };
 
@@ -168,6 +171,7 @@ struct DShared                            // the workgroup's LDS arrays (pointer
 { unsigned *cred; uint16_t *tailq; u64 *ent; uint16_t *lcn; u64 *sq;
   unsigned *s_tn, *s_qn, *s_nbig, *s_unsorted;
   unsigned *bm;                          // candidate-block bits of this tile: D_BMW words (request filter)
+  unsigned *hist;                        // requests of this workgroup per bucket (D_HB bins), for the look-up chain's partition
 };
 
 // The 12 one-away tests of a thread (distances 1..3; entries 4..6 are the right neighbour's 0..2), aggregated on the
@@ -662,6 +666,7 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
   __shared__ u64      sfp[D_TPB / 64][2];
   constexpr bool D_BM = (W == 1 && RW == 1) || (W == 2 && RW == 3);
   __shared__ unsigned bm[D_BM ? D_BMW : 1];
+  __shared__ unsigned hist[(D_BM && W == 1) ? D_HB : 1];
   __shared__ unsigned s_tn, s_qn, s_nbig, s_unsorted, s_chunk, s_used, s_bigbase, s_bigcur;
   __shared__ u64      s_base, s_total;
 
@@ -674,8 +679,9 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
   DShared S;
   S.cred = cred; S.tailq = tailq; S.ent = ent; S.lcn = lcn; S.sq = sq;
   S.s_tn = &s_tn; S.s_qn = &s_qn; S.s_nbig = &s_nbig; S.s_unsorted = &s_unsorted;
-  S.bm = bm;
+  S.bm = bm; S.hist = hist;
   if (D_BM) for (int w = t; w < D_BMW; w += D_TPB) bm[w] = 0;
+  if (D_BM && W == 1) for (int w = t; w < D_HB; w += D_TPB) hist[w] = 0;
   for (int s = t; s < D_CRED; s += D_TPB) cred[s] = 0;
   if (t == 0) { s_chunk = F_NOCHUNK; s_used = 0; s_total = 0; s_tn = 0; s_qn = 0; s_nbig = 0; s_unsorted = 0; }
   lds_barrier();
@@ -733,6 +739,10 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
               s_qn = 0;
             }
           lds_barrier();
+          if (D_BM && W == 1 && A.hbits())            // requests per bucket, for the partition of the look-up chain
+            { const int hsh = 32 - A.hbits();
+              for (unsigned e = t; e < qn; e += D_TPB) atomicAdd(&hist[(unsigned) (sq[e] >> 32) >> hsh], 1u);
+            }
           if (head && old_chunk < max_chunks)
             { u64 *o = req + s_base * RW;
               for (unsigned e = t; e < head * RW; e += D_TPB) o[e] = sq[e];
@@ -758,6 +768,11 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
       lds_barrier();
     }
 
+  if (D_BM && W == 1 && A.hbits())
+    for (int w = t; w < (1 << A.hbits()); w += D_TPB)
+      { const unsigned v = hist[w];
+        if (v) atomicAdd(&cold->ghist[w], v);
+      }
   if (t == 0)
     { if (s_chunk != F_NOCHUNK && s_chunk < cold->max_chunks) cold->chunk_fill[s_chunk] = s_used;
       if (s_total) atomicAdd(&cold->ctl->nreq, s_total);
