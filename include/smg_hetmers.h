@@ -67,6 +67,21 @@ typedef struct smg_table_view
   const int64_t        *prefix_index;  /* [2^(8*ibyte)] cumulative END offsets                 */
 } smg_table_view;
 
+/* A FastK table that is still on disk (or anywhere else): the engine PULLS the records, in pieces of a few tens of
+   megabytes, from up to `host_threads` threads at once, into pinned buffers from which they go to the device while
+   the next pieces are being read -- the host never holds the table.
+   Replaces: More_Kmer_Stream / GoTo_Kmer_Index, src/lib/libfastk.c:759-784, 1273-1307 (1024-record read(2) blocks).  */
+typedef struct smg_table_source
+{ int32_t        kmer, ibyte, nparts, minval;
+  int64_t        nels;
+  const int64_t *part_nels;      /* [nparts]                                                               */
+  const int64_t *prefix_index;   /* [2^(8*ibyte)] cumulative END offsets (host memory)                    */
+  /* copy `nent` records of part `part`, starting at its entry `first`, to dst; 0 = success.  Thread safe. */
+  int          (*read)(void *ctx, int part, int64_t first, int64_t nent, void *dst);
+  void          *ctx;
+  int32_t        host_threads;   /* reader threads (the -T of the command line); <= 0: 4                   */
+} smg_table_source;
+
 /* Table conditioning the reference delegates to FastK's Logex / Symmex
    (PloidyPlot.c:1381-1414), done on the device instead.                                     */
 #define SMG_COND_TRIM  1     /* drop entries with count < ethresh          (Logex 'A[e-]')    */
@@ -105,6 +120,10 @@ typedef struct smg_stats
    plot: caller-allocated int64[SMG_PLOT_CELLS], overwritten.  stats may be NULL.            */
 int smg_hetmers_run(const smg_table_view *table, const smg_opts *opts, int64_t *plot,
                     smg_stats *stats, char *errbuf, size_t errlen);
+
+/* the same from a table source (what the `hetmers` executable uses: smg_ktab_open + smg_ktab_read)      */
+int smg_hetmers_run_source(const smg_table_source *source, const smg_opts *opts, int64_t *plot,
+                           smg_stats *stats, char *errbuf, size_t errlen);
 
 /* ---- extract: the pairs behind the labelled pixels ----------------------------------------
    Replaces the compute section of extract_kmer_pairs, src/lib/PloidyList.c:1207-1583 (same two

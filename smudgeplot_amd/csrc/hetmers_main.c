@@ -19,6 +19,8 @@
  *                                        multiset fingerprint of T against rc(T); exact looks up
  *                                        the complement of every entry; the reference itself only
  *                                        probes entry #1, PloidyPlot.c:1199-1229)
+ *    SMUDGEPLOT_IO_THREADS=<n>           threads that read the part files (default: the -T value, at least 8)
+ *    SMUDGEPLOT_GPUS=<n>                 prefix-shard the table over n GPUs of the node
  *    under -v the engine adds one "[smg]" timing line to stderr
  *
  *  Deviations, deliberate:
@@ -73,12 +75,13 @@ int main(int argc, char *argv[])
   { smg_ktab T;
     smg_opts  opts;
     smg_stats stats;
-    smg_table_view tv;
+    smg_table_source src;
     int64_t *plot;
     char  errbuf[512];
     char *input;
     int   rc;
 
+    Load_Lazy = 1;                 /* stub + index only: the engine streams the parts into HBM (smg_ingest.hpp) */
     input = smg_cli_open_table(&c, SRC, &T, &opts);
 
     if (c.verbose)
@@ -88,9 +91,9 @@ int main(int argc, char *argv[])
     if (plot == NULL)
       { fprintf(stderr, "%s: Out of memory (Allocating plot)\n", Prog_Name); exit(1); }
 
-    smg_cli_table_view(&T, &tv);
+    smg_cli_table_source(&T, &src, c.nthreads);
     errbuf[0] = 0;
-    rc = smg_hetmers_run(&tv, &opts, plot, &stats, errbuf, sizeof(errbuf));
+    rc = smg_hetmers_run_source(&src, &opts, plot, &stats, errbuf, sizeof(errbuf));
     if (rc != SMG_OK)
       { fprintf(stderr, "%s: %s\n", Prog_Name, errbuf[0] ? errbuf : "GPU engine failed");
         exit(1);

@@ -48,10 +48,11 @@ __attribute__((unused)) static void system_x(const char *command)       /* Syste
 }
 
 static int Load_Threads = 1;           /* -T: host threads that read the part files */
+static int Load_Lazy = 0;              /* 1: leave the records on disk (smg_ktab_open), the engine pulls them */
 
 static void load_or_die(const char *name, smg_ktab *T)
 { char what[4096];
-  switch (smg_ktab_load_mt(name, T, what, Load_Threads))
+  switch (Load_Lazy ? smg_ktab_open(name, T, what) : smg_ktab_load_mt(name, T, what, Load_Threads))
   { case SMG_KTAB_OK:
       return;
     case SMG_KTAB_NOSTUB:
@@ -221,7 +222,25 @@ __attribute__((unused)) static char *smg_cli_open_table(const smg_cli *c, const 
   return input;
 }
 
-static void smg_cli_table_view(const smg_ktab *T, smg_table_view *tv)
+/* the table as a source the engine pulls from (records still on disk, or already in memory) */
+__attribute__((unused)) static int smg_cli_source_read(void *ctx, int part, int64_t first, int64_t nent, void *dst)
+{ return smg_ktab_read((const smg_ktab *) ctx, part, first, nent, dst); }
+
+__attribute__((unused)) static void smg_cli_table_source(const smg_ktab *T, smg_table_source *src, int nthreads)
+{ const char *io = getenv("SMUDGEPLOT_IO_THREADS");
+  src->kmer = T->kmer; src->ibyte = T->ibyte; src->nparts = T->nparts; src->minval = T->minval;
+  src->nels = T->nels;
+  src->part_nels = T->part_nels;
+  src->prefix_index = T->index;
+  src->read = smg_cli_source_read;
+  src->ctx = (void *) T;
+  /* readers: the -T of the command line, but at least 8 -- pulling the part files out of the page cache is all
+     the host does for this engine, and 4 threads (the CLI's default) leave the PCIe link two thirds idle      */
+  src->host_threads = io != NULL && atoi(io) > 0 ? atoi(io) : (nthreads > 8 ? nthreads : 8);
+  if (src->host_threads > 64) src->host_threads = 64;
+}
+
+__attribute__((unused)) static void smg_cli_table_view(const smg_ktab *T, smg_table_view *tv)
 { tv->kmer = T->kmer; tv->ibyte = T->ibyte; tv->nparts = T->nparts; tv->minval = T->minval;
   tv->nels = T->nels;
   tv->part_data = (const uint8_t *const *) T->part;

@@ -1626,16 +1626,17 @@ extern "C" int smg_engine_extract(smg_engine *e, const uint16_t *d_labels, uint6
   return SMG_OK;
 }
 
+#include "smg_ingest.hpp"
 #include "smg_multi.hpp"
 
 // ---- one-shot host entry ----------------------------------------------------------------------
 
 // labels == NULL: hetmers.  labels != NULL: additionally the extract leg; *records receives a malloc'ed
 // array of *nrec records of (words + 1) uint64 each.
-static int host_run(const smg_table_view *tv, const smg_opts *opts, int64_t *plot, smg_stats *stats,
+static int host_run(const smg_table_source *tv, const smg_opts *opts, int64_t *plot, smg_stats *stats,
                     const uint16_t *labels, uint64_t **records, int64_t *nrec, int *rec_words,
                     char *errbuf, size_t errlen)
-{ if (!tv || !plot) return fail(errbuf, errlen, SMG_EINVAL, "null argument%s");
+{ if (!tv || !plot || !tv->read) return fail(errbuf, errlen, SMG_EINVAL, "null argument%s");
   const int device = opts ? opts->device : 0;
   const int symcheck = opts ? opts->symcheck : SMG_SYM_EXACT;
   const int verbose = opts ? opts->verbose : 0;
@@ -1647,8 +1648,31 @@ static int host_run(const smg_table_view *tv, const smg_opts *opts, int64_t *plo
   if (sum != tv->nels) return fail(errbuf, errlen, SMG_EFORMAT, "part sizes do not add up to nels%s");
   { // several GPUs of the node (smg_multi.hpp); SMG_VIRTUAL_SHARDS is the 1-GPU test hook of that path
     int ng = opts ? opts->ngpus : 0;
+    bool virt = false;
     const char *v = getenv("SMG_VIRTUAL_SHARDS");
-    if (v && atoi(v) > 1) ng = atoi(v);
+    if (v && atoi(v) > 1) { ng = atoi(v); virt = true; }
+    // A shard addresses its entries with 32 bits.  A table beyond that is cut into prefix shards that all live on
+    // this one device (288 GB of HBM hold ~1.5e10 k=31 entries with their side arrays) -- the same code path as
+    // several GPUs, with device-to-device copies for the exchange: the reference streams a table of any size
+    // (PloidyPlot.c:931-1038), this engine must not refuse one just because of an index width.
+    // SMG_SHARD_LIMIT (tests) lowers the threshold.
+    { int64_t limit = 0xFFFFFFF0ll - 16;
+      const char *sl = getenv("SMG_SHARD_LIMIT");
+      if (sl && atoll(sl) > 0) limit = atoll(sl);
+      if (ng <= 1 && tv->nels >= limit && !labels)
+        { int64_t per = limit > 3000000000ll ? 3000000000ll : limit;     // ~3e9 entries per shard
+          if (per < 1) per = 1;
+          ng = (int) ((tv->nels + per - 1) / per);
+          if (ng < 2) ng = 2;
+          if (ng > SMG_MAXGPU)
+            return fail(errbuf, errlen, SMG_EINVAL, "table too large for one GPU (more than 16 shards of 3e9 entries): use SMUDGEPLOT_GPUS%s");
+          virt = true;
+          if (verbose) fprintf(stderr, "  [smg] %lld entries: %d prefix shards on one device\n", (long long) tv->nels, ng);
+          if ((opts && (opts->condition & SMG_COND_SYMM)) || tv->kmer > FAST_MAX_K)
+            return fail(errbuf, errlen, SMG_EINVAL, "a table of more than 2^32 entries must be symmetric already and have k <= 85 "
+                        "(symmetrise it in pieces with smg_condition, or use the FastK tools)%s");
+        }
+    }
     // SMG_FORCE_MULTI=1 (tests): take the multi-GPU code path even with one GPU -- a one-rank RCCL
     // communicator, send/recv to self, all-reduce: checks the dlopen'ed RCCL entry points on a 1-GPU box
     if (ng <= 1 && getenv("SMG_FORCE_MULTI") && !v) ng = -1;
@@ -1660,7 +1684,10 @@ static int host_run(const smg_table_view *tv, const smg_opts *opts, int64_t *plo
         else
           { smg_opts o; memset(&o, 0, sizeof(o));
             if (opts) o = *opts; else o.symcheck = SMG_SYM_HASH;
-            return host_run_multi(tv, &o, ng == -1 ? 1 : ng, plot, stats, errbuf, errlen);
+            const int mrc = host_run_multi(tv, &o, ng == -1 ? 1 : ng, virt, plot, stats, errbuf, errlen);
+            // a table that fails the symmetry proof: the shards cannot help each other, one GPU takes the general path
+            if (mrc != SMG_ENOTSYM || tv->nels >= 0xFFFFFFF0ll - 16) return mrc;
+            if (verbose) fprintf(stderr, "  [smg] the table is not closed under reverse complement: general path on one GPU\n");
           }
       }
   }
@@ -1672,25 +1699,19 @@ static int host_run(const smg_table_view *tv, const smg_opts *opts, int64_t *plo
   uint16_t *d_labels = NULL; uint64_t *d_out = NULL;
   const size_t ixbytes = sizeof(int64_t) << (8 * tv->ibyte);
   hipEvent_t h0, h1;
+  double h2d_s = 0;
   hipEventCreate(&h0); hipEventCreate(&h1);
 #define BAIL(code, msg) { rc = fail(errbuf, errlen, code, msg "%s"); goto done; }
   if (hipMalloc(&d_rec, (size_t) (tv->nels > 0 ? tv->nels : 1) * pbyte) != hipSuccess
       || hipMalloc(&d_index, ixbytes) != hipSuccess
       || hipMalloc(&d_plot, sizeof(int64_t) * SMG_PLOT_CELLS) != hipSuccess)
     BAIL(SMG_ENOMEM, "out of device memory for the table")
-  hipEventRecord(h0, 0);
-  { size_t off = 0;
-    for (int p = 0; p < tv->nparts; p++)
-      { const size_t b = (size_t) tv->part_nels[p] * pbyte;
-        if (b && hipMemcpy(d_rec + off, tv->part_data[p], b, hipMemcpyHostToDevice) != hipSuccess)
-          BAIL(SMG_ENODEV, "host to device copy failed")
-        off += b;
-      }
-    if (hipMemcpy(d_index, tv->prefix_index, ixbytes, hipMemcpyHostToDevice) != hipSuccess)
+  { // the index goes first (asynchronously from pageable memory: staged by the runtime), the records stream behind it
+    if (hipMemcpyAsync(d_index, tv->prefix_index, ixbytes, hipMemcpyHostToDevice, 0) != hipSuccess)
       BAIL(SMG_ENODEV, "host to device copy failed")
+    if ((rc = ingest_records(tv, pbyte, 0, tv->nels, d_rec, device, tv->host_threads, &h2d_s, errbuf, errlen))) goto done;
+    if (hipStreamSynchronize(0) != hipSuccess) BAIL(SMG_ENODEV, "host to device copy failed")
   }
-  hipEventRecord(h1, 0);
-  hipEventSynchronize(h1);
   if ((rc = smg_engine_decode(e, tv->kmer, tv->ibyte, tv->nels, d_rec, d_index, errbuf, errlen))) goto done;
   hipFree(d_rec); d_rec = NULL;
   if (opts && opts->condition)
@@ -1720,13 +1741,14 @@ static int host_run(const smg_table_view *tv, const smg_opts *opts, int64_t *plo
         { free(h); BAIL(SMG_ENODEV, "device to host copy failed") }
       *records = h; *nrec = want; *rec_words = rw;
     }
-  { float ms = 0; hipEventElapsedTime(&ms, h0, h1); e->st.ms_h2d = ms; }
+  e->st.ms_h2d = h2d_s * 1e3;
   if (stats) *stats = e->st;
   if (verbose)
-    fprintf(stderr, "  [smg] n=%lld k=%d path=%s  h2d %.2f ms, decode %.2f, pass1 %.2f, rc-lookup %.2f, "
+    fprintf(stderr, "  [smg] n=%lld k=%d path=%s  read+h2d %.2f ms (%.1f GB/s, %d readers), decode %.2f, pass1 %.2f, rc-lookup %.2f, "
             "pass2 %.2f, total(device) %.2f ms => %.3g k-mers/s\n",
             (long long) e->st.nels, tv->kmer, e->st.path == 1 ? "rc-half-scan" : "general",
-            e->st.ms_h2d, e->st.ms_decode, e->st.ms_pass1, e->st.ms_rclookup, e->st.ms_pass2,
+            e->st.ms_h2d, h2d_s > 0 ? (double) tv->nels * pbyte / h2d_s / 1e9 : 0.0, tv->host_threads > 0 ? tv->host_threads : 4,
+            e->st.ms_decode, e->st.ms_pass1, e->st.ms_rclookup, e->st.ms_pass2,
             e->st.ms_total, e->st.ms_total > 0 ? e->st.nels / (e->st.ms_total * 1e-3) : 0.0);
 done:
 #undef BAIL
@@ -1742,14 +1764,25 @@ done:
 
 extern "C" int smg_hetmers_run(const smg_table_view *tv, const smg_opts *opts, int64_t *plot,
                                smg_stats *stats, char *errbuf, size_t errlen)
-{ return host_run(tv, opts, plot, stats, NULL, NULL, NULL, NULL, errbuf, errlen); }
+{ if (!tv) return fail(errbuf, errlen, SMG_EINVAL, "null argument%s");
+  ViewCtx vc; smg_table_source src;
+  view_source(tv, &vc, &src);
+  return host_run(&src, opts, plot, stats, NULL, NULL, NULL, NULL, errbuf, errlen);
+}
+
+extern "C" int smg_hetmers_run_source(const smg_table_source *src, const smg_opts *opts, int64_t *plot,
+                                      smg_stats *stats, char *errbuf, size_t errlen)
+{ return host_run(src, opts, plot, stats, NULL, NULL, NULL, NULL, errbuf, errlen); }
 
 extern "C" int smg_hetmers_extract(const smg_table_view *tv, const smg_opts *opts, const uint16_t *labels,
                                    int64_t *plot, uint64_t **records, int64_t *nrec, int *rec_words,
                                    smg_stats *stats, char *errbuf, size_t errlen)
 { if (!labels || !records || !nrec || !rec_words) return fail(errbuf, errlen, SMG_EINVAL, "null argument%s");
   *records = NULL; *nrec = 0; *rec_words = 0;
-  return host_run(tv, opts, plot, stats, labels, records, nrec, rec_words, errbuf, errlen);
+  if (!tv) return fail(errbuf, errlen, SMG_EINVAL, "null argument%s");
+  ViewCtx vc; smg_table_source src;
+  view_source(tv, &vc, &src);
+  return host_run(&src, opts, plot, stats, labels, records, nrec, rec_words, errbuf, errlen);
 }
 
 extern "C" void smg_free(void *p) { free(p); }
@@ -1773,9 +1806,12 @@ extern "C" int smg_condition_table(const smg_table_view *tv, const smg_opts *opt
 #define BAIL(code, msg) { rc = fail(errbuf, errlen, code, msg "%s"); goto done; }
   if (hipMalloc(&d_rec, (size_t) (tv->nels > 0 ? tv->nels : 1) * pbyte) != hipSuccess || hipMalloc(&d_index, ixbytes) != hipSuccess)
     BAIL(SMG_ENOMEM, "out of device memory for the table")
-  if (multi_h2d_records(tv, pbyte, 0, tv->nels, d_rec) != hipSuccess
-      || hipMemcpy(d_index, tv->prefix_index, ixbytes, hipMemcpyHostToDevice) != hipSuccess)
-    BAIL(SMG_ENODEV, "host to device copy failed")
+  { ViewCtx vc; smg_table_source src;
+    view_source(tv, &vc, &src);
+    if ((rc = ingest_records(&src, pbyte, 0, tv->nels, d_rec, opts->device, 4, NULL, errbuf, errlen))) goto done;
+    if (hipMemcpy(d_index, tv->prefix_index, ixbytes, hipMemcpyHostToDevice) != hipSuccess)
+      BAIL(SMG_ENODEV, "host to device copy failed")
+  }
   if ((rc = smg_engine_decode(e, tv->kmer, tv->ibyte, tv->nels, d_rec, d_index, errbuf, errlen))) goto done;
   hipFree(d_rec); d_rec = NULL;
   if (opts->condition

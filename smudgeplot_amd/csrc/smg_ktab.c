@@ -52,7 +52,30 @@ static void *chunk_worker(void *arg)
 int smg_ktab_load(const char *name, smg_ktab *t, char *what)
 { return smg_ktab_load_mt(name, t, what, 1); }
 
+static int ktab_open(const char *name, smg_ktab *t, char *what, int load, int nthreads);
+
+int smg_ktab_open(const char *name, smg_ktab *t, char *what)
+{ return ktab_open(name, t, what, 0, 1); }
+
 int smg_ktab_load_mt(const char *name, smg_ktab *t, char *what, int nthreads)
+{ return ktab_open(name, t, what, 1, nthreads); }
+
+int smg_ktab_read(const smg_ktab *t, int part, int64_t first, int64_t nent, void *dst)
+{ size_t len = (size_t) nent * (size_t) t->pbyte, done = 0;
+  off_t  off = (off_t) 12 + (off_t) first * (off_t) t->pbyte;
+  if (part < 0 || part >= t->nparts || first < 0 || first + nent > t->part_nels[part]) return -1;
+  if (t->part[part] != NULL)
+    { memcpy(dst, t->part[part] + (size_t) first * (size_t) t->pbyte, len); return 0; }
+  if (t->fd == NULL || t->fd[part] < 0) return -1;
+  while (done < len)
+    { ssize_t r = pread(t->fd[part], (uint8_t *) dst + done, len - done, off + (off_t) done);
+      if (r <= 0) return -1;
+      done += (size_t) r;
+    }
+  return 0;
+}
+
+static int ktab_open(const char *name, smg_ktab *t, char *what, int load, int nthreads)
 { const char *slash = strrchr(name, '/');
   char  *dir, *root, *path;
   size_t len;
@@ -73,7 +96,8 @@ int smg_ktab_load_mt(const char *name, smg_ktab *t, char *what, int nthreads)
   if (fd < 0) { rc = SMG_KTAB_NOSTUB; goto out; }
   if (read_full(fd, hdr, sizeof(hdr))) { close(fd); rc = SMG_KTAB_SHORT; goto out; }
   t->kmer = hdr[0]; t->nparts = hdr[1]; t->minval = hdr[2]; t->ibyte = hdr[3];
-  if (t->kmer < 1 || t->nparts < 0 || t->ibyte < 1 || t->ibyte > 3)
+  if (t->kmer < 1 || t->nparts < 0 || t->nparts > (1 << 20) || t->ibyte < 1 || t->ibyte > 3
+      || ((t->kmer + 3) >> 2) <= t->ibyte)           /* no suffix bytes: FastK never writes such a table (hbyte >= 1) */
     { close(fd); rc = SMG_KTAB_SHORT; goto out; }
   t->kbyte = (t->kmer + 3) >> 2;
   t->tbyte = t->kbyte + 2;
@@ -84,18 +108,17 @@ int smg_ktab_load_mt(const char *name, smg_ktab *t, char *what, int nthreads)
   t->part = (uint8_t **) calloc((size_t) (t->nparts > 0 ? t->nparts : 1), sizeof(uint8_t *));
   t->part_nels = (int64_t *) calloc((size_t) (t->nparts > 0 ? t->nparts : 1), sizeof(int64_t));
   t->part_end = (int64_t *) calloc((size_t) (t->nparts > 0 ? t->nparts : 1), sizeof(int64_t));
-  if (!t->index || !t->part || !t->part_nels || !t->part_end)
+  t->fd = (int *) malloc(sizeof(int) * (size_t) (t->nparts > 0 ? t->nparts : 1));
+  if (!t->index || !t->part || !t->part_nels || !t->part_end || !t->fd)
     { close(fd); rc = SMG_KTAB_NOMEM; goto out; }
+  for (p = 0; p < t->nparts; p++) t->fd[p] = -1;
   if (read_full(fd, t->index, sizeof(int64_t) * (size_t) t->ixlen))
     { close(fd); rc = SMG_KTAB_SHORT; goto out; }
   close(fd);
 
-  { int *fds = (int *) malloc(sizeof(int) * (size_t) (t->nparts > 0 ? t->nparts : 1));
-    smg_chunkq q;
+  { smg_chunkq q;
     long cap = 0;
-    int  opened = 0;
     memset(&q, 0, sizeof(q));
-    if (!fds) { rc = SMG_KTAB_NOMEM; goto out; }
     for (p = 1; p <= t->nparts && rc == SMG_KTAB_OK; p++)
       { int32_t km; int64_t n;
         struct stat sb;
@@ -103,16 +126,17 @@ int smg_ktab_load_mt(const char *name, smg_ktab *t, char *what, int nthreads)
         if (what) snprintf(what, 4096, "%s", path);
         fd = open(path, O_RDONLY);
         if (fd < 0) { rc = SMG_KTAB_NOPART; break; }
-        fds[opened++] = fd;
+        t->fd[p - 1] = fd;
         if (read_full(fd, &km, 4) || read_full(fd, &n, 8)) { rc = SMG_KTAB_SHORT; break; }
         if (km != t->kmer) { rc = SMG_KTAB_KMISMATCH; break; }
         if (n < 0 || fstat(fd, &sb) != 0 || (int64_t) sb.st_size < 12 + n * (int64_t) t->pbyte)
           { rc = SMG_KTAB_SHORT; break; }
-        t->part[p - 1] = (uint8_t *) malloc((size_t) (n > 0 ? n : 1) * (size_t) t->pbyte);
-        if (!t->part[p - 1]) { rc = SMG_KTAB_NOMEM; break; }
         t->part_nels[p - 1] = n;
         t->nels += n;
         t->part_end[p - 1] = t->nels;
+        if (!load) continue;
+        t->part[p - 1] = (uint8_t *) malloc((size_t) (n > 0 ? n : 1) * (size_t) t->pbyte);
+        if (!t->part[p - 1]) { rc = SMG_KTAB_NOMEM; break; }
         { size_t bytes = (size_t) n * (size_t) t->pbyte, o;
           for (o = 0; o < bytes; o += SMG_CHUNK)
             { if (q.n >= cap)
@@ -138,8 +162,20 @@ int smg_ktab_load_mt(const char *name, smg_ktab *t, char *what, int nthreads)
         pthread_mutex_destroy(&q.mu);
         if (q.failed) rc = SMG_KTAB_SHORT;
       }
-    while (opened > 0) close(fds[--opened]);
-    free(fds); free(q.ch);
+    free(q.ch);
+    if (rc == SMG_KTAB_OK)
+      { /* the index must be the cumulative entry count of the parts (a hostile or damaged stub would otherwise send
+           the readers out of bounds): non-decreasing, ending at nels                                            */
+        int64_t i, prev = 0;
+        for (i = 0; i < t->ixlen && rc == SMG_KTAB_OK; i++)
+          { if (t->index[i] < prev || t->index[i] > t->nels) rc = SMG_KTAB_SHORT;
+            prev = t->index[i];
+          }
+        if (rc == SMG_KTAB_OK && t->ixlen > 0 && t->index[t->ixlen - 1] != t->nels) rc = SMG_KTAB_SHORT;
+        if (rc != SMG_KTAB_OK && what) { sprintf(path, "%s/%s.ktab", dir, root); snprintf(what, 4096, "%s", path); }
+      }
+    if (load)                                   /* everything is in memory: the descriptors are not needed any more */
+      for (p = 0; p < t->nparts; p++) if (t->fd[p] >= 0) { close(t->fd[p]); t->fd[p] = -1; }
   }
 out:
   free(dir); free(root); free(path);
@@ -151,16 +187,21 @@ void smg_ktab_free(smg_ktab *t)
 { int p;
   if (t->part)
     for (p = 0; p < t->nparts; p++) free(t->part[p]);
-  free(t->part); free(t->part_nels); free(t->part_end); free(t->index);
+  if (t->fd)
+    for (p = 0; p < t->nparts; p++) if (t->fd[p] >= 0) close(t->fd[p]);
+  free(t->part); free(t->part_nels); free(t->part_end); free(t->index); free(t->fd);
   memset(t, 0, sizeof(*t));
 }
 
-static const uint8_t *record_at(const smg_ktab *t, int64_t i)
+/* record i: a pointer into the loaded part, or the record fetched into buf (>= pbyte bytes) from disk */
+static const uint8_t *record_at(const smg_ktab *t, int64_t i, uint8_t *buf)
 { int p = 0;
   int64_t base = 0;
   while (p < t->nparts - 1 && i >= t->part_end[p]) p++;
   if (p > 0) base = t->part_end[p - 1];
-  return t->part[p] + (size_t) (i - base) * (size_t) t->pbyte;
+  if (t->part[p] != NULL) return t->part[p] + (size_t) (i - base) * (size_t) t->pbyte;
+  if (smg_ktab_read(t, p, i - base, 1, buf) != 0) memset(buf, 0, (size_t) t->pbyte);
+  return buf;
 }
 
 static int64_t prefix_of(const smg_ktab *t, int64_t i)      /* smallest p with index[p] > i */
@@ -173,7 +214,8 @@ static int64_t prefix_of(const smg_ktab *t, int64_t i)      /* smallest p with i
 }
 
 void smg_ktab_entry(const smg_ktab *t, int64_t i, uint8_t *kmer_out, int *count_out)
-{ const uint8_t *r = record_at(t, i);
+{ uint8_t rb[64];
+  const uint8_t *r = record_at(t, i, rb);
   int64_t pre = prefix_of(t, i);
   int j;
   for (j = 0; j < t->ibyte; j++)
@@ -184,6 +226,7 @@ void smg_ktab_entry(const smg_ktab *t, int64_t i, uint8_t *kmer_out, int *count_
 
 int64_t smg_ktab_find(const smg_ktab *t, const uint8_t *kmer)
 { int64_t m = 0, lo, hi;
+  uint8_t rb[64];
   int j;
   for (j = 0; j < t->ibyte; j++) m = (m << 8) | kmer[j];
   lo = m == 0 ? 0 : t->index[m - 1];
@@ -191,10 +234,10 @@ int64_t smg_ktab_find(const smg_ktab *t, const uint8_t *kmer)
   if (hi > t->nels) hi = t->nels;
   while (lo < hi)
     { int64_t mid = (lo + hi) >> 1;
-      if (memcmp(record_at(t, mid), kmer + t->ibyte, (size_t) t->hbyte) < 0) lo = mid + 1; else hi = mid;
+      if (memcmp(record_at(t, mid, rb), kmer + t->ibyte, (size_t) t->hbyte) < 0) lo = mid + 1; else hi = mid;
     }
   if (lo < t->index[m] && lo < t->nels
-      && memcmp(record_at(t, lo), kmer + t->ibyte, (size_t) t->hbyte) == 0)
+      && memcmp(record_at(t, lo, rb), kmer + t->ibyte, (size_t) t->hbyte) == 0)
     return lo;
   return -1;
 }
@@ -218,11 +261,27 @@ void smg_ktab_examine(const smg_ktab *t, int ethresh, int *trim, int *symm)
      it (and FastK) supports, they are ignored here instead of writing out of bounds.        */
   if (t->nels + 3 < 100000000) { frst = 0; last = t->nels; }
   else { frst = t->nels / 2 - 50000000; last = t->nels / 2 + 50000000; }
-  for (i = frst; i < last; i++)
-    { const uint8_t *r = record_at(t, i);
-      int c = r[t->hbyte] | (r[t->hbyte + 1] << 8);
-      if (hist && c < 0x8000) hist[c] += 1;
-    }
+  { /* part by part, 64K records at a time (from memory or, for a table left on disk, by pread) */
+    const int64_t blk = 65536;
+    uint8_t *buf = (uint8_t *) malloc((size_t) blk * (size_t) t->pbyte);
+    int p;
+    for (p = 0; p < t->nparts && buf != NULL; p++)
+      { const int64_t pb = p ? t->part_end[p - 1] : 0, pe = t->part_end[p];
+        int64_t a = frst > pb ? frst : pb, b = last < pe ? last : pe;
+        for (i = a; i < b; i += blk)
+          { const int64_t m = b - i < blk ? b - i : blk;
+            int64_t j;
+            const uint8_t *r = buf;
+            if (t->part[p] != NULL) r = t->part[p] + (size_t) (i - pb) * (size_t) t->pbyte;
+            else if (smg_ktab_read(t, p, i - pb, m, buf) != 0) break;
+            for (j = 0; j < m; j++, r += t->pbyte)
+              { int c = r[t->hbyte] | (r[t->hbyte + 1] << 8);
+                if (hist && c < 0x8000) hist[c] += 1;
+              }
+          }
+      }
+    free(buf);
+  }
   nz = 0x8000;
   if (hist)
     for (nz = 1; nz < 0x8000 && hist[nz] == 0; nz++) ;

@@ -1,9 +1,13 @@
 /* smg_ktab.h -- host-side (plain C) loader for FastK k-mer tables, "format F".
  *
  * Stands in for the Kmer_Stream part of the reference's libfastk
- * (/root/reference/src/lib/libfastk.c:717-1409): instead of a seekable stream with 1024-record
- * read(2) blocks, the whole table is read once into host memory (parts kept as they are on
- * disk, headers stripped) so it can be handed to the GPU engine as a `smg_table_view`.
+ * (/root/reference/src/lib/libfastk.c:717-1409).  Two ways to use it:
+ *   smg_ktab_open     stub, prefix index and part headers only; the records stay on disk and are fetched with
+ *                     smg_ktab_read (pread, thread safe) -- what `hetmers` does: the engine pulls the parts
+ *                     through a small pinned ring straight into HBM, the host never holds the table
+ *                     (the reference streams 1024-record blocks, libfastk.c:759-784);
+ *   smg_ktab_load_mt  additionally reads every part into host memory (parts kept as they are on disk,
+ *                     headers stripped), for callers that hand a `smg_table_view` to the engine.
  */
 #ifndef SMG_KTAB_H
 #define SMG_KTAB_H
@@ -20,6 +24,7 @@ typedef struct smg_ktab
   uint8_t **part;                           /* [nparts] raw records                            */
   int64_t  *part_nels;                      /* [nparts]                                        */
   int64_t  *part_end;                       /* [nparts] cumulative (neps, libfastk.c:857)      */
+  int      *fd;                             /* [nparts] open part files (-1 when closed)       */
 } smg_ktab;
 
 #define SMG_KTAB_OK        0
@@ -30,6 +35,9 @@ typedef struct smg_ktab
 #define SMG_KTAB_SHORT     5     /* file shorter than its header promises                       */
 
 /* name: "<path>[.ktab]".  On failure `what` (>= 4096 bytes) receives the offending file name. */
+int  smg_ktab_open(const char *name, smg_ktab *t, char *what);      /* part[p] stay NULL: use smg_ktab_read */
+/* `nent` records of part `part` starting at its entry `first` -> dst; 0 on success.  Thread safe.        */
+int  smg_ktab_read(const smg_ktab *t, int part, int64_t first, int64_t nent, void *dst);
 int  smg_ktab_load(const char *name, smg_ktab *t, char *what);
 /* same, the part files read by `nthreads` threads (the -T of the command line, <= 64)           */
 int  smg_ktab_load_mt(const char *name, smg_ktab *t, char *what, int nthreads);

@@ -54,8 +54,8 @@ struct MultiCtx
 { int  n;                                   // shards == threads
   bool virt;                                // all shards on one device, no RCCL
   int  devs[SMG_MAXGPU];
-  const smg_table_view *tv;
-  int  symcheck, condition, ethresh, W, pbyte;
+  const smg_table_source *tv;
+  int  symcheck, condition, ethresh, W, pbyte, io_threads;
   int64_t cut[SMG_MAXGPU + 1];              // entry ranges of the shards in the input table
   pthread_barrier_t bar;
   volatile int failed;
@@ -79,24 +79,6 @@ struct MultiCtx
 };
 
 struct MultiArg { MultiCtx *c; int r; };
-
-// copy the records of the entries [lo, hi) of the (multi-part) host table to the device
-static hipError_t multi_h2d_records(const smg_table_view *tv, int pbyte, int64_t lo, int64_t hi, uint8_t *d_rec)
-{ int64_t base = 0;
-  size_t off = 0;
-  for (int p = 0; p < tv->nparts && base < hi; p++)
-    { const int64_t pn = tv->part_nels[p];
-      const int64_t a = lo > base ? lo : base, b = hi < base + pn ? hi : base + pn;
-      if (a < b)
-        { const size_t bytes = (size_t) (b - a) * pbyte;
-          hipError_t he = hipMemcpy(d_rec + off, tv->part_data[p] + (size_t) (a - base) * pbyte, bytes, hipMemcpyHostToDevice);
-          if (he != hipSuccess) return he;
-          off += bytes;
-        }
-      base += pn;
-    }
-  return hipSuccess;
-}
 
 static int decode_at(smg_engine *e, int kmer, int ibyte, int64_t nels, int64_t ibase, const uint8_t *d_records,
                      const int64_t *d_prefix_index, char *errbuf, size_t errlen);
@@ -159,7 +141,7 @@ static void *multi_worker(void *argp)
 { MultiArg *arg = (MultiArg *) argp;
   MultiCtx *c = arg->c;
   const int r = arg->r, n = c->n, W = c->W;
-  const smg_table_view *tv = c->tv;
+  const smg_table_source *tv = c->tv;
   smg_engine *e = NULL;
   uint8_t *d_rec = NULL; int64_t *d_index = NULL, *d_plot = NULL;
   uint64_t *recv = NULL;
@@ -179,8 +161,8 @@ static void *multi_worker(void *argp)
           || hipMalloc(&d_plot, sizeof(int64_t) * SMG_PLOT_CELLS) != hipSuccess)
         MFAIL(SMG_ENOMEM, "out of device memory for the table shard");
     }
-  if (MOK && (multi_h2d_records(tv, c->pbyte, lo, hi, d_rec) != hipSuccess
-              || hipMemcpy(d_index, tv->prefix_index, ixbytes, hipMemcpyHostToDevice) != hipSuccess))
+  if (MOK && (c->rc[r] = ingest_records(tv, c->pbyte, lo, hi, d_rec, c->devs[r], c->io_threads, NULL, eb, el))) c->failed = 1;
+  if (MOK && hipMemcpy(d_index, tv->prefix_index, ixbytes, hipMemcpyHostToDevice) != hipSuccess)
     MFAIL(SMG_ENODEV, "host to device copy failed");
   if (MOK && (c->rc[r] = decode_at(e, tv->kmer, tv->ibyte, ns, lo, d_rec, d_index, eb, el))) c->failed = 1;
   if (d_rec) { hipFree(d_rec); d_rec = NULL; }
@@ -314,7 +296,7 @@ static void *multi_worker(void *argp)
 #undef MOK
 
 // cut points: about n*r/N, moved to a prefix-index boundary that is also a window-block boundary
-static void multi_cuts(const smg_table_view *tv, int n, int64_t *cut)
+static void multi_cuts(const smg_table_source *tv, int n, int64_t *cut)
 { const int64_t ixlen = 1ll << (8 * tv->ibyte);
   const int p0 = tv->kmer / 2, ib = 4 * tv->ibyte;          // bases in a window-block prefix / in an index bucket
   // an index bucket fixes the first `ib` bases; a window block the first `p0`: when ib > p0 only every
@@ -334,7 +316,7 @@ static void multi_cuts(const smg_table_view *tv, int n, int64_t *cut)
     }
 }
 
-static int host_run_multi(const smg_table_view *tv, const smg_opts *opts, int ngpus, int64_t *plot,
+static int host_run_multi(const smg_table_source *tv, const smg_opts *opts, int ngpus, bool force_virtual, int64_t *plot,
                           smg_stats *stats, char *errbuf, size_t errlen)
 { if (ngpus > SMG_MAXGPU) ngpus = SMG_MAXGPU;
   if ((opts->condition & SMG_COND_SYMM))
@@ -349,7 +331,9 @@ static int host_run_multi(const smg_table_view *tv, const smg_opts *opts, int ng
   c->W = (tv->kmer + 31) / 32;
   c->pbyte = ((tv->kmer + 3) >> 2) + 2 - tv->ibyte;
   c->plot = plot;
-  { const char *v = getenv("SMG_VIRTUAL_SHARDS"); c->virt = v && atoi(v) > 0; }
+  { const char *v = getenv("SMG_VIRTUAL_SHARDS"); c->virt = force_virtual || (v && atoi(v) > 0); }
+  c->io_threads = (tv->host_threads > 0 ? tv->host_threads : 4) / ngpus;
+  if (c->io_threads < 2) c->io_threads = 2;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
     { delete c; return fail(errbuf, errlen, SMG_ENODEV, "no HIP device available (this engine has no CPU fallback)%s"); }

@@ -272,7 +272,7 @@ def test_sharded_driver_on_the_real_backend_one_rank_group(k, symcheck, monkeypa
     import torch.distributed as dist
     from smudgeplot_amd import sharded
     packed, cnt = synth.adversarial_table(k, 6000, 4, 21, low_complexity=30, dense=1)
-    want = brute.hetmers_plot(packed, cnt, k) if k <= 31 else engine.hetmers_run(table_from(packed, cnt, k))[0]
+    want = brute.hetmers_plot(packed, cnt, k)
     words = (k + 31) // 32
     buf = np.zeros((len(cnt), 8 * words), dtype=np.uint8)              # left-aligned big-endian words
     buf[:, :packed.shape[1]] = packed
@@ -419,7 +419,7 @@ def test_manual_shards_with_an_empty_shard(k):
     """a rank that owns nothing still reports the block-map geometry of the others and joins the exchange"""
     import torch
     packed, cnt = synth.adversarial_table(k, 5000, 4, 33, low_complexity=20, dense=1)
-    want, _ = engine.hetmers_run(table_from(packed, cnt, k), symcheck="hash")
+    want = brute.hetmers_plot(packed, cnt, k)
     if k > 32:
         pytest.skip("_manual_sharded routes one-word k-mers")
     keys = ktab.packed_to_u64(packed)
@@ -580,12 +580,15 @@ def test_multi_gpu_path_medium_table_and_executable(tmp_path, monkeypatch):
     assert r.returncode == 0, r.stderr
     assert "  The input table is untrimmed yet symmetric\n" in r.stderr and "gpus=3" in r.stderr
     assert (tmp_path / "gpu2.smu").read_text() == (tmp_path / "orc2.smu").read_text()
-    # a table that is not closed: the multi-GPU path refuses it loudly (one GPU would take the general path)
+    # a table that is not closed: the shards notice (proof reduced over all of them), one GPU then takes the general
+    # path on the whole table -- the reference gives an answer for such a table, so must every configuration
     bad = np.ones(len(cnt), bool); bad[len(cnt) // 3] = False
+    ktab.write_ktab(str(tmp_path / "b"), k, packed[bad], cnt[bad], ibyte=2, nparts=2)
+    subprocess.run([ORACLE_BIN, "-e8", f"-o{tmp_path}/orcb", str(tmp_path / "b")], check=True)
     monkeypatch.setenv("SMG_VIRTUAL_SHARDS", "2")
-    with pytest.raises(engine.EngineError) as ei:
-        engine.hetmers_run(table_from(packed[bad], cnt[bad], k), symcheck="hash")
-    assert ei.value.code == -5
+    plot, st = engine.hetmers_run(table_from(packed[bad], cnt[bad], k), symcheck="hash")
+    assert st["path"] == 2
+    assert engine.smu_text(plot) == (tmp_path / "orcb.smu").read_text()
 
 
 def test_multi_gpu_path_one_rank_rccl(monkeypatch):
@@ -665,3 +668,173 @@ def test_standalone_conditioning_tool_writes_the_numpy_conditioned_table(tmp_pat
             assert "  The input table is trimmed and symmetric\n" in q.stderr
             assert (tmp_path / "ref.smu").read_text() == brute.smu_text(brute.hetmers_plot(cp, cc, k))
             os.remove(tmp_path / "ref.smu")
+
+
+# ---- tables beyond the 32-bit entry index of a shard: prefix shards on ONE device, automatically ------------------
+
+@pytest.mark.parametrize("nshards", [2, 5, 13])
+@pytest.mark.parametrize("name", ["k31_i1", "k31_i3_p4", "k21_i2_p2", "k51_i1_p3", "k32_i1_p2"])
+def test_tables_beyond_the_shard_limit_are_cut_into_shards_on_one_device(name, nshards, monkeypatch, tmp_path):
+    """the product path for tables of >= 2^32 entries (SMG_SHARD_LIMIT lowers the threshold so that the golden
+    vectors take it): host_run cuts the table itself, nobody has to ask for it"""
+    g = load_golden(name)
+    limit = len(g["counts"]) // nshards + 1
+    monkeypatch.setenv("SMG_SHARD_LIMIT", str(limit))
+    plot, st = engine.hetmers_run(make_table(g), symcheck="hash")
+    assert engine.smu_text(plot) == g["smu"]
+    assert st["nels"] == len(g["counts"])
+    ktab.write_ktab(str(tmp_path / "t"), g["k"], g["packed"], g["counts"], ibyte=g["ibyte"], nparts=g["nparts"])
+    r = subprocess.run([HETMERS_BIN, "-oout", f"-e{g['L']}", "-T4", "-v", "t.ktab"], cwd=tmp_path, capture_output=True, text=True,
+                       env=dict(os.environ, SMG_SHARD_LIMIT=str(limit)))
+    assert r.returncode == 0, r.stderr
+    assert f"{nshards} prefix shards on one device" in r.stderr
+    assert (tmp_path / "out.smu").read_text() == g["smu"]
+
+
+def _records_on_device(tk, tc, k):
+    """format F records (ibyte = 3) + prefix index of a device-resident one-word table, built with torch"""
+    import torch
+    assert k <= 31
+    n = tc.numel()
+    kb = (k + 3) // 4
+    hb = kb - 3
+    rec = torch.empty((n, hb + 2), dtype=torch.uint8, device=tk.device)
+    for j in range(hb):                                   # suffix bytes: bytes 3 .. kb-1 of the left-aligned k-mer
+        rec[:, j] = ((tk >> (8 * (7 - (3 + j)))) & 0xFF).to(torch.uint8)
+    c = tc.to(torch.int32) & 0xFFFF
+    rec[:, hb] = (c & 0xFF).to(torch.uint8)
+    rec[:, hb + 1] = (c >> 8).to(torch.uint8)
+    pre = (tk >> 40) & 0xFFFFFF
+    index = torch.cumsum(torch.bincount(pre, minlength=1 << 24), 0)
+    return rec, index.cpu().numpy().astype(np.int64)
+
+
+def _run_source_from_device(rec, index, k, n, limit=None):
+    """smg_hetmers_run_source with a read callback that copies the wanted records from the DEVICE tensor `rec`:
+    the table never exists in host memory, the engine's own ingestion path (pinned ring, H2D) is what runs"""
+    import ctypes as C
+    import torch
+    lib = engine.load_library()
+    hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    pb = rec.shape[1]
+    base = rec.data_ptr()
+    READ = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p)
+
+    def read(ctx, part, first, nent, dst):
+        return 0 if hip.hipMemcpy(dst, base + first * pb, nent * pb, 2) == 0 else -1      # 2 = device to host
+
+    class Source(C.Structure):
+        _fields_ = [("kmer", C.c_int32), ("ibyte", C.c_int32), ("nparts", C.c_int32), ("minval", C.c_int32),
+                    ("nels", C.c_int64), ("part_nels", C.POINTER(C.c_int64)), ("prefix_index", C.POINTER(C.c_int64)),
+                    ("read", READ), ("ctx", C.c_void_p), ("host_threads", C.c_int32)]
+    pn = (C.c_int64 * 1)(n)
+    cb = READ(read)
+    src = Source(k, 3, 1, 1, n, pn, index.ctypes.data_as(C.POINTER(C.c_int64)), cb, None, 4)
+    opts = engine.Opts(0, engine._SYM["hash"], 0, 0, 0, 0)
+    plot = np.zeros(engine.PLOT_CELLS, dtype=np.int64)
+    st = engine.Stats()
+    buf = C.create_string_buffer(512)
+    lib.smg_hetmers_run_source.argtypes = [C.c_void_p, C.POINTER(engine.Opts), C.c_void_p, C.POINTER(engine.Stats), C.c_char_p, C.c_size_t]
+    old = os.environ.get("SMG_SHARD_LIMIT")
+    if limit is not None:
+        os.environ["SMG_SHARD_LIMIT"] = str(limit)
+    try:
+        rc = lib.smg_hetmers_run_source(C.byref(src), C.byref(opts), plot.ctypes.data, C.byref(st), buf, 512)
+    finally:
+        if limit is not None:
+            if old is None:
+                del os.environ["SMG_SHARD_LIMIT"]
+            else:
+                os.environ["SMG_SHARD_LIMIT"] = old
+    assert rc == 0, buf.value
+    return plot.reshape(1001, 501), st.asdict()
+
+
+def test_table_source_with_the_reference_binary_as_judge(tmp_path):
+    """the twin of the big test below at 1/50 of its size: device generated table -> smg_hetmers_run_source (records
+    pulled from the device through the read callback) in 1, 2 and 3 shards, against the REFERENCE binary"""
+    import torch
+    from conftest import REF_BIN
+    from smudgeplot_amd import synth_device
+    if not os.path.exists(REF_BIN):
+        pytest.skip("prebuilt reference binary not present")
+    k = 31
+    dev = torch.device("cuda:0")
+    tk, tc = synth_device.diploid_table(35_000_000, k=k, het=0.01, cov=50.0, L=10, seed=5, device=dev)
+    n = tc.numel()
+    rec, index = _records_on_device(tk, tc, k)
+    plots = [_run_source_from_device(rec, index, k, n, limit)[0] for limit in (None, n // 2 + 1, n // 3 + 1)]
+    assert np.array_equal(plots[0], plots[1]) and np.array_equal(plots[0], plots[2])
+    synth.write_u64_table(str(tmp_path / "t"), tk.cpu().numpy().view(np.uint64), tc.cpu().numpy().view(np.uint16), k, ibyte=3, nparts=4)
+    r = subprocess.run([REF_BIN, "-e10", f"-T{min(64, os.cpu_count() or 1)}", "-oref", "t.ktab"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "ref.smu").read_text() == engine.smu_text(plots[0])
+    # and the drop-in executable on the same files (parts streamed from disk by 8 readers)
+    r = subprocess.run([HETMERS_BIN, "-e10", "-T4", "-v", "-ogpu", "t.ktab"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "gpu.smu").read_text() == (tmp_path / "ref.smu").read_text()
+
+
+def test_a_table_of_more_than_2_to_the_32_entries():
+    """4.4e9 entries (synthetic diploid 1.75 Gbp, k=31): more than a shard can index.  The records live in a device
+    tensor and reach the engine through the table-source callback, so the host holds nothing.  Checked: the automatic
+    2-shard run equals a 3-shard run (shard invariance), every cell off the self-mirrored diagonal is even (each pair
+    has a distinct mirror image on a closed table), and the pair count is 1.75x the 1 Gbp table's within 1 %."""
+    import torch
+    from smudgeplot_amd import synth_device
+    dev = torch.device("cuda:0")
+    free, total = torch.cuda.mem_get_info(dev)
+    if total < 250e9:
+        pytest.skip("needs a 288 GB device")
+    k = 31
+    tk, tc = synth_device.diploid_table(1_750_000_000, k=k, het=0.01, cov=50.0, L=10, seed=1, device=dev)
+    n = tc.numel()
+    assert n > (1 << 32)
+    rec, index = _records_on_device(tk, tc, k)
+    del tk, tc
+    torch.cuda.empty_cache()
+    p2, st2 = _run_source_from_device(rec, index, k, n)
+    p3, st3 = _run_source_from_device(rec, index, k, n, limit=n // 3 + 1)
+    assert st2["nels"] == n and st2["path"] == 1
+    assert np.array_equal(p2, p3)
+    # the plot counts a pair and its mirror image: odd cells can only come from self-mirrored pairs (position 15),
+    # of which there are few; their number is the same in both runs, and the total is plausible for the model
+    pairs = int(p2.sum())
+    assert 0.98 < pairs / (458466309 * 1.75) < 1.02, pairs
+
+
+def test_exact_proof_is_not_fooled_by_a_signature_twin():
+    """A closed table in which ONE complement is missing, while a k-mer with the same directory bucket, the same 16-bit
+    look-up signature and the same count stands where it would be (its SNP partner in the last base).  The look-ups of
+    the exact proof must compare the k-mer itself, not just signature and count: the table is not closed, the general
+    path has to run and give the reference's (= the brute force) answer."""
+    k = 31
+    keys, cnt = synth.diploid_table_u64(3000, k=k, seed=77, het_frac=0.3, cov=30, L=5)
+    rc = ktab.revcomp_u64(keys, k)
+    top = keys >> np.uint64(39)
+    uniq_top = np.ones(len(keys), bool)
+    uniq_top[1:] &= top[1:] != top[:-1]
+    uniq_top[:-1] &= top[:-1] != top[1:]
+    cand = np.flatnonzero((keys < rc) & uniq_top[np.searchsorted(keys, rc)])
+    for i in cand:
+        x, y = keys[i], rc[i]
+        yp = y ^ np.uint64(1 << 2)                                  # last base changed: same leading 25 bits
+        xp = ktab.revcomp_u64(np.array([yp], np.uint64), k)[0]
+        if yp in keys or xp in keys or yp == xp:
+            continue
+        c = cnt[i]
+        keep = keys != y
+        nk = np.concatenate([keys[keep], np.array([yp, xp], np.uint64)])
+        nc = np.concatenate([cnt[keep], np.array([c, c], np.uint16)])
+        o = np.argsort(nk)
+        nk, nc = nk[o], nc[o]
+        break
+    else:
+        pytest.fail("no suitable entry in the synthetic table")
+    packed = ktab.u64_to_packed(nk, k)
+    want = brute.hetmers_plot(packed, nc, k)
+    for mode in ("exact", "hash"):
+        plot, st = engine.hetmers_run(table_from(packed, nc, k), symcheck=mode)
+        assert st["path"] == 2, mode
+        assert np.array_equal(plot, want), mode
