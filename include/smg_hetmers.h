@@ -228,12 +228,19 @@ int     smg_engine_apply_own(smg_engine *e, int64_t *missing, char *errbuf, size
 int     smg_engine_blockmap(smg_engine *e, int *id_bits, int64_t *nwords);
 int     smg_engine_blockmap_copy(smg_engine *e, int64_t word_lo, int64_t nw, uint32_t *d_dst,
                                  char *errbuf, size_t errlen);
+/* the gathered word ranges of `nranks` shards -> one map: d_parts holds nranks slices of `width` words, slice r
+   covers the map words [word_lo[r], word_lo[r] + nwords_of[r]) (neighbours share their boundary word: OR, not
+   copy); d_full (the whole map, smg_engine_blockmap's nwords) is overwritten.  One kernel launch.           */
+int     smg_engine_merge_maps(smg_engine *e, const uint32_t *d_parts, int64_t width, int nranks,
+                              const int64_t *word_lo, const int64_t *nwords_of, uint32_t *d_full,
+                              char *errbuf, size_t errlen);
 int     smg_engine_filter(smg_engine *e, const uint32_t *d_map, int64_t *kept, char *errbuf, size_t errlen);
 /* optional, between pass1 and filter: start the part of the filter that does not need the map (long request
    lists are bucketed on their leading 8 bits so that the map probes stay in L2) -- a sharded run calls it
    while the block maps are in flight.  A no-op when there is nothing to do. */
 int     smg_engine_presort(smg_engine *e, char *errbuf, size_t errlen);
 int     smg_engine_symhash(smg_engine *e, uint64_t out[4], char *errbuf, size_t errlen);
+/* (smg_stats.npairs is left 0 by this entry: the caller sums the plot it reduces over the ranks anyway) */
 int     smg_engine_pass2(smg_engine *e, int64_t *d_plot, char *errbuf, size_t errlen);
 int     smg_engine_stats(smg_engine *e, smg_stats *stats);
 

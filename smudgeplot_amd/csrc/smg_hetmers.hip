@@ -1224,7 +1224,7 @@ static int fast_apply(smg_engine *e, const u64 *flat, int64_t nflat, int check_c
   return SMG_OK;
 }
 
-static int fast_pass2(smg_engine *e, int64_t *d_plot, char *errbuf, size_t errlen)
+static int fast_pass2(smg_engine *e, int64_t *d_plot, bool with_sum, char *errbuf, size_t errlen)
 { HIPCHK(hipMemsetAsync(d_plot, 0, sizeof(int64_t) * SMG_PLOT_CELLS, e->stream));
   FastArgs a = make_fast(e);
   hipEventRecord(e->ev[6], e->stream);
@@ -1237,7 +1237,9 @@ static int fast_pass2(smg_engine *e, int64_t *d_plot, char *errbuf, size_t errle
     }
   hipEventRecord(e->ev[7], e->stream);
   HIPCHK(hipGetLastError());
-  int rc = plot_sum(e, d_plot, errbuf, errlen);
+  int rc = SMG_OK;
+  if (with_sum) rc = plot_sum(e, d_plot, errbuf, errlen);           // (one more kernel and a host round trip)
+  else { e->st.npairs = 0; HIPCHK(hipEventSynchronize(e->ev[7])); }
   if (rc) return rc;
   float ms = 0; hipEventElapsedTime(&ms, e->ev[6], e->ev[7]);
   e->st.ms_pass2 = ms;
@@ -1294,6 +1296,42 @@ extern "C" int smg_engine_blockmap_copy(smg_engine *e, int64_t word_lo, int64_t 
     return fail(errbuf, errlen, SMG_EINVAL, "block map range out of bounds%s");
   HIPCHK(hipSetDevice(e->device));
   if (nw > 0) HIPCHK(hipMemcpyAsync(d_dst, e->bmap + word_lo, (size_t) nw * 4, hipMemcpyDeviceToDevice, e->stream));
+  return SMG_OK;
+}
+
+struct MapGeo { int64_t lo[16], ln[16]; };
+
+__global__ void __launch_bounds__(256)
+km_merge_maps(const uint32_t *__restrict__ parts, int64_t width, int nranks, MapGeo geo, uint32_t *__restrict__ full, int64_t nwords)
+{ __shared__ int64_t lo[16], ln[16];
+  if (threadIdx.x < 16) { lo[threadIdx.x] = geo.lo[threadIdx.x]; ln[threadIdx.x] = geo.ln[threadIdx.x]; }
+  __syncthreads();
+  for (int64_t w = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += (int64_t) gridDim.x * blockDim.x)
+    { uint32_t v = 0;
+      for (int r = 0; r < nranks; r++)
+        { const int64_t o = w - lo[r];
+          if (o >= 0 && o < ln[r]) v |= parts[(size_t) r * width + o];
+        }
+      full[w] = v;
+    }
+}
+
+extern "C" int smg_engine_merge_maps(smg_engine *e, const uint32_t *d_parts, int64_t width, int nranks,
+                                     const int64_t *word_lo, const int64_t *nwords_of, uint32_t *d_full,
+                                     char *errbuf, size_t errlen)
+{ NEED_FAST(e)
+  if (!e->prepared || !e->bm_bits) return fail(errbuf, errlen, SMG_EINVAL, "no block map: pass 1 (hash proof, k <= 64) has not run%s");
+  if (!d_parts || !d_full || !word_lo || !nwords_of || nranks < 1 || nranks > 16 || width < 1)
+    return fail(errbuf, errlen, SMG_EINVAL, "bad merge_maps arguments (1..16 ranks)%s");
+  const int64_t nwords = ((1ll << e->bm_bits) + 31) >> 5;
+  MapGeo geo;
+  for (int r = 0; r < 16; r++) { geo.lo[r] = r < nranks ? word_lo[r] : 0; geo.ln[r] = r < nranks ? nwords_of[r] : 0; }
+  for (int r = 0; r < nranks; r++)
+    if (geo.lo[r] < 0 || geo.ln[r] < 0 || geo.ln[r] > width || geo.lo[r] + geo.ln[r] > nwords)
+      return fail(errbuf, errlen, SMG_EINVAL, "block map range out of bounds%s");
+  HIPCHK(hipSetDevice(e->device));
+  hipLaunchKernelGGL(km_merge_maps, dim3(2048), dim3(256), 0, e->stream, d_parts, width, nranks, geo, d_full, nwords);
+  HIPCHK(hipGetLastError());
   return SMG_OK;
 }
 
@@ -1376,7 +1414,7 @@ extern "C" int smg_engine_pass2(smg_engine *e, int64_t *d_plot, char *errbuf, si
 { NEED_FAST(e)
   if (!e->prepared || !d_plot) return fail(errbuf, errlen, SMG_EINVAL, "pass2 before pass1%s");
   HIPCHK(hipSetDevice(e->device));
-  return fast_pass2(e, d_plot, errbuf, errlen);
+  return fast_pass2(e, d_plot, false, errbuf, errlen);
 }
 
 extern "C" int smg_engine_stats(smg_engine *e, smg_stats *stats)
@@ -1406,7 +1444,7 @@ extern "C" int smg_engine_run(smg_engine *e, int symcheck, int64_t *d_plot, smg_
       symmetric = (missing == 0);
       if (symmetric && symcheck == SMG_SYM_HASH)
         symmetric = e->fp[0] == e->fp[2] && e->fp[1] == e->fp[3];
-      if (symmetric && (rc = fast_pass2(e, d_plot, errbuf, errlen))) return rc;
+      if (symmetric && (rc = fast_pass2(e, d_plot, true, errbuf, errlen))) return rc;
     }
   else if (symcheck != SMG_SYM_NONE)
     { if ((rc = counted_symmetric(e, symcheck, d_plot, &symmetric, errbuf, errlen))) return rc; }
