@@ -38,16 +38,26 @@ def alg_bytes_per_kmer_pass(k):
     return (k + 3) // 4 + 2 + 1
 
 
-def cpu_baseline(sample_n0: int, k: int, L: int):
-    """Time the REFERENCE hetmers binary (oracle/_ref, compiled from the reference's own sources)
-    on a bounded sample of the same kind of table, on this box's host cores."""
+def cpu_baseline(sample_genome: int, k: int, L: int, dev, repeats: float):
+    """Time the REFERENCE hetmers binary (oracle/_ref, compiled from the reference's own sources) on a bounded sample
+    of the SAME workload -- the bench's own generator at 1/25 of the genome: ~1e8 table entries, ~6 s of wall time
+    at -T64 -- on this box's host cores.  (Round 1 timed a 2e7-entry table, on which the reference reaches 1.1e7
+    k-mers/s; on 1e8 entries it reaches 1.7e7 -- as on the 1e9-entry table of profiles/r02_e2e_1e9_entries.json.)"""
     ref = os.path.join(ROOT, "oracle", "_ref", "hetmers_ref")
     if not os.path.exists(ref):
         return None
     cores = min(64, os.cpu_count() or 1)
-    keys, cnt = synth.diploid_table_u64(sample_n0, k=k, seed=7, het_frac=0.3, cov=50.0, L=L)
+    if k <= 31:
+        tk, tc = synth_device.diploid_table(sample_genome, k=k, het=0.01, cov=50.0, L=L, seed=7, device=dev, repeats=repeats)
+        packed = ktab.u64_to_packed(tk.cpu().numpy().view(np.uint64), k)
+    else:
+        tk, tc = synth_device.diploid_table_wide(sample_genome, k=k, het=0.01, cov=50.0, L=L, seed=7, device=dev)
+        kw = tk.cpu().numpy().view(np.uint64).reshape(tc.numel(), -1)
+        packed = np.ascontiguousarray(np.ascontiguousarray(kw.astype(">u8")).view(np.uint8).reshape(len(kw), -1)[:, : (k + 3) // 4])
+    cnt = tc.cpu().numpy().view(np.uint16)
+    del tk, tc
     with tempfile.TemporaryDirectory(prefix="smg_cpu") as d:
-        synth.write_u64_table(os.path.join(d, "t"), keys, cnt, k, ibyte=3, nparts=4)
+        ktab.write_ktab(os.path.join(d, "t"), k, packed, cnt, ibyte=3, nparts=4)
         best = None
         for _ in range(2):                       # second run = warm page cache
             out = os.path.join(d, "cpu.smu")
@@ -58,8 +68,8 @@ def cpu_baseline(sample_n0: int, k: int, L: int):
                            capture_output=True)
             best = time.time() - t0
     return {"value": len(cnt) / best, "unit": "k-mers/s", "cores": cores, "kind": "reference",
-            "sample": f"reference hetmers -T{cores} on a {len(cnt)}-entry synthetic diploid k={k} "
-                      f"table (warm second run, {best:.1f} s wall)"}
+            "sample": f"reference hetmers -T{cores} on a {len(cnt)}-entry table of the same generator "
+                      f"(genome {sample_genome} bp, k={k}; warm second run, {best:.1f} s wall)"}
 
 
 def main():
@@ -71,8 +81,11 @@ def main():
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--L", type=int, default=10)
     ap.add_argument("--symcheck", default="hash", choices=["exact", "hash"])
-    ap.add_argument("--cpu-sample", type=int, default=8_000_000)
+    ap.add_argument("--cpu-sample", type=float, default=0, help="genome size of the CPU baseline's sample (default: genome / 25)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--workload", default="uniform", choices=["uniform", "repeats"],
+                    help="uniform: BASELINE configs[2] (uniform random genome); repeats: 5 %% of the genome are dispersed / "
+                         "tandem repeats and homopolymer runs (exercises kf_bigfix and the repeat tail of the plot)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -90,8 +103,9 @@ def main():
 
     # ---- workload: identical table on every rank, then keep this rank's prefix shard ----------
     G = int(args.genome)
+    repeats = 0.05 if args.workload == "repeats" else 0.0
     if args.k <= 31:
-        keys, cnt = synth_device.diploid_table(G, k=args.k, het=0.01, cov=50.0, L=args.L, seed=1, device=dev)
+        keys, cnt = synth_device.diploid_table(G, k=args.k, het=0.01, cov=50.0, L=args.L, seed=1, device=dev, repeats=repeats)
     else:                                  # two-word k-mers (BASELINE configs[4] is k=51); keys is [n, 2]
         keys, cnt = synth_device.diploid_table_wide(G, k=args.k, het=0.01, cov=50.0, L=args.L, seed=1, device=dev)
     n_total = cnt.numel()
@@ -159,9 +173,9 @@ def main():
     # short launches (compact, 4 radix passes, in-order look-ups), each well below pass 1
     tf = lambda b: "true" if b else "false"                                   # noqa: E731
     if args.k <= 32:
-        p1 = "kf_pass1_r<1, %d, %s, %s>" % (1 if args.symcheck == "hash" else 2, tf(args.k & 1), tf(17 <= args.k))
+        p1 = "kf_pass1_d<1, %d, %s, %s>" % (1 if args.symcheck == "hash" else 2, tf(args.k & 1), tf(17 <= args.k))
     elif args.k <= 64:
-        p1 = "kf_pass1_r<2, 3, %s, false>" % tf(args.k & 1)
+        p1 = "kf_pass1_d<2, 3, %s, false>" % tf(args.k & 1)
     else:
         p1 = "kf_pass1<3>"
     single = {"ms_pass1": p1, "ms_pass2": "kf_pass2<%d>" % ((args.k + 31) // 32)}
@@ -172,27 +186,33 @@ def main():
     if os.path.exists(tj):
         with open(tj) as f:
             t = json.load(f)
-        if dom in t.get("bytes_per_entry", {}) and t.get("k") == args.k:
+        t = t.get("k%d" % args.k, {})
+        if dom in t.get("bytes_per_entry", {}):
             traffic = t["bytes_per_entry"][dom] * n_local
             traffic_src = t.get("source")
 
     if rank == 0:
         # the CPU baseline is timed on rank 0 of the single-GPU run only (it takes ~25 s of host time)
-        cpu = None if (args.no_cpu or world > 1 or args.k > 32) else cpu_baseline(args.cpu_sample, args.k, args.L)
+        cpu = None
+        if not (args.no_cpu or world > 1):
+            cpu = cpu_baseline(int(args.cpu_sample) if args.cpu_sample else max(G // 25, 100000), args.k, args.L, dev, repeats)
         value = n_total * args.steps / dt
         out = {
             "metric": "k-mers/sec through hetmers (k=%d)" % args.k,
             "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u64" if args.k <= 32 else "u64x%d" % ((args.k + 31) // 32), "data": "synthetic",
-            "config": {"workload": f"synthetic diploid {G:.3g} bp, 50x, 1% het, k={args.k}, L={args.L}: "
-                                   f"{n_total} table entries (conditioned, rc-closed)",
+            "config": {"workload": f"synthetic diploid {G:.3g} bp, 50x, 1% het, k={args.k}, L={args.L}"
+                                   + (", 5% of the genome repeats (dispersed, tandem, homopolymer)" if repeats else "")
+                                   + f": {n_total} table entries (conditioned, rc-closed)",
                        "symcheck": args.symcheck, "sharding": f"prefix x{world}"},
             "roofline": {"bound": "hbm", "kernel": single[dom],
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg[dom], "kernel_ms": ms,
-                         "requests": {"emitted": nreq, "kept_by_filter": nkept, "ms_filter": ms_filter},
+                         "requests": {"emitted": nreq, "kept_by_filter": nkept, "ms_partition": ms_filter},
+                         "deferred_entries": {"count": float(np.mean([s.get("nbig", 0) for s in eng_stats])),
+                                              "ms_bigfix": float(np.mean([s.get("ms_bigfix", 0.0) for s in eng_stats]))},
                          "lookup_phase_GBps": alg["ms_rclookup"] / (ms["ms_rclookup"] * 1e-3) / 1e9
                          if ms["ms_rclookup"] > 0 else 0.0,
                          "whole_job_frac_of_22B_roofline":

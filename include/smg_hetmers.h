@@ -112,6 +112,9 @@ typedef struct smg_stats
   double  ms_total;      /* decode .. histogram on device (no H2D)                           */
   int64_t nemitted;      /* complement requests pass 1 emitted (before the request filter)   */
   double  ms_filter;     /* request filter (also counted in ms_rclookup)                     */
+  int64_t nbig;          /* entries whose window block outgrew the +-30 entry window (redone   */
+                         /* exactly by kf_bigfix: low-complexity / repeat k-mers)              */
+  double  ms_bigfix;     /* ... and the time of that (also counted in ms_pass1)                */
 } smg_stats;
 
 /* ---- one-shot entry: host FastK table -> plot ------------------------------------------
@@ -225,6 +228,10 @@ int     smg_engine_apply_own(smg_engine *e, int64_t *missing, char *errbuf, size
    the device and pass that to filter, then route().  id_bits = 0: no map (exact proof or k > 64).
    No counterpart in the reference (it has no complement look-ups at all: PloidyPlot.c scans every
    position of every k-mer). */
+/* id bits of the block map that the NEXT smg_engine_pass1 builds (8..32; 0 = the default: 30, what a sharded run
+   exchanges -- 128 MB in total).  A caller that will not exchange maps (one rank) asks for 32: four times fewer
+   requests survive the filter, at the price of a 512 MB map that only this GPU ever reads.                    */
+int     smg_engine_set_blockmap_bits(smg_engine *e, int id_bits);
 int     smg_engine_blockmap(smg_engine *e, int *id_bits, int64_t *nwords);
 int     smg_engine_blockmap_copy(smg_engine *e, int64_t word_lo, int64_t nw, uint32_t *d_dst,
                                  char *errbuf, size_t errlen);

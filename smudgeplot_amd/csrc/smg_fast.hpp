@@ -319,8 +319,11 @@ template <int W> SMG_DEV int64_t sig_find(const FastArgs &A, const Key<W> &y, bo
   int64_t j = lo;
   if (j >= bhi || A.sig[j] != sy) return -1;
   if (j + 1 < bhi && A.sig[j + 1] == sy)             // several entries share the signature: compare k-mers
-    { int64_t e2 = j + 1;
-      while (e2 < bhi && A.sig[e2] == sy) e2++;
+    { int64_t e2 = j + 1, eh = bhi;                   // end of the run of equal signatures: bisection (repeat-rich
+      while (e2 < eh)                                 // tables hold runs of 1e5 entries: a linear walk took seconds)
+        { const int64_t m = (e2 + eh) >> 1;
+          if (A.sig[m] <= sy) e2 = m + 1; else eh = m;
+        }
       j = lower_bound_key<W>(A.keys, j, e2, y);
       if (j >= e2 || !key_eq<W>(load_key<W>(A.keys, j), y)) return -1;
     }

@@ -425,6 +425,7 @@ struct smg_engine
   u64         *boff;       //   bucket offsets [L_BK + 1] and scatter cursors [L_BK] behind them
   LookupGeo    lg;         //   geometry of the current run (lg.nb = 0: the round-1 chain is used)
   int          bm_cap;     //   id bits of the block map: 32 on one GPU, 30 when the maps of several shards are exchanged
+  int          bm_want;    //   ... as asked for by smg_engine_set_blockmap_bits (0: default)
   P1Cold      *p1cold;     // rarely used arguments of kf_pass1_d (device copy)
   P1Cold      *h_p1cold;   // pinned staging
   u64         *d_split;
@@ -926,6 +927,7 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
           if (fb > 256) fb = 256;
 #define BIGFIX(W_, RW_) hipLaunchKernelGGL((kf_bigfix<W_, RW_>), dim3(fb), dim3(F_TPB), 0, e->stream, a, e->biglist, nbig, e->req, \
                               e->chunk_fill, maxc, &e->ctrl->fast, e->lg.nb ? e->ghist : (unsigned *) NULL, e->lg.nb)
+          hipEventRecord(e->ev[0], e->stream);
           if (e->W == 2) BIGFIX(2, 3); else if (e->rw == 1) BIGFIX(1, 1); else BIGFIX(1, 2);
 #undef BIGFIX
           hipEventRecord(e->ev[3], e->stream);
@@ -948,6 +950,9 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
   e->st.nrequests = (int64_t) e->h_ctrl->fast.nreq;
   e->st.nemitted = e->st.nrequests;
   e->st.ms_filter = 0;
+  e->st.nbig = narrow ? (int64_t) e->h_ctrl->fast.nbig : 0;
+  e->st.ms_bigfix = 0;
+  if (e->st.nbig > 0) { float mb = 0; hipEventElapsedTime(&mb, e->ev[0], e->ev[3]); e->st.ms_bigfix = mb; }
   e->prepared = true;
   return SMG_OK;
 }
@@ -1258,7 +1263,7 @@ extern "C" int smg_engine_pass1(smg_engine *e, int symcheck, char *errbuf, size_
 { NEED_FAST(e)
   HIPCHK(hipSetDevice(e->device));
   e->st.ms_rclookup = 0;
-  e->bm_cap = 30;                            // the maps of the shards are exchanged: 128 MB in total
+  e->bm_cap = e->bm_want ? e->bm_want : 30;  // default: the maps of the shards are exchanged, 128 MB in total
   return fast_pass1(e, symcheck == SMG_SYM_EXACT, symcheck == SMG_SYM_EXACT, symcheck == SMG_SYM_HASH, errbuf, errlen);
 }
 
@@ -1278,6 +1283,12 @@ extern "C" int smg_engine_apply_own(smg_engine *e, int64_t *missing, char *errbu
   if (!e->prepared) return fail(errbuf, errlen, SMG_EINVAL, "apply before pass1%s");
   HIPCHK(hipSetDevice(e->device));
   return fast_apply(e, NULL, 0, 1, missing, errbuf, errlen);
+}
+
+extern "C" int smg_engine_set_blockmap_bits(smg_engine *e, int id_bits)
+{ if (!e || (id_bits != 0 && (id_bits < 8 || id_bits > 32))) return SMG_EINVAL;
+  e->bm_want = id_bits;
+  return SMG_OK;
 }
 
 extern "C" int smg_engine_blockmap(smg_engine *e, int *id_bits, int64_t *nwords)

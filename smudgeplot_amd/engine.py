@@ -51,7 +51,7 @@ class Stats(C.Structure):
                 ("path", C.c_int32), ("key_words", C.c_int32),
                 ("ms_h2d", C.c_double), ("ms_decode", C.c_double), ("ms_pass1", C.c_double),
                 ("ms_rclookup", C.c_double), ("ms_pass2", C.c_double), ("ms_total", C.c_double),
-                ("nemitted", C.c_int64), ("ms_filter", C.c_double)]
+                ("nemitted", C.c_int64), ("ms_filter", C.c_double), ("nbig", C.c_int64), ("ms_bigfix", C.c_double)]
 
     def asdict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -62,7 +62,7 @@ EXPORTS = [
     "smg_engine_decode", "smg_engine_bind", "smg_engine_condition", "smg_engine_run", "smg_engine_pass1",
     "smg_engine_nreq", "smg_engine_record_words", "smg_engine_route", "smg_engine_apply",
     "smg_engine_apply_own", "smg_engine_blockmap", "smg_engine_blockmap_copy", "smg_engine_filter",
-    "smg_engine_presort",
+    "smg_engine_presort", "smg_engine_merge_maps", "smg_engine_set_blockmap_bits",
     "smg_engine_symhash", "smg_engine_pass2", "smg_engine_stats",
     "smg_engine_extract", "smg_hetmers_extract", "smg_free", "smg_condition_table", "smg_version",
 ]
@@ -128,6 +128,8 @@ def load_library():
     lib.smg_engine_blockmap_copy.argtypes = [vp, i64, i64, vp, *err]
     lib.smg_engine_filter.argtypes = [vp, vp, C.POINTER(i64), *err]
     lib.smg_engine_presort.argtypes = [vp, *err]
+    lib.smg_engine_set_blockmap_bits.argtypes = [vp, i32]
+    lib.smg_engine_merge_maps.argtypes = [vp, vp, i64, i32, C.POINTER(i64), C.POINTER(i64), vp, *err]
     lib.smg_engine_symhash.argtypes = [vp, C.POINTER(C.c_uint64), *err]
     lib.smg_engine_pass2.argtypes = [vp, vp, *err]
     lib.smg_engine_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -322,6 +324,16 @@ class Engine:
 
     def presort(self):
         _check(self.lib.smg_engine_presort(self.h, self._buf, 512), self._buf)
+
+    def set_blockmap_bits(self, bits: int):
+        self.lib.smg_engine_set_blockmap_bits(self.h, bits)
+
+    def merge_maps(self, parts_ptr: int, width: int, word_lo, nwords_of, full_ptr: int):
+        """gathered word ranges of len(word_lo) shards -> the whole map at full_ptr (one kernel launch)"""
+        n = len(word_lo)
+        lo = (C.c_int64 * n)(*[int(v) for v in word_lo])
+        ln = (C.c_int64 * n)(*[int(v) for v in nwords_of])
+        _check(self.lib.smg_engine_merge_maps(self.h, parts_ptr, width, n, lo, ln, full_ptr, self._buf, 512), self._buf)
 
     def filter(self, map_ptr=None) -> int:
         kept = C.c_int64(0)

@@ -51,7 +51,9 @@ class TorchEngine:
         self._keep = (keys, counts)
         self.e.bind(k, counts.numel(), keys.data_ptr(), counts.data_ptr())
 
-    def pass1(self, symcheck):
+    def pass1(self, symcheck, exchange=True):
+        # nobody to exchange block maps with: the finest map (32 id bits) costs nothing but its memset
+        self.e.set_blockmap_bits(0 if exchange else 32)
         self.e.pass1(symcheck)
 
     def nreq(self):
@@ -77,6 +79,14 @@ class TorchEngine:
 
     def presort(self):
         self.e.presort()
+
+    def merge_maps(self, parts, width, wlo, wlen, full):
+        self.e.merge_maps(parts.data_ptr(), width, wlo, wlen, full.data_ptr())
+
+    def run_general(self, k, keys, counts, plot):
+        """the assumption-free all-positions path on a whole table (what one GPU does when the proof fails)"""
+        self.e.bind(k, counts.numel(), keys.data_ptr(), counts.data_ptr())
+        return self.e.run(plot.data_ptr(), "none")
 
     def filter(self, full_map=None):
         return self.e.filter(None if full_map is None else full_map.data_ptr())
@@ -130,8 +140,37 @@ def blockmap_ranges(splitters, words: int, world: int, bits: int):
     return wlo, wlen
 
 
+def _general_on_rank0(k, keys, counts, sizes, eng, plot, group, rank, world, words):
+    """The table failed the symmetry proof: the shards cannot help each other (a pair's mirror image may be
+    missing), so rank 0 collects the table and runs the general all-positions path, like a single GPU would; every
+    rank gets the plot.  The reference gives an answer for such a table (PloidyPlot.c scans every position of every
+    k-mer), so must the sharded run."""
+    dev = keys.device
+    if world > 1:
+        if rank == 0:
+            ks, cs = [keys], [counts]
+            for r in range(1, world):
+                if sizes[r]:
+                    kr = torch.empty(sizes[r] * words, dtype=keys.dtype, device=dev)
+                    cr = torch.empty(sizes[r], dtype=counts.dtype, device=dev)
+                    dist.recv(kr, src=r, group=group)
+                    dist.recv(cr, src=r, group=group)
+                    ks.append(kr); cs.append(cr)
+            keys, counts = torch.cat(ks), torch.cat(cs)
+        elif counts.numel():
+            dist.send(keys.contiguous(), dst=0, group=group)
+            dist.send(counts.contiguous(), dst=0, group=group)
+    if rank == 0:
+        eng._general_keep = (keys, counts)
+        eng.run_general(k, keys, counts, plot)
+    else:
+        plot.zero_()
+    if world > 1:
+        dist.broadcast(plot, src=0, group=group)
+
+
 def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: str = "hash",
-                    engine_factory=TorchEngine, group=None, eng=None):
+                    engine_factory=TorchEngine, group=None, eng=None, fallback: bool = True):
     """Run hetmers on this rank's shard; returns (plot int64[1001*501] on the shard's device,
     summed over all ranks, and a stats dict).  Collective: every rank must call it.
 
@@ -139,6 +178,8 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
     counts : int16 tensor viewing the shard's uint16 counts (n)
     eng    : an engine from a previous call on the same shard (its device buffers are reused;
              allocation is set-up cost, not part of a step)
+    fallback: a table that fails the symmetry proof is collected on rank 0 and run through the general path
+             (False: raise NotSymmetric instead)
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -158,7 +199,7 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
     tag = (keys.data_ptr(), n, world, rank)
     cached = getattr(eng, "_splitter_cache", None)
     if cached is not None and cached[0] == tag:
-        splitters = cached[1]
+        splitters, sizes = cached[1], cached[2]
     elif exchange:
         first = torch.full((words,), -1, dtype=torch.int64, device=dev)       # all ones = +inf
         if n > 0:
@@ -174,11 +215,11 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
             if sizes[r] == 0:
                 firsts[r] = firsts[r + 1]
         splitters = np.concatenate(firsts[1:]) if world > 1 else np.zeros(0, np.uint64)
-        eng._splitter_cache = (tag, splitters)
+        eng._splitter_cache = (tag, splitters, sizes)
     else:
-        splitters = np.zeros(0, np.uint64)
+        splitters, sizes = np.zeros(0, np.uint64), [n]
 
-    eng.pass1(symcheck)
+    eng.pass1(symcheck, exchange) if engine_factory is TorchEngine or isinstance(eng, TorchEngine) else eng.pass1(symcheck)
     rw = eng.record_words()
     nreq = eng.nreq()
 
@@ -187,17 +228,23 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
         if bits:
             wlo, wlen = blockmap_ranges(splitters, words, world, bits)
             width = max(wlen)
-            mine = torch.zeros(width, dtype=torch.int32, device=dev)
+            # the three map buffers live as long as the engine (a fresh 128 MB torch.zeros per step is a memset and
+            # an allocator round trip; the merge kernel overwrites every word of `full`)
+            mk = (bits, world, width)
+            bufs = getattr(eng, "_map_bufs", None)
+            if bufs is None or bufs[0] != mk:
+                bufs = (mk, torch.zeros(width, dtype=torch.int32, device=dev),
+                        torch.empty(world * width, dtype=torch.int32, device=dev),
+                        torch.empty(nwords, dtype=torch.int32, device=dev))
+                eng._map_bufs = bufs
+            _, mine, parts, full = bufs
             eng.blockmap_copy(wlo[rank], wlen[rank], mine)
-            parts = torch.empty(world * width, dtype=torch.int32, device=dev)
             work = dist.all_gather_into_tensor(parts, mine, group=group, async_op=True)
             eng.presort()          # the map-independent half of the filter runs while the maps are in flight
             work.wait()
-            full = torch.zeros(nwords, dtype=torch.int32, device=dev)
-            for r in range(world):                  # ranges of neighbours share their boundary word: OR, not copy
-                full[wlo[r]: wlo[r] + wlen[r]] |= parts[r * width: r * width + wlen[r]]
+            # ranges of neighbours share their boundary word: the merge ORs them (one launch)
+            eng.merge_maps(parts, width, wlo, wlen, full)
             nreq = eng.filter(full)
-            del parts, full, mine
         send = torch.empty(max(nreq, 1) * rw, dtype=torch.int64, device=dev)
         send_counts = eng.route(splitters, world, send)
         sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
@@ -228,8 +275,13 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
     if symcheck == "hash":
         symmetric = symmetric and pv[1] == pv[3] and pv[2] == pv[4]
     if not symmetric:
-        raise NotSymmetric("table is not closed under reverse complement with equal counts; "
-                           "run the single-GPU engine (general path) or condition the table")
+        if not fallback:
+            raise NotSymmetric("table is not closed under reverse complement with equal counts; "
+                               "run the single-GPU engine (general path) or condition the table")
+        _general_on_rank0(k, keys, counts, sizes, eng, plot, group, rank, world if exchange else 1, words)
+        eng._splitter_cache = None          # (rank 0's engine is bound to the gathered table now)
     st = eng.stats()
     st.update(rank=rank, world=world, shard_nels=n, sent=nreq if exchange else 0, received=nrecv, engine=eng)
+    if not symmetric:
+        st["path"] = 2
     return plot, st

@@ -48,14 +48,50 @@ def _mix(z: torch.Tensor) -> torch.Tensor:
     return z ^ ((z >> 31) & 0x1FFFFFFFF)
 
 
+def _plant_repeats(h1: torch.Tensor, frac: float, gen) -> None:
+    """Overwrite about `frac` of the haploid genome with the three kinds of repeats real genomes have (SURVEY.md
+    section 8d, value distributions 4 and 5): copies of one 3 kb unit with 2 % divergence (dispersed repeats), short
+    motifs repeated in tandem, and homopolymer runs.  They give the engine what a uniform random genome never does:
+    k-mers with many one-away neighbours, window blocks far beyond the +-30 entry window (kf_bigfix), counts in
+    the repeat tail of the plot (global atomics instead of the LDS tile)."""
+    G, dev = h1.numel(), h1.device
+    if frac <= 0 or G < 200000:
+        return
+    ar = torch.arange(3000, device=dev)
+    # dispersed: frac/2 of the genome
+    unit = torch.randint(0, 4, (3000,), dtype=torch.uint8, device=dev, generator=gen)
+    ncopy = max(int(G * frac / 2 / 3000), 2)
+    starts = torch.randint(0, G - 3000, (ncopy,), device=dev, generator=gen)
+    idx = (starts[:, None] + ar[None, :]).reshape(-1)
+    mut = torch.rand(idx.numel(), device=dev, generator=gen) < 0.02
+    val = unit.repeat(ncopy)
+    val = torch.where(mut, (val + torch.randint(1, 4, (idx.numel(),), dtype=torch.uint8, device=dev, generator=gen)) & 3, val)
+    h1[idx] = val
+    # tandem: frac/4, segments of 1000 bases, motif length 2..24
+    nseg = max(int(G * frac / 4 / 1000), 1)
+    starts = torch.randint(0, G - 1000, (nseg,), device=dev, generator=gen)
+    mlen = torch.randint(2, 25, (nseg,), device=dev, generator=gen)
+    motif = torch.randint(0, 4, (nseg, 24), dtype=torch.uint8, device=dev, generator=gen)
+    pos = ar[None, :1000] % mlen[:, None]
+    h1[(starts[:, None] + ar[None, :1000]).reshape(-1)] = torch.gather(motif, 1, pos).reshape(-1)
+    # homopolymers: frac/4, runs of 300
+    nrun = max(int(G * frac / 4 / 300), 1)
+    starts = torch.randint(0, G - 300, (nrun,), device=dev, generator=gen)
+    base = torch.randint(0, 4, (nrun,), dtype=torch.uint8, device=dev, generator=gen)
+    h1[(starts[:, None] + ar[None, :300]).reshape(-1)] = base[:, None].expand(nrun, 300).reshape(-1)
+
+
 def diploid_table(G: int, k: int = 31, het: float = 0.01, cov: float = 50.0, L: int = 10,
-                  seed: int = 1, device="cuda", chunks: int = 1):
+                  seed: int = 1, device="cuda", chunks: int = 1, repeats: float = 0.0):
     """-> (keys int64 viewing LEFT-aligned uint64 k-mers, sorted as unsigned; counts int16
-    viewing uint16).  k <= 31 so the right-aligned value is non-negative and sorts correctly."""
+    viewing uint16).  k <= 31 so the right-aligned value is non-negative and sorts correctly.
+    repeats > 0: that fraction of the genome is repeats (see _plant_repeats) and a k-mer's coverage scales with
+    its copy number."""
     assert k <= 31
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
     h1 = torch.randint(0, 4, (G,), dtype=torch.uint8, device=device, generator=gen)
+    _plant_repeats(h1, repeats, gen)
     snp = torch.rand(G, device=device, generator=gen) < het
     delta = torch.randint(1, 4, (G,), dtype=torch.uint8, device=device, generator=gen)
     h2 = torch.where(snp, (h1 + delta) & 3, h1)
@@ -89,8 +125,11 @@ def diploid_table(G: int, k: int = 31, het: float = 0.01, cov: float = 50.0, L: 
         u1 = u1 - torch.floor(u1); u2 = u2 - torch.floor(u2)
         z = torch.sqrt(-2.0 * torch.log(u1.clamp_min(1e-300))) * torch.cos(2 * math.pi * u2)
         del u1, u2
-        mean = torch.where(mult >= 2, torch.tensor(float(cov), device=device, dtype=torch.float64),
-                           torch.tensor(float(cov) / 2, device=device, dtype=torch.float64))
+        if repeats > 0:         # copy number: every occurrence in either haplotype (on either strand) adds cov / 2
+            mean = (float(cov) / 2) * mult.clamp(max=1200).to(torch.float64)
+        else:
+            mean = torch.where(mult >= 2, torch.tensor(float(cov), device=device, dtype=torch.float64),
+                               torch.tensor(float(cov) / 2, device=device, dtype=torch.float64))
         cnt = torch.round(mean + torch.sqrt(mean) * z).clamp_(L, 32767).to(torch.int16)
         del z, mean, mult
         key_parts.append(keys)

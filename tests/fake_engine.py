@@ -1,10 +1,11 @@
 """Numpy stand-in for `smudgeplot_amd.sharded.TorchEngine` -- TEST INFRASTRUCTURE ONLY.
 
-It implements the same phase protocol (bind / pass1 / route / apply / symhash / pass2) on CPU
-tensors with brute-force numpy, so that the world_size>1 orchestration of
-`sharded.hetmers_sharded` (splitter exchange, all_to_all of the complement requests, symmetry
-proof all_reduce, histogram all_reduce) can run under the `gloo` backend without a GPU.
-k <= 32 only (one 64-bit word per k-mer).  The product path never imports this module.
+It implements the same phase protocol (bind / pass1 / blockmap / filter / route / apply / symhash / pass2, and the
+general-path fallback) on CPU tensors with brute-force numpy, so that the world_size>1 orchestration of
+`sharded.hetmers_sharded` (splitter exchange, block-map all_gather, all_to_all of the complement requests,
+symmetry proof + histogram all_reduce, gather for the fallback) can run under the `gloo` backend without a GPU.
+Any k <= 128: a k-mer is handled as a Python integer of 64 * W bits (left aligned, like the engine's W words).
+The product path never imports this module.
 """
 import numpy as np
 import torch
@@ -14,83 +15,112 @@ from smudgeplot_amd import ktab
 SMAX, FMAX = 1000, 500
 PLOT_COLS = FMAX + 1
 PLOT_CELLS = (SMAX + 1) * PLOT_COLS
+M64 = (1 << 64) - 1
 
 
 def _mix(z):
-    z = z.astype(np.uint64)
-    z ^= z >> np.uint64(30); z *= np.uint64(0xbf58476d1ce4e5b9)
-    z ^= z >> np.uint64(27); z *= np.uint64(0x94d049bb133111eb)
-    return z ^ (z >> np.uint64(31))
+    z &= M64
+    z ^= z >> 30; z = (z * 0xbf58476d1ce4e5b9) & M64
+    z ^= z >> 27; z = (z * 0x94d049bb133111eb) & M64
+    return z ^ (z >> 31)
 
 
 class NumpyEngine:
     def __init__(self, device):
         self.device = device
 
+    # ---- helpers on integer k-mers ------------------------------------------------------------------
+    def _ints(self, words_u64):
+        w = np.asarray(words_u64, dtype=np.uint64).reshape(-1, self.W)
+        out = np.empty(len(w), dtype=object)
+        for i in range(len(w)):
+            v = 0
+            for j in range(self.W):
+                v = (v << 64) | int(w[i, j])
+            out[i] = v
+        return out
+
+    def _words(self, x):
+        return [(x >> (64 * (self.W - 1 - j))) & M64 for j in range(self.W)]
+
+    def _rc(self, x):
+        k, bits = self.k, 64 * self.W
+        v = x >> (bits - 2 * k)                       # right aligned
+        r = 0
+        for _ in range(k):
+            r = (r << 2) | (3 - (v & 3))
+            v >>= 2
+        return r << (bits - 2 * k)
+
     def bind(self, k, keys, counts):
-        assert k <= 32
         self.k = k
-        self.keys = keys.cpu().numpy().view(np.uint64).copy()
+        self.W = (k + 31) // 32
+        self.keys = self._ints(keys.cpu().numpy().view(np.uint64))
         self.cnt = counts.cpu().numpy().view(np.uint16).astype(np.int64)
         self.n = len(self.cnt)
 
     def record_words(self):
-        return 2
+        return self.W + 1
 
     def pass1(self, symcheck):
         k, keys, cnt, n = self.k, self.keys, self.cnt, self.n
+        bits = 64 * self.W
         p0 = k // 2
         s_all = np.zeros(n, np.int64)
         s_hi = np.zeros(n, np.int64)
         pa, pb, ph = [], [], []
         for p in range(p0, k):
-            m = keys & ~(np.uint64(3) << np.uint64(62 - 2 * p))
-            order = np.argsort(m, kind="stable")
-            ms = m[order]
-            for d in (1, 2, 3):
-                if n <= d:
-                    continue
-                same = ms[d:] == ms[:-d]
-                a, b = order[:-d][same], order[d:][same]
-                ok = cnt[a] + cnt[b] <= SMAX
-                a, b = a[ok], b[ok]
-                hi = int(p != k - 1 - p)
-                np.add.at(s_all, a, 1); np.add.at(s_all, b, 1)
-                np.add.at(s_hi, a, hi); np.add.at(s_hi, b, hi)
-                pa.append(a); pb.append(b); ph.append(np.full(len(a), hi, np.int64))
-        self.pa = np.concatenate(pa) if pa else np.zeros(0, np.int64)
-        self.pb = np.concatenate(pb) if pb else np.zeros(0, np.int64)
-        self.ph = np.concatenate(ph) if ph else np.zeros(0, np.int64)
+            mask = ~(3 << (bits - 2 - 2 * p))
+            groups = {}
+            for i in range(n):
+                groups.setdefault(keys[i] & mask, []).append(i)
+            hi = int(p != k - 1 - p)
+            for g in groups.values():
+                for x in range(len(g)):
+                    for y in range(x + 1, len(g)):
+                        a, b = g[x], g[y]
+                        if cnt[a] + cnt[b] <= SMAX:
+                            s_all[a] += 1; s_all[b] += 1
+                            s_hi[a] += hi; s_hi[b] += hi
+                            pa.append(a); pb.append(b); ph.append(hi)
+        self.pa = np.array(pa, np.int64); self.pb = np.array(pb, np.int64); self.ph = np.array(ph, np.int64)
         self.s_all = s_all
         self.P = np.zeros(n, np.int64)
+        self.rc = [self._rc(x) for x in keys]
         emit = np.ones(n, bool) if symcheck == "exact" else s_hi > 0
-        rc = ktab.revcomp_u64(keys, k)
-        self.req = np.stack([rc[emit], (cnt[emit] | ((s_hi[emit] > 0).astype(np.int64) << 16)).astype(np.uint64)],
-                            axis=1).reshape(-1)
+        req = []
+        for i in np.flatnonzero(emit):
+            req.extend(self._words(self.rc[i]))
+            req.append(int(cnt[i]) | (int(s_hi[i] > 0) << 16))
+        self.req = np.array(req, dtype=np.uint64)
         # signed canonical fingerprint (any function that cancels over {x, rc(x)} pairs will do)
-        h = _mix(np.minimum(keys, rc) ^ _mix(cnt.astype(np.uint64)))
-        sign = np.where(keys < rc, 1, np.where(keys > rc, -1, 0)).astype(np.int64)
-        with np.errstate(over="ignore"):
-            f = np.sum(h.view(np.int64) * sign, dtype=np.int64) if n else np.int64(0)
-        self.fp = [int(np.uint64(np.int64(f))), 0, 0, 0]
-
+        f = 0
+        for i in range(n):
+            x, r = keys[i], self.rc[i]
+            if x == r:
+                continue
+            c = min(x, r)
+            h = _mix(_mix(c & M64) ^ _mix(c >> 64) ^ _mix(int(cnt[i])))
+            f = (f + h) & M64 if x < r else (f - h) & M64
+        self.fp = [f, 0, 0, 0]
         self.symcheck = symcheck
 
     def nreq(self):
-        return len(self.req) // 2
+        return len(self.req) // (self.W + 1)
 
     # request filter: same protocol as the engine (block id = leading id_bits bits of the k-mer)
     def blockmap(self):
-        if self.symcheck != "hash":
+        if self.symcheck != "hash" or self.k > 64:
             return 0, 0
-        bits = min(14, 2 * (self.k // 2))      # (the engine uses up to 30 bits = 128 MB; any width the ranks agree on works)
+        bits = min(14, 2 * (self.k // 2))      # (the engine uses 30 bits; any width the ranks agree on works)
         return bits, ((1 << bits) + 31) >> 5
 
     def _own_map(self):
         bits, nwords = self.blockmap()
         m = np.zeros(nwords, np.uint32)
-        ids = (self.keys[self.s_all == 1] >> np.uint64(64 - bits)).astype(np.int64)
-        np.bitwise_or.at(m, ids >> 5, (np.uint32(1) << (ids & 31).astype(np.uint32)))
+        for i in np.flatnonzero(self.s_all == 1):
+            b = self.keys[i] >> (64 * self.W - bits)
+            m[b >> 5] |= np.uint32(1 << (b & 31))
         return m
 
     def blockmap_copy(self, word_lo, nw, dst):
@@ -99,37 +129,54 @@ class NumpyEngine:
     def presort(self):
         pass
 
+    def merge_maps(self, parts, width, wlo, wlen, full):
+        p = parts.cpu().numpy().view(np.uint32)
+        m = np.zeros(full.numel(), np.uint32)
+        for r in range(len(wlo)):
+            m[wlo[r]: wlo[r] + wlen[r]] |= p[r * width: r * width + wlen[r]]
+        full.copy_(torch.from_numpy(m.view(np.int32)))
+
     def filter(self, full_map=None):
         bits, _ = self.blockmap()
         m = self._own_map() if full_map is None else full_map.cpu().numpy().view(np.uint32)
-        rec = self.req.reshape(-1, 2)
-        ids = (rec[:, 0] >> np.uint64(64 - bits)).astype(np.int64)
-        keep = ((m[ids >> 5] >> (ids & 31).astype(np.uint32)) & np.uint32(1)).astype(bool)
+        rw = self.W + 1
+        rec = self.req.reshape(-1, rw)
+        keep = np.zeros(len(rec), bool)
+        for i in range(len(rec)):
+            b = int(rec[i, 0]) >> (64 - bits)
+            keep[i] = (int(m[b >> 5]) >> (b & 31)) & 1
         self.dropped = int((~keep).sum())
         self.req = rec[keep].reshape(-1)
-        return len(self.req) // 2
+        return len(self.req) // rw
 
     def route(self, splitters, nranks, send):
-        rec = self.req.reshape(-1, 2)
-        dest = np.searchsorted(np.asarray(splitters, dtype=np.uint64), rec[:, 0], side="right")
+        rw = self.W + 1
+        rec = self.req.reshape(-1, rw)
+        sp = self._ints(np.asarray(splitters, dtype=np.uint64)) if len(splitters) else []
+        tgt = self._ints(rec[:, : self.W].reshape(-1)) if len(rec) else []
+        dest = np.array([sum(1 for s in sp if t >= s) for t in tgt], dtype=np.int64)
         order = np.argsort(dest, kind="stable")
         out = rec[order].reshape(-1)
         send[: len(out)] = torch.from_numpy(out.view(np.int64).copy())
         return [int((dest == r).sum()) for r in range(nranks)]
 
     def _apply(self, rec):
-        rec = rec.reshape(-1, 2)
-        j = np.searchsorted(self.keys, rec[:, 0])
-        jj = np.minimum(j, max(self.n - 1, 0))
-        found = (j < self.n) & (self.keys[jj] == rec[:, 0]) if self.n else np.zeros(len(rec), bool)
-        c = (rec[:, 1] & np.uint64(0xFFFF)).astype(np.int64)
-        good = found & (self.cnt[jj] == c) if self.n else found
-        flag = ((rec[:, 1] >> np.uint64(16)) & np.uint64(1)).astype(bool)
-        self.P[jj[good & flag]] = 1
-        return int((~good).sum())
+        rw = self.W + 1
+        rec = np.asarray(rec, dtype=np.uint64).reshape(-1, rw)
+        index = {x: i for i, x in enumerate(self.keys)}
+        bad = 0
+        tgt = self._ints(rec[:, : self.W].reshape(-1)) if len(rec) else []
+        for t, meta in zip(tgt, rec[:, self.W]):
+            j = index.get(t)
+            meta = int(meta)
+            if j is None or self.cnt[j] != (meta & 0xFFFF):
+                bad += 1
+            elif (meta >> 16) & 1:
+                self.P[j] = 1
+        return bad
 
     def apply(self, recv, nrecv):
-        return self._apply(recv[: nrecv * 2].cpu().numpy().view(np.uint64))
+        return self._apply(recv[: nrecv * (self.W + 1)].cpu().numpy().view(np.uint64))
 
     def apply_own(self):
         return self._apply(self.req)
@@ -139,13 +186,23 @@ class NumpyEngine:
 
     def pass2(self, plot):
         a, b = self.pa, self.pb
-        keep = (self.s_all[a] == 1) & (self.s_all[b] == 1) & (self.P[a] == 0) & (self.P[b] == 0)
-        a, b, w = a[keep], b[keep], 1 + self.ph[keep]
-        s = self.cnt[a] + self.cnt[b]
-        m = np.minimum(self.cnt[a], self.cnt[b])
         out = np.zeros(PLOT_CELLS, np.int64)
-        np.add.at(out, s * PLOT_COLS + m, w)
+        if len(a):
+            keep = (self.s_all[a] == 1) & (self.s_all[b] == 1) & (self.P[a] == 0) & (self.P[b] == 0)
+            a, b, w = a[keep], b[keep], 1 + self.ph[keep]
+            s = self.cnt[a] + self.cnt[b]
+            m = np.minimum(self.cnt[a], self.cnt[b])
+            np.add.at(out, s * PLOT_COLS + m, w)
         plot.copy_(torch.from_numpy(out))
+
+    def run_general(self, k, keys, counts, plot):
+        """what one GPU does with a table that fails the proof: the oracle's all-positions count"""
+        import brute
+        W = (k + 31) // 32
+        kw = keys.cpu().numpy().view(np.uint64).reshape(-1, W)
+        packed = np.ascontiguousarray(kw.astype(">u8")).view(np.uint8).reshape(len(kw), 8 * W)[:, : (k + 3) // 4]
+        cnt = counts.cpu().numpy().view(np.uint16)
+        plot.copy_(torch.from_numpy(brute.hetmers_plot(np.ascontiguousarray(packed), cnt, k).reshape(-1)))
 
     def stats(self):
         return {"nels": self.n, "path": 1}
