@@ -102,11 +102,21 @@ SMG_DEV u64 rev2_word(u64 x)        // reverse the order of the 32 2-bit groups 
   return ((y >> 1) & 0x5555555555555555ull) | ((y & 0x5555555555555555ull) << 1);
 }
 
+// rev2_word(~x): the complement of a word with its 32 bases in reverse order.  Bit reversal of the two halves, then
+// the two bits of every base are swapped back AND complemented by one v_bitop3_b32 per half:
+// (~(y >> 1) & 0x55..) | (~(y << 1) & 0xAA..), truth table 0x1B on (y >> 1, y << 1, 0x55555555)  [8 instructions]
+SMG_DEV u64 rev2_comp_word(u64 x)
+{ const unsigned zh = __builtin_bitreverse32((unsigned) x), zl = __builtin_bitreverse32((unsigned) (x >> 32));
+  const unsigned rh = __builtin_amdgcn_bitop3_b32(zh >> 1, zh << 1, 0x55555555u, 0x1B);
+  const unsigned rl = __builtin_amdgcn_bitop3_b32(zl >> 1, zl << 1, 0x55555555u, 0x1B);
+  return ((u64) rh << 32) | rl;
+}
+
 // reverse complement of a left aligned k-mer (restates compress_comp, PloidyPlot.c:1143-1165)
 template <int W> SMG_DEV Key<W> revcomp(const Key<W> &x, int k)
 { Key<W> r, o;
 #pragma unroll
-  for (int w = 0; w < W; w++) r.w[w] = rev2_word(~x.w[W - 1 - w]);
+  for (int w = 0; w < W; w++) r.w[w] = rev2_comp_word(x.w[W - 1 - w]);
   // r holds the complement reversed over 32*W bases: the wanted k bases are the LAST k of it,
   // i.e. shift the whole W-word value left by 2*(32W-k) bits (always < 64)
   const int s = 2 * (32 * W - k);
