@@ -861,7 +861,8 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
   // (an engine that is reused on the same table must not redo pass 1 every time)
   int64_t want_rec = (emit_all ? e->n + e->n / 24 : e->n / 4) + (int64_t) (grid + 16 + 256) * F_CH;
   int64_t big_cap = e->biglist_cap / 4 > (1 << 20) ? e->biglist_cap / 4 : (1 << 20);
-  for (int attempt = 0; attempt < 3; attempt++)
+  bool done = false;
+  for (int attempt = 0; attempt < 4 && !done; attempt++)
     { unsigned maxc = (unsigned) ((want_rec + F_CH - 1) / F_CH);
       { const int64_t have = e->req_cap / ((int64_t) F_CH * (int64_t) sizeof(u64) * e->rw);
         if (e->req && have > (int64_t) maxc && have < 0x7FFFFFFFll) maxc = (unsigned) have;
@@ -938,8 +939,12 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
               continue;
             }
         }
-      break;
+      done = true;
     }
+  // (each redo sizes the lists from the counts the failed attempt reported, so the second attempt fits; a list that
+  //  still overflows after that is a bug, and must not be read as a complete request list)
+  if (!done || e->h_ctrl->fast.n_chunks > e->max_chunks)
+    return fail(errbuf, errlen, SMG_ENODEV, "pass 1: the request list overflowed its capacity on every attempt%s");
   e->n_chunks = e->h_ctrl->fast.n_chunks;
   memset(e->fp, 0, sizeof(e->fp));
   if (want_fp)

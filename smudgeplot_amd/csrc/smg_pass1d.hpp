@@ -58,7 +58,8 @@
 #endif
 #ifndef D_ABL
 #define D_ABL    0                         // ablation mask (timing experiments only; results are WRONG when non-zero):
-#endif                                     //   1 fingerprint, 2 directory, 4 signatures, 8 block map, 16 requests, 32 tail, 64 scan
+#endif                                     //   1 fingerprint, 2 directory, 4 signatures, 8 block map, 16 requests, 32 tail, 64 scan,
+                                           //   256 tail continuation, 512 tail processing, 1024/2048/4096/8192 the four barriers
 
 template <int W> struct DWord;
 template <> struct DWord<1> { typedef unsigned type; };
@@ -416,7 +417,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
   // The staged copy and the tail queue are complete for every wave from here on.  The tail itself runs at the END of
   // this phase, without a barrier of its own: between two barriers every wave has the same long stretch of work (tests,
   // fingerprints, requests) plus its share of the tail items, instead of three waves idling while one walks the queue.
-  lds_barrier();
+  if (!(D_ABL & 1024)) lds_barrier();
 
   // ---- the 12 one-away tests of a thread (distances 1..3), aggregated on the fly -----------------------------
   //@mark D_TESTS
@@ -583,7 +584,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
           }
       }
   }
-  lds_barrier();
+  if (!(D_ABL & 2048)) lds_barrier();
 
   // ---- merge the tail's hand-overs (rare: a wave-uniform branch per entry), store the code bytes ------------------
   //@mark D_MERGE
@@ -698,7 +699,7 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
         d_tile<W, RW, ODD, KF, true>(A, S, g0, g0n, t, fa, fb, fneg, bigmask, pf);
       else
         d_tile<W, RW, ODD, KF, false>(A, S, g0, g0n, t, fa, fb, fneg, bigmask, pf);
-      lds_barrier();
+      if (!(D_ABL & 4096)) lds_barrier();
       //@mark D_FLUSH
       if (D_BM && A.bmap)                           // candidate-block bits of this tile -> global map
         for (int w = t; w < D_BMW; w += D_TPB)
@@ -765,7 +766,7 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
             if (s_bigbase + e < cold->big_cap) cold->biglist[s_bigbase + e] = list[e];
         }
       if (t == 0) s_tn = 0;
-      lds_barrier();
+      if (!(D_ABL & 8192)) lds_barrier();
     }
 
   if (D_BM && W == 1 && A.hbits())
