@@ -779,8 +779,10 @@ def test_table_source_with_the_reference_binary_as_judge(tmp_path):
 def test_a_table_of_more_than_2_to_the_32_entries():
     """4.4e9 entries (synthetic diploid 1.75 Gbp, k=31): more than a shard can index.  The records live in a device
     tensor and reach the engine through the table-source callback, so the host holds nothing.  Checked: the automatic
-    2-shard run equals a 3-shard run (shard invariance), every cell off the self-mirrored diagonal is even (each pair
-    has a distinct mirror image on a closed table), and the pair count is 1.75x the 1 Gbp table's within 1 %."""
+    2-shard run equals a 3-shard run (shard invariance); the pair count is 1.75x the 1 Gbp table's within 2 %; and the
+    SHAPE of the plot is that of its 1/50 twin (the 35 Mbp table of the same generator, which the test above runs
+    through the reference binary): every well filled cell holds 50x the twin's count within 5 sigma of the twin's
+    counting noise."""
     import torch
     from smudgeplot_amd import synth_device
     dev = torch.device("cuda:0")
@@ -788,6 +790,11 @@ def test_a_table_of_more_than_2_to_the_32_entries():
     if total < 250e9:
         pytest.skip("needs a 288 GB device")
     k = 31
+    tk, tc = synth_device.diploid_table(35_000_000, k=k, het=0.01, cov=50.0, L=10, seed=5, device=dev)
+    rec, index = _records_on_device(tk, tc, k)
+    twin, _ = _run_source_from_device(rec, index, k, tc.numel())
+    del tk, tc, rec
+    torch.cuda.empty_cache()
     tk, tc = synth_device.diploid_table(1_750_000_000, k=k, het=0.01, cov=50.0, L=10, seed=1, device=dev)
     n = tc.numel()
     assert n > (1 << 32)
@@ -798,10 +805,13 @@ def test_a_table_of_more_than_2_to_the_32_entries():
     p3, st3 = _run_source_from_device(rec, index, k, n, limit=n // 3 + 1)
     assert st2["nels"] == n and st2["path"] == 1
     assert np.array_equal(p2, p3)
-    # the plot counts a pair and its mirror image: odd cells can only come from self-mirrored pairs (position 15),
-    # of which there are few; their number is the same in both runs, and the total is plausible for the model
     pairs = int(p2.sum())
     assert 0.98 < pairs / (458466309 * 1.75) < 1.02, pairs
+    full = twin >= 20000                               # (a cell counts a pair twice: sigma = sqrt(2 c))
+    assert full.sum() > 50
+    z = (p2[full] / 50.0 - twin[full]) / np.sqrt(2.0 * twin[full] * (1 + 1 / 50.0))
+    assert np.abs(z).max() < 5, float(np.abs(z).max())
+    assert 0.99 < p2.sum() / (50.0 * twin.sum()) < 1.01
 
 
 def test_exact_proof_is_not_fooled_by_a_signature_twin():
