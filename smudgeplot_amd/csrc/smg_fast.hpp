@@ -60,8 +60,19 @@ struct FastArgs
   uint16_t       *sig;           // k <= 64: the 16 k-mer bits below the directory bucket bits (look-up signatures)
   int             sigsh;         //          sig[i] = (uint16_t) (keys[i] >> sigsh)
   uint32_t       *bmap;          // candidate block map (or NULL): bit (hi32(kmer) >> bmsh) is set when a window block
-  int             bmsh;          //   (coarsened to <= 30 leading bits) holds an entry with exactly one suffix-side pair
+  int             bmsh;          //   (coarsened to <= 32 leading bits) holds an entry with exactly one suffix-side pair
+  int             bm2;           // two-bit map (below): 64-bit map words
 };
+
+// Two-bit candidate map (one GPU, 32 id bits, one-word k-mers of >= 24 bases).  The map word of 32 block ids is 64 bits
+// wide: the low half holds the usual bit (id & 31), the high half a SECOND bit at a position hashed from the 32 k-mer
+// bits below the id.  A request passes the filter only if both bits of its target are set: its target's block must hold
+// a candidate AND some candidate of the same 32-block group must hash to the same position -- for a request that aims
+// at no candidate that happens 11 times less often than the first bit alone (density d = 0.057 on the 1 Gbp table:
+// d -> d * d + d / 32), and every survivor costs a look-up of four random memory lines.  Both bits sit in one 8-byte
+// word, so marking is one atomic and probing one load.
+SMG_DEV unsigned bm2_pos(uint32_t lo) { return (lo * 0x9E3779B1u) >> 27; }
+SMG_DEV u64 bm2_bits(uint32_t id, uint32_t lo) { return (u64) (1u << (id & 31u)) | ((u64) (1u << bm2_pos(lo)) << 32); }
 
 struct FastCtl                    // device control words of the fast path
 { unsigned n_chunks;             // chunks handed out (may exceed max_chunks => rerun)
@@ -859,7 +870,8 @@ kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, unsigned nbig, u64 *
           A.code[i] = (uint8_t) make_code(s_all, partner - i, w2);
           if (W <= 2 && A.bmap && s_all == 1)             // a candidate: mark its block for the request filter
             { const uint32_t id = (uint32_t) (A.keys[i * W] >> 32) >> A.bmsh;
-              atomicOr(&A.bmap[id >> 5], 1u << (id & 31));
+              if (A.bm2) atomicOr(reinterpret_cast<u64 *>(A.bmap) + (id >> 5), bm2_bits(id, (uint32_t) A.keys[i * W]));
+              else atomicOr(&A.bmap[id >> 5], 1u << (id & 31));
             }
           if (s_hi > 0)
             { const Key<W> kx = load_key<W>(A.keys, i);

@@ -424,6 +424,7 @@ struct smg_engine
   unsigned    *ghist;      // look-up chain: requests per bucket [L_BK], bucket cursor `bnext` behind it
   u64         *boff;       //   bucket offsets [L_BK + 1] and scatter cursors [L_BK] behind them
   LookupGeo    lg;         //   geometry of the current run (lg.nb = 0: the round-1 chain is used)
+  int          bm2;        //   the map is a two-bit map (smg_fast.hpp): 64-bit words, private to this engine
   int          bm_cap;     //   id bits of the block map: 32 on one GPU, 30 when the maps of several shards are exchanged
   int          bm_want;    //   ... as asked for by smg_engine_set_blockmap_bits (0: default)
   P1Cold      *p1cold;     // rarely used arguments of kf_pass1_d (device copy)
@@ -778,6 +779,7 @@ static FastArgs make_fast(smg_engine *e)
   a.sigsh = 16 + e->dir.dsh;               // the 16 bits right below the directory's bucket bits
   a.bmap = e->bm_bits ? e->bmap : NULL;
   a.bmsh = 32 - e->bm_bits;
+  a.bm2 = e->bm2;
   return a;
 }
 
@@ -798,18 +800,21 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
   if ((rc = dir_geometry(e, errbuf, errlen))) return rc;
   // request filter: the candidate block map (an empty shard has one too -- all zero -- so that every rank of a
   // sharded run reports the same geometry and takes part in the exchange of the maps)
-  e->bm_bits = 0;
+  e->bm_bits = 0; e->bm2 = 0;
   e->filtered = false; e->presorted = 0;
+  e->lg.nb = 0;
   if (filter_ok(e) && !emit_all && !getenv("SMG_NO_FILTER"))
     { const int nbits = bm_id_bits(e->kmer, e->bm_cap);
-      const int64_t bytes = 4 * (((1ll << nbits) + 31) >> 5) + 4 * D_BMW + 64;
+      // the look-up chain of smg_lookup.hpp: one-word k-mers, key-only records, a map of >= 12 id bits
+      const bool chain = nbits >= 12 && e->W == 1 && e->rw == 1 && !getenv("SMG_OLD_LOOKUP");
+      // ... with the two-bit map (smg_fast.hpp) when the map stays on this GPU and the k-mer has bits below the id
+      e->bm2 = (chain && nbits == 32 && e->kmer >= 24 && !getenv("SMG_ONE_BIT_MAP")) ? 1 : 0;
+      const int64_t bytes = (4 * (((1ll << nbits) + 31) >> 5) + 4 * D_BMW + 64) << e->bm2;
       if ((rc = grow(&e->bmap, &e->bmap_cap, bytes, errbuf, errlen))) return rc;
       HIPCHK(hipMemsetAsync(e->bmap, 0, (size_t) bytes, e->stream));
       e->bm_bits = nbits;
+      if (chain) e->lg = lookup_geo(nbits);
     }
-  // the look-up chain of smg_lookup.hpp: one-word k-mers, key-only records, a map of >= 12 id bits
-  e->lg.nb = 0;
-  if (e->bm_bits >= 12 && e->W == 1 && e->rw == 1 && !getenv("SMG_OLD_LOOKUP")) e->lg = lookup_geo(e->bm_bits);
   if (e->n > 0)
     HIPCHK(hipMemsetAsync(e->bstart, 0xFF, sizeof(uint32_t) * ((size_t) e->dir.nb + 2), e->stream));
   if (e->n == 0)
@@ -879,7 +884,7 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
           P1Hot hot;
           hot.keys = a.keys; hot.cnt = a.cnt; hot.n = a.n; hot.code = a.code; hot.sig = a.sig; hot.bstart = e->bstart;
           hot.bmap = a.bmap; hot.b0 = e->dir.b0; hot.nb = e->dir.nb; hot.shifts = (unsigned) e->dir.dsh | ((unsigned) a.sigsh << 6) | (((unsigned) a.bmsh & 31u) << 12)
-                       | ((emit_all ? 1u : 0u) << 18) | ((want_fp ? 1u : 0u) << 19) | ((unsigned) e->lg.nb << 20);
+                       | ((emit_all ? 1u : 0u) << 18) | ((want_fp ? 1u : 0u) << 19) | ((unsigned) e->lg.nb << 20) | ((unsigned) e->bm2 << 24);
           hot.G = gr; hot.ntiles = ntiles;
           e->h_p1cold->req = e->req; e->h_p1cold->chunk_fill = e->chunk_fill; e->h_p1cold->biglist = e->biglist;
           e->h_p1cold->partials = e->partials; e->h_p1cold->ctl = &e->ctrl->fast; e->h_p1cold->max_chunks = maxc; e->h_p1cold->ghist = e->ghist;
@@ -1093,19 +1098,19 @@ static int filter_presort(smg_engine *e, char *errbuf, size_t errlen)
 
 // smg_lookup.hpp: filter the partitioned requests against `map`; list = false: look the survivors up at once
 static int lookup_probe(smg_engine *e, const uint32_t *map, bool list, unsigned maxout, char *errbuf, size_t errlen)
-{ unsigned grid = 256;
+{ const bool two = e->bm2 && map == e->bmap;                // (a map that came from outside is a one-bit map)
+  unsigned grid = 256;
   { int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) == hipSuccess && cus > 0) grid = (unsigned) cus;
   }
   const unsigned nbk = 1u << e->lg.nb;
   if (grid > nbk) grid = nbk;
   FastArgs a = make_fast(e);
-  if (list)
-    hipLaunchKernelGGL(kl_probe<true>, dim3(grid), dim3(PB_TPB), 0, e->stream, a, (const u64 *) e->req2, (const u64 *) e->boff, map, e->lg,
-                       e->ghist + L_BK, e->reqf, e->chunk_fillf, maxout, &e->ctrl->fast);
-  else
-    hipLaunchKernelGGL(kl_probe<false>, dim3(grid), dim3(PB_TPB), 0, e->stream, a, (const u64 *) e->req2, (const u64 *) e->boff, map, e->lg,
-                       e->ghist + L_BK, (u64 *) NULL, (uint32_t *) NULL, 0u, &e->ctrl->fast);
+#define PROBE(LIST_, TWO_, OUT_, FILL_, MAX_) hipLaunchKernelGGL((kl_probe<LIST_, TWO_>), dim3(grid), dim3(PB_TPB), 0, e->stream, a, \
+                       (const u64 *) e->req2, (const u64 *) e->boff, map, e->lg, e->ghist + L_BK, OUT_, FILL_, MAX_, &e->ctrl->fast)
+  if (list) { if (two) PROBE(true, true, e->reqf, e->chunk_fillf, maxout); else PROBE(true, false, e->reqf, e->chunk_fillf, maxout); }
+  else      { if (two) PROBE(false, true, (u64 *) NULL, (uint32_t *) NULL, 0u); else PROBE(false, false, (u64 *) NULL, (uint32_t *) NULL, 0u); }
+#undef PROBE
   HIPCHK(hipGetLastError());
   return SMG_OK;
 }
@@ -1298,7 +1303,7 @@ extern "C" int smg_engine_set_blockmap_bits(smg_engine *e, int id_bits)
 
 extern "C" int smg_engine_blockmap(smg_engine *e, int *id_bits, int64_t *nwords)
 { if (!e || !id_bits || !nwords) return SMG_EINVAL;
-  *id_bits = e->prepared ? e->bm_bits : 0;
+  *id_bits = (e->prepared && !e->bm2) ? e->bm_bits : 0;         // (a two-bit map is private: nothing to exchange)
   *nwords = *id_bits ? ((1ll << *id_bits) + 31) >> 5 : 0;
   return SMG_OK;
 }
@@ -1307,6 +1312,7 @@ extern "C" int smg_engine_blockmap_copy(smg_engine *e, int64_t word_lo, int64_t 
                                         char *errbuf, size_t errlen)
 { NEED_FAST(e)
   if (!e->prepared || !e->bm_bits) return fail(errbuf, errlen, SMG_EINVAL, "no block map: pass 1 (hash proof, k <= 64) has not run%s");
+  if (e->bm2) return fail(errbuf, errlen, SMG_EINVAL, "the block map of a single-GPU run cannot be exchanged (smg_engine_set_blockmap_bits(30) before pass 1)%s");
   const int64_t nwords = ((1ll << e->bm_bits) + 31) >> 5;
   if (word_lo < 0 || nw < 0 || word_lo + nw > nwords || (nw > 0 && !d_dst))
     return fail(errbuf, errlen, SMG_EINVAL, "block map range out of bounds%s");

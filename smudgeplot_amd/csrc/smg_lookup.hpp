@@ -157,7 +157,7 @@ SMG_DEV unsigned pb_fold(unsigned f)
 
 // LIST = false: look the survivors up and set their P flags.  LIST = true: append them to the chunk list `out`
 // (every wave fills chunks of its own).
-template <bool LIST> __global__ void __launch_bounds__(PB_TPB)
+template <bool LIST, bool TWO> __global__ void __launch_bounds__(PB_TPB)
 kl_probe(FastArgs A, const u64 *__restrict__ recs, const u64 *__restrict__ boff, const uint32_t *__restrict__ fmap,
          LookupGeo g, unsigned *__restrict__ bnext, u64 *__restrict__ out, uint32_t *__restrict__ out_fill,
          unsigned max_out, FastCtl *__restrict__ ctl)
@@ -209,15 +209,21 @@ kl_probe(FastArgs A, const u64 *__restrict__ recs, const u64 *__restrict__ boff,
       const u64 r0 = boff[b], r1 = boff[b + 1];
       if (r0 == r1) continue;
       // the bucket's part of the map, folded 4:1 into LDS  (fb >= 12: at least 2^9 coarse bits per bucket)
-      { const uint32_t *fw = fmap + ((size_t) b << (g.fb - g.nb - 5));
+      { const uint32_t *fw = fmap + (((size_t) b << (g.fb - g.nb - 5)) << (TWO ? 1 : 0));
         for (unsigned cw = t; cw < ncw; cw += PB_TPB)
-          { const uint4 f = *reinterpret_cast<const uint4 *>(fw + 4 * cw);
-            cmap[cw] = pb_fold(f.x) | (pb_fold(f.y) << 8) | (pb_fold(f.z) << 16) | (pb_fold(f.w) << 24);
+          { if (TWO)                                  // 64-bit map words: the first bits are the even 32-bit words
+              { const uint4 f0 = *reinterpret_cast<const uint4 *>(fw + 8 * cw), f1 = *reinterpret_cast<const uint4 *>(fw + 8 * cw + 4);
+                cmap[cw] = pb_fold(f0.x) | (pb_fold(f0.z) << 8) | (pb_fold(f1.x) << 16) | (pb_fold(f1.z) << 24);
+              }
+            else
+              { const uint4 f = *reinterpret_cast<const uint4 *>(fw + 4 * cw);
+                cmap[cw] = pb_fold(f.x) | (pb_fold(f.y) << 8) | (pb_fold(f.z) << 16) | (pb_fold(f.w) << 24);
+              }
           }
       }
       __syncthreads();
       for (u64 i0 = r0 + (u64) wv * (64 * PB_PER); i0 < r1; i0 += (u64) PB_WAVES * 64 * PB_PER)
-        { u64 y[PB_PER]; bool keep[PB_PER]; unsigned fwd[PB_PER];
+        { u64 y[PB_PER]; bool keep[PB_PER]; unsigned fwd[PB_PER], fw2[PB_PER];
 #pragma unroll
           for (int j = 0; j < PB_PER; j++)
             { const u64 i = i0 + (u64) j * 64 + lane;
@@ -232,12 +238,17 @@ kl_probe(FastArgs A, const u64 *__restrict__ recs, const u64 *__restrict__ boff,
 #pragma unroll
           for (int j = 0; j < PB_PER; j++)                     // the full-resolution map: global memory, ~20 % of the lanes
             { const unsigned fid = (unsigned) (y[j] >> (64 - g.fb));
-              fwd[j] = keep[j] ? fmap[fid >> 5] : 0u;
+              if (TWO)
+                { const uint2 f = keep[j] ? reinterpret_cast<const uint2 *>(fmap)[fid >> 5] : make_uint2(0u, 0u);
+                  fwd[j] = f.x; fw2[j] = f.y;
+                }
+              else { fwd[j] = keep[j] ? fmap[fid >> 5] : 0u; fw2[j] = 0u; }
             }
 #pragma unroll
           for (int j = 0; j < PB_PER; j++)
             { const unsigned fid = (unsigned) (y[j] >> (64 - g.fb));
               keep[j] = keep[j] && ((fwd[j] >> (fid & 31)) & 1u);
+              if (TWO) keep[j] = keep[j] && ((fw2[j] >> bm2_pos((uint32_t) y[j])) & 1u);
             }
 #pragma unroll
           for (int j = 0; j < PB_PER; j += 2)                  // queue two wave-instructions' worth, drain to below 64

@@ -147,7 +147,7 @@ struct P1Hot                              // kernel argument: what every tile to
   uint32_t       *bstart;        // bucket directory: bucket(x) = (hi32(x) >> dsh) - b0
   uint32_t       *bmap;          // candidate block map (or NULL): bit (hi32(x) >> bmsh)
   uint32_t        b0, nb;
-  unsigned        shifts;        // dsh | sigsh << 6 | bmsh << 12 | emit_all << 18 | want_fp << 19 | hbits << 20  (one register)
+  unsigned        shifts;        // dsh | sigsh << 6 | bmsh << 12 | emit_all << 18 | want_fp << 19 | hbits << 20 | two << 24  (one register)
   GeoR            G;
   int64_t         ntiles;
   SMG_DEV int dsh() const { return (int) (shifts & 63u); }
@@ -156,6 +156,7 @@ struct P1Hot                              // kernel argument: what every tile to
   SMG_DEV bool emit_all() const { return (shifts >> 18 & 1u) != 0; }
   SMG_DEV bool want_fp() const { return (shifts >> 19 & 1u) != 0; }
   SMG_DEV int hbits() const { return (int) ((shifts >> 20) & 15u); }    // request histogram on the leading hbits bits (0: none)
+  SMG_DEV bool two() const { return (shifts >> 24 & 1u) != 0; }         // two-bit block map (BM2_* in smg_fast.hpp)
 };
 
 struct P1Cold                             // in device memory: what only a flush touches (kept out of the register file)
@@ -171,7 +172,7 @@ struct P1Cold                             // in device memory: what only a flush
 struct DShared                            // the workgroup's LDS arrays (pointers: the tile body is a function)
 { unsigned *cred; uint16_t *tailq; u64 *ent; uint16_t *lcn; u64 *sq;
   unsigned *s_tn, *s_qn, *s_nbig, *s_unsorted;
-  unsigned *bm;                          // candidate-block bits of this tile: D_BMW words (request filter)
+  unsigned *bm;                          // candidate-block bits of this tile: D_BMW words (2 * D_BMW: two-bit map)
   unsigned *hist;                        // requests of this workgroup per bucket (D_HB bins), for the look-up chain's partition
 };
 
@@ -370,11 +371,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
         for (int e = 0; e < 4; e++)
           if (vmask >> e & 1) A.sig[i0 + e] = (uint16_t) sg[e];
     }
-  // block ids for the request filter (the k-mers themselves are not needed past this point)
-  const int bmsh = A.bmsh();
-  uint32_t idv[4];
-#pragma unroll
-  for (int e = 0; e < 4; e++) idv[e] = (uint32_t) (kk[e].w[0] >> 32) >> bmsh;
+  const int bmsh = A.bmsh();             // (the k-mers themselves are not needed past this point)
 
   // ---- window-block structure as lane masks ---------------------------------------------------------------
   //@mark D_MASKS
@@ -455,18 +452,51 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
   // word 0 of the tile's LDS bit map = the map word of the tile's first owned entry (a uniform, scalar load)
   const uint32_t bmbase = D_BM ? (((uint32_t) (A.keys[(g0 + D_LEAD) * W] >> 32) >> bmsh) & ~31u) : 0u;
   if (D_BM && A.bmap && !(D_ABL & 8))
-    {
+    { // leading word of the thread's own entries, back from the staged copy (cheaper than four registers kept alive
+      // across the tests)
+      u64 kw[4];
+      if constexpr (W == 1)
+        { const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(&S.ent[slot0]);
+          const ulonglong2 b = *reinterpret_cast<const ulonglong2 *>(&S.ent[slot0 + 2]);
+          kw[0] = a.x; kw[1] = a.y; kw[2] = b.x; kw[3] = b.y;
+        }
+      else
+        {
 #pragma unroll
-      for (int e = 0; e < 4; e++)
-        { u64 cm = uniqM[e] & ownM;
-          if (!INNER) cm &= V[e];
-          if (cm)
-            { const uint32_t id = idv[e];
-              const uint32_t rel = id - bmbase;
-              const u64 nearM = __ballot(rel < D_BMF) & cm;
-              if (d_lane(nearM)) atomicOr(&S.bm[rel >> 5], 1u << (rel & 31));
-              const u64 farM = cm & ~nearM;                                      // sparse table: outside the tile's LDS window
-              if (farM) { if (d_lane(farM)) atomicOr(&A.bmap[id >> 5], 1u << (id & 31)); }
+          for (int e = 0; e < 4; e++) kw[e] = S.ent[(slot0 + e) * W];
+        }
+      if (A.two())
+        { u64 *bm64 = reinterpret_cast<u64 *>(S.bm);
+          u64 *gm64 = reinterpret_cast<u64 *>(A.bmap);
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+            { u64 cm = uniqM[e] & ownM;
+              if (!INNER) cm &= V[e];
+              if (cm)
+                { const uint32_t id = (uint32_t) (kw[e] >> 32) >> bmsh;
+                  const uint32_t rel = id - bmbase;
+                  const u64 v = bm2_bits(id, (uint32_t) kw[e]);
+                  const u64 nearM = __ballot(rel < D_BMF) & cm;
+                  if (d_lane(nearM)) atomicOr(&bm64[rel >> 5], v);
+                  const u64 farM = cm & ~nearM;
+                  if (farM) { if (d_lane(farM)) atomicOr(&gm64[id >> 5], v); }
+                }
+            }
+        }
+      else
+        {
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+            { u64 cm = uniqM[e] & ownM;
+              if (!INNER) cm &= V[e];
+              if (cm)
+                { const uint32_t id = (uint32_t) (kw[e] >> 32) >> bmsh;
+                  const uint32_t rel = id - bmbase;
+                  const u64 nearM = __ballot(rel < D_BMF) & cm;
+                  if (d_lane(nearM)) atomicOr(&S.bm[rel >> 5], 1u << (rel & 31));
+                  const u64 farM = cm & ~nearM;                                      // sparse table: outside the tile's LDS window
+                  if (farM) { if (d_lane(farM)) atomicOr(&A.bmap[id >> 5], 1u << (id & 31)); }
+                }
             }
         }
     }
@@ -614,9 +644,15 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
               { codes = (codes & ~(0xFFu << (8 * e))) | (nc << (8 * e));
                 if (big) { bigmask |= 1u << e; atomicAdd(S.s_nbig, 1u); }
                 if (D_BM && A.bmap && d_code_uq(nc) && !d_code_uq(oc))              // a candidate only now
-                  { const uint32_t id = (uint32_t) (S.ent[(slot0 + e) * W] >> 32) >> bmsh;
+                  { const u64 kw0 = S.ent[(slot0 + e) * W];
+                    const uint32_t id = (uint32_t) (kw0 >> 32) >> bmsh;
                     const uint32_t rel = id - bmbase;
-                    if (rel < D_BMF) atomicOr(&S.bm[rel >> 5], 1u << (rel & 31));
+                    if (A.two())
+                      { const u64 v = bm2_bits(id, (uint32_t) kw0);
+                        if (rel < D_BMF) atomicOr(reinterpret_cast<u64 *>(S.bm) + (rel >> 5), v);
+                        else atomicOr(reinterpret_cast<u64 *>(A.bmap) + (id >> 5), v);
+                      }
+                    else if (rel < D_BMF) atomicOr(&S.bm[rel >> 5], 1u << (rel & 31));
                     else atomicOr(&A.bmap[id >> 5], 1u << (id & 31));
                   }
                 if (!A.emit_all() && d_code_hi(nc) && !d_code_hi(oc) && !(D_ABL & 16))  // its first hi-side pair: send late
@@ -666,7 +702,7 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
   __shared__ u64      sq[(RW == 1 ? D_QCAP : D_OWN) * RW];
   __shared__ u64      sfp[D_TPB / 64][2];
   constexpr bool D_BM = (W == 1 && RW == 1) || (W == 2 && RW == 3);
-  __shared__ unsigned bm[D_BM ? D_BMW : 1];
+  __shared__ __attribute__((aligned(16))) unsigned bm[D_BM ? 2 * D_BMW : 1];
   __shared__ unsigned hist[(D_BM && W == 1) ? D_HB : 1];
   __shared__ unsigned s_tn, s_qn, s_nbig, s_unsorted, s_chunk, s_used, s_bigbase, s_bigcur;
   __shared__ u64      s_base, s_total;
@@ -681,7 +717,7 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
   S.cred = cred; S.tailq = tailq; S.ent = ent; S.lcn = lcn; S.sq = sq;
   S.s_tn = &s_tn; S.s_qn = &s_qn; S.s_nbig = &s_nbig; S.s_unsorted = &s_unsorted;
   S.bm = bm; S.hist = hist;
-  if (D_BM) for (int w = t; w < D_BMW; w += D_TPB) bm[w] = 0;
+  if (D_BM) for (int w = t; w < 2 * D_BMW; w += D_TPB) bm[w] = 0;
   if (D_BM && W == 1) for (int w = t; w < D_HB; w += D_TPB) hist[w] = 0;
   for (int s = t; s < D_CRED; s += D_TPB) cred[s] = 0;
   if (t == 0) { s_chunk = F_NOCHUNK; s_used = 0; s_total = 0; s_tn = 0; s_qn = 0; s_nbig = 0; s_unsorted = 0; }
@@ -702,13 +738,15 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
       if (!(D_ABL & 4096)) lds_barrier();
       //@mark D_FLUSH
       if (D_BM && A.bmap)                           // candidate-block bits of this tile -> global map
-        for (int w = t; w < D_BMW; w += D_TPB)
-          { const unsigned v = bm[w];
-            if (v)
-              { atomicOr(&A.bmap[(((uint32_t) (ent[D_LEAD * W] >> 32) >> A.bmsh()) >> 5) + w], v);
-                bm[w] = 0;
-              }
-          }
+        { const int two = A.two() ? 1 : 0;          // (two-bit map: twice the words, at twice the word offset)
+          for (int w = t; w < (D_BMW << two); w += D_TPB)
+            { const unsigned v = bm[w];
+              if (v)
+                { atomicOr(&A.bmap[(((size_t) (((uint32_t) (ent[D_LEAD * W] >> 32) >> A.bmsh()) >> 5)) << two) + w], v);
+                  bm[w] = 0;
+                }
+            }
+        }
       // zero the hand-over words for the next tile (every thread its own four; the tail past the staged range)
       *reinterpret_cast<uint4 *>(&cred[slot0]) = make_uint4(0, 0, 0, 0);
       if (t < (D_CRED - D_SLOTS) / 4) *reinterpret_cast<uint4 *>(&cred[D_SLOTS + 4 * t]) = make_uint4(0, 0, 0, 0);

@@ -9,7 +9,7 @@ rows = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(path)):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if not name.startswith(("kf_", "k_", "rd", "wr")):
+        if not name.startswith(("kf_", "kl_", "km_", "k_", "rd", "wr")):
             continue
         rows[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for name in sorted(rows):
