@@ -138,7 +138,7 @@ int smg_hetmers_run_source(const smg_table_source *source, const smg_opts *opts,
      last word              : variant position | alt base (0..3 = acgt) << 8 | label << 16
    One record per printed line of the reference (print_het, PloidyList.c:128-165); the order of the
    records is unspecified (so is the order of the reference's lines: mutex-guarded fprintf from threads).
-   plot receives the same histogram smg_hetmers_run computes.  Needs k <= 85.                   */
+   plot receives the same histogram smg_hetmers_run computes.                                    */
 int smg_hetmers_extract(const smg_table_view *table, const smg_opts *opts, const uint16_t *labels,
                         int64_t *plot, uint64_t **records, int64_t *nrec, int *rec_words,
                         smg_stats *stats, char *errbuf, size_t errlen);
@@ -219,7 +219,7 @@ int     smg_engine_route(smg_engine *e, const uint64_t *splitters, int nranks, u
 int     smg_engine_apply(smg_engine *e, const uint64_t *d_recv, int64_t nrecv, int64_t *missing,
                          char *errbuf, size_t errlen);
 int     smg_engine_apply_own(smg_engine *e, int64_t *missing, char *errbuf, size_t errlen);
-/* Request filter (hash proof, k <= 64).  A request only matters when its target is a candidate of
+/* Request filter (hash proof, k <= 85).  A request only matters when its target is a candidate of
    pass 2 (exactly one suffix-side pair).  Pass 1 records in a bit map which block ids -- the leading
    id_bits = min(30, 2*(k/2)) bits of a k-mer -- hold a candidate; smg_engine_filter drops every request
    whose target id has a clear bit, before the requests are routed, sorted or looked up.  Single shard:

@@ -240,6 +240,10 @@ kf_pass1(FastArgs A, uint32_t *__restrict__ bstart, u64 *__restrict__ req,
               delta = partner - i;
             }
           A.code[i] = (uint8_t) make_code(s_all, delta, w2);
+          if (A.bmap && s_all == 1)                       // a candidate: mark its block for the request filter
+            { const uint32_t id = (uint32_t) (x.w[0] >> 32) >> A.bmsh;
+              atomicOr(&A.bmap[id >> 5], 1u << (id & 31));
+            }
 
           // bucket directory + strict order check (the predecessor is in the halo)
           { const uint32_t bcur = dir_bucket(A.dir, x.w[0]);

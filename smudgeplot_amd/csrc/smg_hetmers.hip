@@ -380,6 +380,75 @@ k_pass2(Tab t, int64_t lo, int64_t hi, u64 *__restrict__ plot)
     }
 }
 
+// ---- extract on the counted path (k > 85): the pairs pass 2 counts, as records ---------------------
+// The same walk as k_pass2<W, true>; a pair at a labelled pixel is written out like kf_extract writes it (the pair,
+// and for p != k-1-p its mirror image at k-1-p).  One global atomic per pair: this path is exact, not fast.
+template <int W> __global__ void __launch_bounds__(TPB)
+k_extract(Tab t, const uint16_t *__restrict__ labels, u64 *__restrict__ out, u64 capacity, u64 *__restrict__ total)
+{ const int64_t i = (int64_t) blockIdx.x * TPB + threadIdx.x;
+  if (i >= t.n) return;
+  const Geo g = t.g;
+  const unsigned di = t.deg[i];
+  if (di > 1) return;
+  if (di == 0 && !g.wrap) return;
+  const Key<W> x = load_key<W>(t.keys, i);
+  const unsigned c = t.cnt[i];
+  const int k = g.k;
+
+  auto emit = [&](int64_t j, const Key<W> &y, int p)
+  { const unsigned cj = t.cnt[j];
+    if (c + cj > SMG_SMAX || t.deg[j] > 1) return;
+    const unsigned sum = c + cj, mn = c < cj ? c : cj;
+    const unsigned lab = labels[(size_t) sum * SMG_PLOT_COLS + mn];
+    if (!lab) return;
+    const bool w2 = p != k - 1 - p;
+    const unsigned bi = base_at<W>(x, p), bj = base_at<W>(y, p);              // bi < bj (i < j)
+    const u64 q = atomicAdd(total, (u64) (w2 ? 2 : 1));
+    if (q < capacity)
+      { const bool pj = c < cj;                                                 // cnt[a] < cnt[b]: print b, alt base of a
+        const Key<W> &who = pj ? y : x;
+        u64 *o = out + q * (W + 1);
+#pragma unroll
+        for (int w = 0; w < W; w++) o[w] = who.w[w];
+        o[W] = (u64) p | ((u64) (pj ? bi : bj) << 8) | ((u64) lab << 16);
+      }
+    if (w2 && q + 1 < capacity)
+      { const bool pb = cj < c;                                                 // mirror image: a = rc(y), b = rc(x)
+        const Key<W> who = revcomp<W>(pb ? x : y, k);
+        u64 *o = out + (q + 1) * (W + 1);
+#pragma unroll
+        for (int w = 0; w < W; w++) o[w] = who.w[w];
+        o[W] = (u64) (k - 1 - p) | ((u64) (pb ? 3u - bj : 3u - bi) << 8) | ((u64) lab << 16);
+      }
+  };
+
+  bool big = false;
+  if (i + WIN_LIM < t.n) big = same_block<W>(x, load_key<W>(t.keys, i + WIN_LIM), g);
+  if (!big)
+    { for (int64_t j = i + 1; j < t.n; j++)
+        { const Key<W> y = load_key<W>(t.keys, j);
+          if (!same_block<W>(x, y, g)) break;
+          const int p = pair_pos<W>(x, y);
+          if (p >= 0) emit(j, y, p);
+        }
+    }
+  else
+    { int64_t a = i + 1, b = t.n;
+      while (a < b)
+        { const int64_t m = (a + b) >> 1;
+          if (!same_block<W>(x, load_key<W>(t.keys, m), g)) b = m; else a = m + 1;
+        }
+      const int64_t bhi = a;
+      for (int p = g.p0; p < g.k; p++)
+        for (int d = 1; d <= 3; d++)
+          { const Key<W> y = flip_base<W>(x, p, d);
+            if (!key_lt<W>(x, y)) continue;
+            const int64_t j = lower_bound_key<W>(t.keys, i + 1, bhi, y);
+            if (j < bhi && key_eq<W>(load_key<W>(t.keys, j), y)) emit(j, y, p);
+          }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 //  Host side
 // ------------------------------------------------------------------------------------------
@@ -424,6 +493,7 @@ struct smg_engine
   unsigned    *ghist;      // look-up chain: requests per bucket [L_BK], bucket cursor `bnext` behind it
   u64         *boff;       //   bucket offsets [L_BK + 1] and scatter cursors [L_BK] behind them
   LookupGeo    lg;         //   geometry of the current run (lg.nb = 0: the round-1 chain is used)
+  bool         counted_done; // the counted path (k > 85) has run on a closed table: deg[] holds the wrapped degrees
   int          bm2;        //   the map is a two-bit map (smg_fast.hpp): 64-bit words, private to this engine
   int          bm_cap;     //   id bits of the block map: 32 on one GPU, 30 when the maps of several shards are exchanged
   int          bm_want;    //   ... as asked for by smg_engine_set_blockmap_bits (0: default)
@@ -521,7 +591,7 @@ static int set_table(smg_engine *e, int kmer, int64_t nels, char *errbuf, size_t
   e->kmer = kmer;
   e->W = (kmer + 31) / 32;
   e->n = nels;
-  e->prepared = false;
+  e->prepared = false; e->counted_done = false;
   memset(&e->st, 0, sizeof(e->st));
   e->st.nels = nels;
   e->st.key_words = e->W;
@@ -638,6 +708,7 @@ static Tab make_tab(smg_engine *e)
 static int counted_prepare(smg_engine *e, char *errbuf, size_t errlen)
 { HIPCHK(hipMemsetAsync(e->ctrl, 0, sizeof(Ctrl), e->stream));
   set_geo(e);
+  e->fast = false; e->counted_done = false;
   const int64_t dbytes = ((e->n + 3) & ~3ll) + 4;
   int rc = grow(&e->deg, &e->deg_cap, dbytes, errbuf, errlen);
   if (rc) return rc;
@@ -730,6 +801,7 @@ static int counted_symmetric(smg_engine *e, int symcheck, int64_t *d_plot, bool 
   hipEventElapsedTime(&ms, e->ev[6], e->ev[7]);
   e->st.ms_pass2 = ms;
   e->st.path = 1;
+  e->counted_done = true;
   return SMG_OK;
 }
 
@@ -785,7 +857,8 @@ static FastArgs make_fast(smg_engine *e)
 
 static int bm_id_bits(int kmer, int cap);
 // (k = 1 has no prefix bases to name a block by)
-static bool filter_ok(const smg_engine *e) { return e->kmer >= 2 && ((e->W == 1 && e->rw == 1) || (e->W == 2 && e->rw == 3)); }
+static bool filter_ok(const smg_engine *e)
+{ return e->kmer >= 2 && ((e->W == 1 && e->rw == 1) || (e->W == 2 && e->rw == 3) || (e->W == 3 && e->rw == 4)); }
 
 static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, char *errbuf, size_t errlen)
 { int rc;
@@ -793,7 +866,7 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
   e->rw = e->W + ((with_meta || e->W > 1) ? 1 : 0);
   HIPCHK(hipMemsetAsync(e->ctrl, 0, sizeof(Ctrl), e->stream));
   set_geo(e);
-  e->fast = true;
+  e->fast = true; e->counted_done = false;
   if ((rc = grow(&e->deg, &e->deg_cap, ((e->n + 15) & ~15ll) + 32, errbuf, errlen))) return rc;
   const int64_t pbytes = ((e->n + 15) & ~15ll) + 32;
   if (e->W <= 2 && (rc = grow(&e->sig, &e->sig_cap, 2 * pbytes, errbuf, errlen))) return rc;
@@ -1149,8 +1222,11 @@ static int fast_filter(smg_engine *e, const uint32_t *map, char *errbuf, size_t 
   else if (e->rw == 1)
     hipLaunchKernelGGL(kf_filter<1>, dim3(grid), dim3(F_TPB), 0, e->stream, e->req, e->chunk_fill, e->n_chunks, (int64_t) 0,
                        map, 64 - nbits, e->reqf, e->chunk_fillf, maxout, &e->ctrl->fast);
-  else
+  else if (e->rw == 3)
     hipLaunchKernelGGL(kf_filter<3>, dim3(grid), dim3(F_TPB), 0, e->stream, e->req, e->chunk_fill, e->n_chunks, (int64_t) 0,
+                       map, 64 - nbits, e->reqf, e->chunk_fillf, maxout, &e->ctrl->fast);
+  else
+    hipLaunchKernelGGL(kf_filter<4>, dim3(grid), dim3(F_TPB), 0, e->stream, e->req, e->chunk_fill, e->n_chunks, (int64_t) 0,
                        map, 64 - nbits, e->reqf, e->chunk_fillf, maxout, &e->ctrl->fast);
   hipEventRecord(e->ev[5], e->stream);
   HIPCHK(hipGetLastError());
@@ -1311,7 +1387,7 @@ extern "C" int smg_engine_blockmap(smg_engine *e, int *id_bits, int64_t *nwords)
 extern "C" int smg_engine_blockmap_copy(smg_engine *e, int64_t word_lo, int64_t nw, uint32_t *d_dst,
                                         char *errbuf, size_t errlen)
 { NEED_FAST(e)
-  if (!e->prepared || !e->bm_bits) return fail(errbuf, errlen, SMG_EINVAL, "no block map: pass 1 (hash proof, k <= 64) has not run%s");
+  if (!e->prepared || !e->bm_bits) return fail(errbuf, errlen, SMG_EINVAL, "no block map: pass 1 (hash proof, k <= 85) has not run%s");
   if (e->bm2) return fail(errbuf, errlen, SMG_EINVAL, "the block map of a single-GPU run cannot be exchanged (smg_engine_set_blockmap_bits(30) before pass 1)%s");
   const int64_t nwords = ((1ll << e->bm_bits) + 31) >> 5;
   if (word_lo < 0 || nw < 0 || word_lo + nw > nwords || (nw > 0 && !d_dst))
@@ -1342,7 +1418,7 @@ extern "C" int smg_engine_merge_maps(smg_engine *e, const uint32_t *d_parts, int
                                      const int64_t *word_lo, const int64_t *nwords_of, uint32_t *d_full,
                                      char *errbuf, size_t errlen)
 { NEED_FAST(e)
-  if (!e->prepared || !e->bm_bits) return fail(errbuf, errlen, SMG_EINVAL, "no block map: pass 1 (hash proof, k <= 64) has not run%s");
+  if (!e->prepared || !e->bm_bits) return fail(errbuf, errlen, SMG_EINVAL, "no block map: pass 1 (hash proof, k <= 85) has not run%s");
   if (!d_parts || !d_full || !word_lo || !nwords_of || nranks < 1 || nranks > 16 || width < 1)
     return fail(errbuf, errlen, SMG_EINVAL, "bad merge_maps arguments (1..16 ranks)%s");
   const int64_t nwords = ((1ll << e->bm_bits) + 31) >> 5;
@@ -1368,7 +1444,7 @@ extern "C" int smg_engine_presort(smg_engine *e, char *errbuf, size_t errlen)
 extern "C" int smg_engine_filter(smg_engine *e, const uint32_t *d_map, int64_t *kept, char *errbuf, size_t errlen)
 { NEED_FAST(e)
   if (!e->prepared) return fail(errbuf, errlen, SMG_EINVAL, "filter before pass1%s");
-  if (!filter_ok(e)) return fail(errbuf, errlen, SMG_EINVAL, "the request filter covers the hash proof at k <= 64%s");
+  if (!filter_ok(e)) return fail(errbuf, errlen, SMG_EINVAL, "the request filter covers the hash proof at k <= 85%s");
   if (!d_map && !e->bm_bits) return fail(errbuf, errlen, SMG_EINVAL, "no block map to filter with%s");
   HIPCHK(hipSetDevice(e->device));
   int rc = e->filtered ? SMG_OK : fast_filter(e, d_map, errbuf, errlen);
@@ -1652,7 +1728,7 @@ extern "C" int smg_engine_condition(smg_engine *e, int ethresh, int do_trim, int
 #undef CCHK
 #undef CRC
   e->n = n;
-  e->prepared = false;
+  e->prepared = false; e->counted_done = false;
   e->st.nels = n;
   e->st.ms_decode += ms;
   if (new_nels) *new_nels = n;
@@ -1664,13 +1740,22 @@ extern "C" int smg_engine_condition(smg_engine *e, int ethresh, int do_trim, int
 extern "C" int smg_engine_extract(smg_engine *e, const uint16_t *d_labels, uint64_t *d_out, int64_t capacity,
                                   int64_t *nrec, char *errbuf, size_t errlen)
 { if (!e || !d_labels || !nrec) return fail(errbuf, errlen, SMG_EINVAL, "null argument%s");
-  if (!e->prepared || !e->fast || e->st.path != 1)
+  const bool counted = e->counted_done && !e->fast && e->st.path == 1;        // k > 85: degrees instead of code bytes
+  if (!counted && (!e->prepared || !e->fast || e->st.path != 1))
     return fail(errbuf, errlen, SMG_EINVAL,
-                "extract needs a completed run on a conditioned (reverse-complement closed) table with k <= 85%s");
+                "extract needs a completed run on a conditioned (reverse-complement closed) table%s");
   HIPCHK(hipSetDevice(e->device));
   u64 *d_total = &e->ctrl->plot_sum;
   HIPCHK(hipMemsetAsync(d_total, 0, sizeof(u64), e->stream));
-  if (e->n > 0)
+  if (e->n > 0 && counted)
+    { Tab t = make_tab(e);
+      const unsigned nblk = (unsigned) ((e->n + TPB - 1) / TPB);
+#define CALL(WW) hipLaunchKernelGGL(k_extract<WW>, dim3(nblk), dim3(TPB), 0, e->stream, t, d_labels, (u64 *) d_out, \
+                   (u64) (d_out ? capacity : 0), d_total)
+      DISPATCH_W(e, CALL)
+#undef CALL
+    }
+  else if (e->n > 0)
     { FastArgs a = make_fast(e);
       int64_t nb = (e->n + F_TPB - 1) / F_TPB;
       if (nb > 2048) nb = 2048;
@@ -1784,7 +1869,7 @@ static int host_run(const smg_table_source *tv, const smg_opts *opts, int64_t *p
   if (labels)
     { // exact record count = plot weight on the labelled pixels (the plot counts a mirrored pair twice)
       if (e->st.path != 1)
-        BAIL(SMG_EINVAL, "extract needs a trimmed, reverse-complement closed table with k <= 85")
+        BAIL(SMG_EINVAL, "extract needs a trimmed, reverse-complement closed table")
       int64_t want = 0, got = 0;
       for (int c = 0; c < SMG_PLOT_CELLS; c++) if (labels[c]) want += plot[c];
       const int rw = e->W + 1;

@@ -6,7 +6,7 @@ prefix-subtree task decomposition of `small_window` (src/lib/PloidyPlot.c:1040-1
 
 Data path per run (see DESIGN.md "Multi-GPU"):
   1. pass 1 on every shard (window scan of the suffix-side positions: always shard local);
-  2. request filter (hash proof, k <= 64): one all_gather of the candidate block maps (each rank contributes the
+  2. request filter (hash proof, k <= 85): one all_gather of the candidate block maps (each rank contributes the
      words its k-mer range covers: 128 MB / world at k = 31) -- a request whose target block holds no candidate
      of pass 2 is dropped before it is sent (about 4 in 5 on a diploid table);
      ONE exchange: every entry that owns a suffix-side pair sends (rc(kmer), count, S_hi) to the

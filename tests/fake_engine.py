@@ -110,7 +110,7 @@ class NumpyEngine:
 
     # request filter: same protocol as the engine (block id = leading id_bits bits of the k-mer)
     def blockmap(self):
-        if self.symcheck != "hash" or self.k > 64:
+        if self.symcheck != "hash" or self.k > 85:
             return 0, 0
         bits = min(14, 2 * (self.k // 2))      # (the engine uses 30 bits; any width the ranks agree on works)
         return bits, ((1 << bits) + 31) >> 5

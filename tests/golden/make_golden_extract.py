@@ -20,7 +20,7 @@ from smudgeplot_amd import ktab  # noqa: E402
 
 REF = os.path.join(ROOT, "oracle", "_ref", "extract_ref")
 OUT = os.path.dirname(os.path.abspath(__file__))
-NAMES = ["k31_i1", "k32_i1_p2", "k21_i2_p2", "k51_i1_p3", "k65_i1"]
+NAMES = ["k31_i1", "k32_i1_p2", "k21_i2_p2", "k51_i1_p3", "k65_i1", "k100_i1", "k100_wrap"]
 SMUDGES = ["1A1B", "2A1B", "2A2B"]
 
 

@@ -42,7 +42,7 @@ def test_numpy_oracle_extract_matches_reference_golden(name):
     g, labels, lines, _ = load_extract(name)
     got = brute.extract_lines(g["packed"], g["counts"], g["k"], labels)
     assert got == lines
-    assert sum(len(v) for v in lines.values()) > 500
+    assert sum(len(v) for v in lines.values()) > (500 if name != "k100_wrap" else 1)     # (the wrap table has one pixel)
 
 
 def test_extract_golden_set_is_not_trivial():
@@ -108,7 +108,7 @@ def test_engine_extract_matches_reference_golden(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["k31_i1", "k51_i1_p3", "k65_i1"])
+@pytest.mark.parametrize("name", ["k31_i1", "k51_i1_p3", "k65_i1", "k100_i1", "k100_wrap"])
 def test_extract_executable_matches_reference_golden(name, tmp_path):
     g, labels, lines, rows = load_extract(name)
     ktab.write_ktab(str(tmp_path / "t"), g["k"], g["packed"], g["counts"], ibyte=min(g["ibyte"], 2), nparts=g["nparts"])
@@ -121,7 +121,7 @@ def test_extract_executable_matches_reference_golden(name, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,seed", [(19, 1), (32, 2), (33, 3), (47, 4), (64, 5), (85, 6)])
+@pytest.mark.parametrize("k,seed", [(19, 1), (32, 2), (33, 3), (47, 4), (64, 5), (85, 6), (86, 7), (97, 8), (128, 9)])
 def test_extract_fresh_tables_vs_oracle(k, seed):
     packed, cnt = synth.adversarial_table(k, 2000, 4, seed, low_complexity=100, dense=1)
     want_plot = brute.hetmers_plot(packed, cnt, k)

@@ -243,9 +243,10 @@ def test_engine_object_with_torch_tensors_and_manual_two_shard_exchange():
 
 
 @pytest.mark.parametrize("k,m,seed", [(31, 30000, 3), (21, 30000, 4), (12, 20000, 5), (32, 8000, 6), (33, 8000, 7),
-                                      (40, 20000, 8), (51, 6000, 9), (64, 5000, 10)])
+                                      (40, 20000, 8), (51, 6000, 9), (64, 5000, 10), (65, 5000, 11), (70, 5000, 12),
+                                      (85, 4000, 13)])
 def test_request_filter_changes_nothing_but_the_request_count(k, m, seed, monkeypatch):
-    """hash proof, k <= 64: requests whose target block holds no candidate are dropped before the look-ups"""
+    """hash proof, k <= 85: requests whose target block holds no candidate are dropped before the look-ups"""
     packed, cnt = synth.adversarial_table(k, m, 4, seed, low_complexity=40, dense=1)
     want = brute.hetmers_plot(packed, cnt, k) if m * k <= 400000 else None
     tab = table_from(packed, cnt, k)
@@ -260,6 +261,8 @@ def test_request_filter_changes_nothing_but_the_request_count(k, m, seed, monkey
         assert np.array_equal(plot_f, want)
     assert st_u["nrequests"] == st_u["nemitted"] == st_f["nemitted"] > 0
     assert st_f["nrequests"] <= st_f["nemitted"]
+    if k >= 24:                                            # (sparse tables: nearly every target block is empty)
+        assert st_f["nrequests"] < st_f["nemitted"]
 
 
 @pytest.mark.parametrize("k,symcheck", [(31, "hash"), (12, "hash"), (31, "exact"), (40, "hash")])
