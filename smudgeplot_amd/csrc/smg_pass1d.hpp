@@ -56,10 +56,13 @@
 #else
 #define D_SCHED_FENCE()
 #endif
+#ifndef D_TAILB
+#define D_TAILB  8                         // tail: distances 4 .. D_TAILB + 3 come in batches of four LDS reads
+#endif
 #ifndef D_ABL
 #define D_ABL    0                         // ablation mask (timing experiments only; results are WRONG when non-zero):
 #endif                                     //   1 fingerprint, 2 directory, 4 signatures, 8 block map, 16 requests, 32 tail, 64 scan,
-                                           //   256 tail continuation, 512 tail processing, 1024/2048/4096/8192 the four barriers
+                                           //   256 tail continuation, 512 tail processing, 1024/2048/4096/8192 the four barriers, 16384 merge of the tail's results
 
 template <int W> struct DWord;
 template <> struct DWord<1> { typedef unsigned type; };
@@ -572,28 +575,32 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
         d_unpack<W, KF>(lds_key<W>(S.ent, sa), G, pa, sfa);
         const unsigned ca = S.lcn[sa];
         int d = 4;
-        if (sa + 7 < D_SLOTS)                   // the usual case: distances 4..7 are staged
-          { Key<W> kb[4]; unsigned cb[4];
+        bool done = false;
 #pragma unroll
-            for (int j = 0; j < 4; j++) { kb[j] = lds_key<W>(S.ent, sa + 4 + j); cb[j] = S.lcn[sa + 4 + j]; }
+        for (int base = 4; base <= D_TAILB; base += 4)           // distances 4..7 (and 8..11), each fetched as ONE batch
+          { if (done || sa + base + 3 >= D_SLOTS) break;          // (not staged: the loop below reads global memory)
+            Key<W> kb[4]; unsigned cb[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { kb[j] = lds_key<W>(S.ent, sa + base + j); cb[j] = S.lcn[sa + base + j]; }
             bool same = true;                   // (the entry at distance 4 shares the prefix: that is why sa is queued)
 #pragma unroll
             for (int j = 0; j < 4; j++)
               { WT pb, sfb;
                 d_unpack<W, KF>(kb[j], G, pb, sfb);
-                same = same && pb == pa && (INNER || g0 + sa + 4 + j < n);
+                same = same && pb == pa && (INNER || g0 + sa + base + j < n);
                 const WT dd = sfa ^ sfb;
                 const WT tt = ((dd << 1) | dd) & (WT) 0xAAAAAAAAAAAAAAAAull;
                 if (same && d_popc(tt) == 1 && ca + cb[j] <= SMG_SMAX)
-                  { unsigned v = 1u | ((unsigned) (31 + 4 + j) << 8);
+                  { unsigned v = 1u | ((unsigned) (31 + base + j) << 8);
                     if (ODD) v += (unsigned) (dd >> G.mshift) << 24;
                     atomicAdd(&S.cred[sa], v);
-                    atomicAdd(&S.cred[sa + 4 + j], v - ((unsigned) (2 * (4 + j)) << 8));
+                    atomicAdd(&S.cred[sa + base + j], v - ((unsigned) (2 * (base + j)) << 8));
                   }
               }
-            if (!same || (D_ABL & 256)) continue;
-            d = 8;
+            d = base + 4;
+            if (!same || (D_ABL & 256)) done = true;
           }
+        if (done) continue;
         for (; d <= D_WIN + 1; d++)             // longer blocks, and entries next to the end of the staged range
           { const int sb = sa + d;
             WT pb, sfb; unsigned cb;
@@ -630,7 +637,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
 #pragma unroll
     for (int e = 0; e < 4; e++)
       { const u64 tM = __ballot(R[e] != 0u) & ownM & VL[e];
-        if (tM)
+        if (tM && !(D_ABL & 16384))
           { const bool touched = d_lane(tM);
             const unsigned oc = (codes >> (8 * e)) & 0xFFu;
             const unsigned cnt_t = R[e] & 0xFFu;
