@@ -856,13 +856,15 @@ kf_route_scatter(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk
 template <int W, int RW> __global__ void __launch_bounds__(F_TPB)
 kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, unsigned nbig, u64 *__restrict__ req,
           uint32_t *__restrict__ chunk_fill, unsigned max_chunks, FastCtl *__restrict__ ctl,
-          unsigned *__restrict__ ghist, int hbits)
+          unsigned *__restrict__ whist /* this kernel's rows */, unsigned owner0, unsigned owners, int hbits)
 { constexpr int rw = RW;
   __shared__ u64      sq[F_TPB * RW];
+  __shared__ unsigned hist[1024];       // requests of this workgroup per look-up bucket (a row of whist, like pass 1's)
   __shared__ unsigned s_qn, s_chunk, s_used;
   __shared__ u64      s_base, s_total;
   const int t = threadIdx.x;
   if (t == 0) { s_qn = 0; s_chunk = F_NOCHUNK; s_used = 0; s_total = 0; }
+  for (int b = t; b < 1024; b += F_TPB) hist[b] = 0;
   __syncthreads();
   for (unsigned r0 = blockIdx.x * F_TPB; r0 < nbig; r0 += gridDim.x * F_TPB)
     { const unsigned r = r0 + t;
@@ -884,7 +886,7 @@ kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, unsigned nbig, u64 *
 #pragma unroll
               for (int w = 0; w < W; w++) sq[q * rw + w] = rc.w[w];
               if (rw > W) sq[q * rw + W] = (u64) A.cnt[i] | (1ull << 16);
-              if (ghist && hbits) atomicAdd(&ghist[(unsigned) (rc.w[0] >> 32) >> (32 - hbits)], 1u);    // (rare path)
+              if (whist && hbits) atomicAdd(&hist[(unsigned) (rc.w[0] >> 32) >> (32 - hbits)], 1u);
             }
         }
       __syncthreads();
@@ -893,7 +895,9 @@ kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, unsigned nbig, u64 *
         { if (t == 0)
             { if (s_chunk == F_NOCHUNK || s_used + qn > F_CH)
                 { if (s_chunk != F_NOCHUNK && s_chunk < max_chunks) chunk_fill[s_chunk] = s_used;
-                  s_chunk = atomicAdd(&ctl->n_chunks, 1u);
+                  // (look-up chain: chunk slots owner, owner + owners, .. as in pass 1; this kernel's owners follow pass 1's)
+                  if (whist && hbits) s_chunk = s_chunk == F_NOCHUNK ? owner0 + blockIdx.x : s_chunk + owners;
+                  else s_chunk = atomicAdd(&ctl->n_chunks, 1u);
                   s_used = 0;
                 }
               s_base = (u64) s_chunk * F_CH + s_used;
@@ -909,6 +913,9 @@ kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, unsigned nbig, u64 *
     }
   if (t == 0)
     { if (s_chunk != F_NOCHUNK && s_chunk < max_chunks) chunk_fill[s_chunk] = s_used;
+      if (whist && hbits && s_chunk != F_NOCHUNK) atomicMax(&ctl->n_chunks, s_chunk + 1u);
       if (s_total) atomicAdd(&ctl->nreq, s_total);
     }
+  if (whist && hbits)
+    for (int b = t; b < 1024; b += F_TPB) whist[(size_t) blockIdx.x * 1024 + b] = hist[b];
 }

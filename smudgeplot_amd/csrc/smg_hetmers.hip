@@ -456,6 +456,7 @@ k_extract(Tab t, const uint16_t *__restrict__ labels, u64 *__restrict__ out, u64
 #define FAST_MAX_K   85        // above this a uint8 degree can wrap: counted path (v1 kernels)
 #define P1_GRID      1280      // persistent workgroups of the generic kf_pass1<W> (5 per CU resident: LDS bound)
 #define P1_MAXGRID   4096      // upper bound of any pass-1 grid (partial fingerprint sums)
+#define BF_MAXGRID   256       // workgroups of kf_bigfix
 #define P2_GRID      512       // persistent workgroups of kf_pass2 (2 per CU: 43.7 KB plot tile + 32 KB queue each)
 
 struct smg_engine
@@ -491,6 +492,9 @@ struct smg_engine
   u64         *route_off;  int64_t route_off_cap;
   u64         *partials;   // [P1_MAXGRID][4]
   unsigned    *ghist;      // look-up chain: requests per bucket [L_BK], bucket cursor `bnext` behind it
+  unsigned    *whist;  int64_t whist_cap;     //   requests per owner and bucket [owners][L_BK] (owner = a workgroup of pass 1 / kf_bigfix)
+  unsigned     p1grid, nown; //  workgroups of the last pass 1; owners of the request list (+ BF_MAXGRID for kf_bigfix):
+                           //   owner w fills the chunk slots w, w + nown, w + 2 nown, ..
   u64         *boff;       //   bucket offsets [L_BK + 1] and scatter cursors [L_BK] behind them
   LookupGeo    lg;         //   geometry of the current run (lg.nb = 0: the round-1 chain is used)
   bool         counted_done; // the counted path (k > 85) has run on a closed table: deg[] holds the wrapped degrees
@@ -562,6 +566,7 @@ extern "C" smg_engine *smg_engine_create(int device, void *stream, char *errbuf,
       || hipMalloc(&e->d_split, sizeof(u64) * 16 * 4) != hipSuccess
       || hipMalloc(&e->p1cold, sizeof(P1Cold)) != hipSuccess
       || hipMalloc(&e->ghist, sizeof(unsigned) * (L_BK + 4)) != hipSuccess
+
       || hipMalloc(&e->boff, sizeof(u64) * (2 * L_BK + 4)) != hipSuccess
       || hipHostMalloc(&e->h_p1cold, sizeof(P1Cold)) != hipSuccess)
     { fail(errbuf, errlen, SMG_ENOMEM, "cannot allocate the control block%s");
@@ -578,6 +583,7 @@ extern "C" void smg_engine_destroy(smg_engine *e)
   hipFree(e->own_keys); hipFree(e->own_cnt); hipFree(e->deg); hipFree(e->sig); hipFree(e->bstart);
   hipFree(e->req); hipFree(e->req2); hipFree(e->sort_tmp); hipFree(e->dense); hipFree(e->chunk_off); hipFree(e->skey[0]); hipFree(e->skey[1]); hipFree(e->sidx[0]); hipFree(e->sidx[1]); hipFree(e->biglist); hipFree(e->chunk_fill); hipFree(e->bmap); hipFree(e->reqf); hipFree(e->chunk_fillf); hipFree(e->route_cnt); hipFree(e->route_off);
   hipFree(e->partials); hipFree(e->ctrl); hipFree(e->d_split); hipFree(e->p1cold); hipFree(e->ghist); hipFree(e->boff);
+  hipFree(e->whist);
   hipHostFree(e->h_ctrl); hipHostFree(e->h_partials); hipHostFree(e->h_p1cold);
   for (int i = 0; i < 10; i++) hipEventDestroy(e->ev[i]);
   delete e;
@@ -950,7 +956,13 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
       e->max_chunks = maxc;
       if ((rc = grow(&e->biglist, &e->biglist_cap, big_cap * 4, errbuf, errlen))) return rc;
       FastArgs a = make_fast(e);
-      if (e->lg.nb) HIPCHK(hipMemsetAsync(e->ghist, 0, sizeof(unsigned) * (L_BK + 4), e->stream));
+      if (e->lg.nb)
+        { // owners of the request chunks: the workgroups of this launch, then those of kf_bigfix (rows zero unless it runs)
+          if ((rc = grow((char **) &e->whist, &e->whist_cap, (int64_t) (grid + BF_MAXGRID) * L_BK * 4, errbuf, errlen))) return rc;
+          HIPCHK(hipMemsetAsync(e->whist + (size_t) grid * L_BK, 0, sizeof(unsigned) * BF_MAXGRID * L_BK, e->stream));
+          HIPCHK(hipMemsetAsync(e->chunk_fill, 0, (size_t) maxc * 4, e->stream));      // (a slot that stays empty has fill 0)
+          e->p1grid = grid; e->nown = grid + BF_MAXGRID;
+        }
       hipEventRecord(e->ev[2], e->stream);
       if (narrow)
         {
@@ -960,7 +972,8 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
                        | ((emit_all ? 1u : 0u) << 18) | ((want_fp ? 1u : 0u) << 19) | ((unsigned) e->lg.nb << 20) | ((unsigned) e->bm2 << 24);
           hot.G = gr; hot.ntiles = ntiles;
           e->h_p1cold->req = e->req; e->h_p1cold->chunk_fill = e->chunk_fill; e->h_p1cold->biglist = e->biglist;
-          e->h_p1cold->partials = e->partials; e->h_p1cold->ctl = &e->ctrl->fast; e->h_p1cold->max_chunks = maxc; e->h_p1cold->ghist = e->ghist;
+          e->h_p1cold->partials = e->partials; e->h_p1cold->ctl = &e->ctrl->fast; e->h_p1cold->max_chunks = maxc;
+          e->h_p1cold->whist = e->whist; e->h_p1cold->owners = grid + BF_MAXGRID;
           e->h_p1cold->big_cap = (unsigned) big_cap;
           HIPCHK(hipMemcpyAsync(e->p1cold, e->h_p1cold, sizeof(P1Cold), hipMemcpyHostToDevice, e->stream));
 #define LAUNCH_R(W_, RW_, ODD_, KF_) hipLaunchKernelGGL((kf_pass1_d<W_, RW_, ODD_, KF_>), dim3(grid), dim3(D_TPB), 0, e->stream, hot, \
@@ -1003,9 +1016,11 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
         { // exact redo of the entries whose window block is longer than the halo
           const unsigned nbig = e->h_ctrl->fast.nbig;
           unsigned fb = (nbig + F_TPB - 1) / F_TPB;
-          if (fb > 256) fb = 256;
+          if (fb > BF_MAXGRID) fb = BF_MAXGRID;
+
 #define BIGFIX(W_, RW_) hipLaunchKernelGGL((kf_bigfix<W_, RW_>), dim3(fb), dim3(F_TPB), 0, e->stream, a, e->biglist, nbig, e->req, \
-                              e->chunk_fill, maxc, &e->ctrl->fast, e->lg.nb ? e->ghist : (unsigned *) NULL, e->lg.nb)
+                              e->chunk_fill, maxc, &e->ctrl->fast, e->lg.nb ? e->whist + (size_t) grid * L_BK : (unsigned *) NULL, \
+                              grid, grid + BF_MAXGRID, e->lg.nb)
           hipEventRecord(e->ev[0], e->stream);
           if (e->W == 2) BIGFIX(2, 3); else if (e->rw == 1) BIGFIX(1, 1); else BIGFIX(1, 2);
 #undef BIGFIX
@@ -1141,15 +1156,13 @@ static int filter_presort(smg_engine *e, char *errbuf, size_t errlen)
       const int64_t nreq = e->st.nrequests;
       if ((rc = grow(&e->req2, &e->req2_cap, (nreq > 0 ? nreq : 1) * (int64_t) sizeof(u64), errbuf, errlen))) return rc;
       const int nbk = 1 << e->lg.nb;
+      // bucket sizes = column sums of the owners' histogram rows -> bucket offsets -> first slot of every owner in every bucket
+      hipLaunchKernelGGL(kl_tot, dim3(L_BK / LW_BPW), dim3(64 * LW_BPW), 0, e->stream, (const unsigned *) e->whist, e->nown, e->ghist);
       hipLaunchKernelGGL(kl_scan, dim3(1), dim3(L_BK), 0, e->stream, e->ghist, nbk, e->boff, e->boff + L_BK + 2, e->ghist + L_BK);
-      unsigned grid = 512;
-      { int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) == hipSuccess && cus > 0) grid = 2u * (unsigned) cus;
-      }
-      const unsigned nbatch = (e->n_chunks + PT_CH - 1) / PT_CH;
-      if (grid > nbatch) grid = nbatch;
-      if (grid) hipLaunchKernelGGL(kl_part, dim3(grid), dim3(PT_TPB), 0, e->stream, e->req, e->chunk_fill, e->n_chunks, e->lg.nb,
-                                   e->boff + L_BK + 2, e->req2);
+      hipLaunchKernelGGL(kl_woff, dim3(L_BK / LW_BPW), dim3(64 * LW_BPW), 0, e->stream, e->whist, e->nown, (const u64 *) e->boff);
+      if (e->n_chunks)
+        hipLaunchKernelGGL(kl_part, dim3(e->nown), dim3(PT_TPB), 0, e->stream, e->req, e->chunk_fill, e->nown,
+                           (const unsigned *) e->whist, e->max_chunks, e->lg.nb, e->req2);
       HIPCHK(hipGetLastError());
       e->presorted = 3;
       return SMG_OK;

@@ -2,22 +2,28 @@
 //
 // Round 1: sentinel fill, rocPRIM Onesweep histogram + scatter on the leading 8 bits (3.5 ms on the 1 Gbp table),
 // kf_filter probing the block map through the L2s (3.0), Onesweep on 24 bits of the survivors (1.1), in-order look-ups
-// (1.75): 9.3 ms for 4.4e8 requests.  Now three kernels:
+// (1.75): 9.3 ms for 4.4e8 requests.  Now (5.0 ms):
 //
-//   kl_scan   bucket offsets from the histogram that PASS 1 keeps of its requests (leading NB <= 10 bits of rc(x):
-//             one LDS add per request there, which replaces a 1.5 ms pass over the 3.5 GB request list);
-//   kl_part   one pass partition of the chunk list into a dense, bucket-ordered array: 8192 records staged in LDS,
-//             one global atomic per non-empty (batch, bucket), records scattered in 64-byte runs; no sentinels;
+//   kl_tot / kl_scan / kl_woff   Every workgroup of PASS 1 counts its requests per bucket (leading NB <= 10 bits of
+//             rc(x): one LDS add per request there, instead of a 1.5 ms pass over the 3.5 GB request list) and fills
+//             chunk slots that are its own by construction (w, w + owners, ..).  Column sums of the owners' rows ->
+//             bucket offsets -> the first output slot of every owner in every bucket;
+//   kl_part   one-pass partition into a dense, bucket-ordered array: workgroup w takes the chunks of owner w, 16384
+//             records at a time, sorts them by bucket inside LDS and copies them out in runs of ~16 records.  The output
+//             cursors are LDS words of the owner -- the first version took a slot range per (batch, bucket) from
+//             global cursors: 5.5e7 atomics, 2.4 of its 3.4 ms;
 //   kl_probe  one 1024-thread workgroup per CU takes whole buckets.  The part of the block map that a bucket can hit
 //             is folded 4:1 into 128 KB of LDS (a "coarse" bit = four neighbouring block ids), so the first test of
-//             every request is an LDS read (the 128-512 MB map itself is read exactly once, as a stream); the ~20 %
-//             that pass probe the full-resolution map in global memory, and the ~6 % that pass that too are queued in
-//             LDS and looked up in batches of up to 1024 with every lane busy (directory bucket, bisection on the
-//             signatures, P flag) -- inside their bucket, i.e. inside 1/1024 of the table, without being sorted first.
+//             every request is an LDS read (the 128 MB - 1 GB map itself is read exactly once, as a stream); the ~20 %
+//             that pass probe the full-resolution map in global memory, and the survivors (1 in 115 with the two-bit
+//             map of a single-GPU run, 1 in 5 with the 30-bit map of a sharded one) are queued in LDS and looked up
+//             64 at a time with every lane busy (directory bucket, bisection on the signatures, P flag) -- inside
+//             their bucket, i.e. inside 1/1024 of the table, without being sorted first.
 //             In a sharded run the same kernel appends the survivors to a chunk list instead (they have to travel).
 //
 // The map resolution went from 30 to 32 id bits (5.7 % instead of 20 % of the requests survive) once the filter no
-// longer had to keep the map words of the resident workgroups inside the L2s.
+// longer had to keep the map words of the resident workgroups inside the L2s; the second bit per 32-block group
+// (smg_fast.hpp, bm2_bits) took the survivors to 0.9 %.
 
 #pragma once
 #include "smg_fast.hpp"
@@ -61,77 +67,146 @@ kl_scan(const unsigned *__restrict__ ghist, int nbk, u64 *__restrict__ boff /* [
   if (t == 0) *bnext = 0;
 }
 
+// ---- per-owner offsets ---------------------------------------------------------------------------------------------
+// Every workgroup of pass 1 (and of kf_bigfix) is the OWNER of the chunks it filled and has counted its requests per
+// bucket (row w of whist).  kl_tot sums the rows (-> the bucket sizes kl_scan turns into bucket offsets), kl_woff turns
+// row w into the first output slot of owner w in every bucket.  One wave per bucket, a lane per slice of the owners.
+#define LW_BPW 16                          // buckets per workgroup (one 64-byte segment of a row)
+
+__global__ void __launch_bounds__(64 * LW_BPW)
+kl_tot(const unsigned *__restrict__ whist, unsigned nown, unsigned *__restrict__ tot /* [L_BK] */)
+{ const int lane = threadIdx.x & 63, b = blockIdx.x * LW_BPW + (threadIdx.x >> 6);
+  const unsigned per = (nown + 63) / 64, w0 = lane * per, w1 = w0 + per < nown ? w0 + per : nown;
+  unsigned s = 0;
+  for (unsigned w = w0; w < w1; w++) s += whist[(size_t) w * L_BK + b];
+#pragma unroll
+  for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) tot[b] = s;
+}
+
+__global__ void __launch_bounds__(64 * LW_BPW)
+kl_woff(unsigned *__restrict__ whist /* in: counts, out: first slots */, unsigned nown, const u64 *__restrict__ boff)
+{ const int lane = threadIdx.x & 63, b = blockIdx.x * LW_BPW + (threadIdx.x >> 6);
+  const unsigned per = (nown + 63) / 64, w0 = lane * per, w1 = w0 + per < nown ? w0 + per : nown;
+  unsigned s = 0;
+  for (unsigned w = w0; w < w1; w++) s += whist[(size_t) w * L_BK + b];
+  unsigned incl = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1)
+    { const unsigned v = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += v;
+    }
+  unsigned run = (unsigned) boff[b] + incl - s;               // (slots are 32-bit: a shard holds < 2^32 requests)
+  for (unsigned w = w0; w < w1; w++)
+    { const unsigned c = whist[(size_t) w * L_BK + b];
+      whist[(size_t) w * L_BK + b] = run;
+      run += c;
+    }
+}
+
 // ---- partition ---------------------------------------------------------------------------------------------------
-// A batch of 8192 records is counted, sorted by bucket INSIDE LDS and copied out in order: neighbouring lanes then write
-// neighbouring addresses (runs of ~8 records per bucket and batch).  Scattering the records straight from registers --
-// 64 lanes, 64 buckets, 64 separate 8-byte writes per instruction -- ran at a third of the speed (4.6 ms for 3.5 GB).
-#define PT_TPB    512
-#define PT_CH     2                        // chunks per batch
-#define PT_BATCH  (PT_CH * F_CH)           // 8192 records = 64 KB of LDS
+// Workgroup w takes the chunks of owner w (slots w, w + owners, ..), PT_CH at a time: count per bucket, sort by bucket INSIDE LDS,
+// copy out in order -- neighbouring lanes then write neighbouring addresses (runs of ~16 records per bucket and batch;
+// scattering the records straight from registers ran at a third of the speed).  The output cursors of the owner live
+// in LDS: the first version took one slot range per (batch, bucket) from global cursors -- 5.5e7 atomics that cost
+// 2.4 of its 3.4 ms.
+#ifndef PT_TPB
+#define PT_TPB    1024
+#endif
+#ifndef PT_CH
+#define PT_CH     4                        // chunks per batch (2 with 512 threads: 3.0 instead of 2.6 ms -- shorter runs)
+#endif
+#define PT_BATCH  (PT_CH * F_CH)           // 16384 records = 128 KB of LDS: one workgroup per CU
 #define PT_PER    (PT_BATCH / PT_TPB)      // 16 records per thread, held in registers between the phases
+#define PT_BPT    (L_BK / PT_TPB)          // buckets per thread in the scan
 
 __global__ void __launch_bounds__(PT_TPB)
-kl_part(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill, unsigned n_chunks, int nb,
-        u64 *__restrict__ bcur, u64 *__restrict__ out)
+kl_part(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill, unsigned owners,
+        const unsigned *__restrict__ woff, unsigned max_chunks, int nb, u64 *__restrict__ out)
 { __shared__ u64      sorted[PT_BATCH];
   __shared__ unsigned cur[L_BK];           // phase A: counts; phase C: cursors
   __shared__ unsigned lbase[L_BK];         // first slot of the bucket in `sorted`
-  __shared__ unsigned gbase[L_BK];         // first slot of this batch's run in the output (low 32 bits suffice: nreq < 2^32)
+  __shared__ unsigned gbase[L_BK];         // first output slot of this batch's run
+  __shared__ unsigned gcur[L_BK];          // the owner's next output slot per bucket
   __shared__ unsigned wsum[PT_TPB / 64];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const int hsh = 32 - nb, nbk = 1 << nb;
-  for (int b = t; b < L_BK; b += PT_TPB) cur[b] = 0;
-  __syncthreads();
-  const unsigned nbatch = (n_chunks + PT_CH - 1) / PT_CH;
-  for (unsigned bt = blockIdx.x; bt < nbatch; bt += gridDim.x)
-    { // A: load (16 records per thread), count per bucket
-      u64 y[PT_PER]; bool ok[PT_PER];
+  const int hsh = 32 - nb;
+  for (int b = t; b < L_BK; b += PT_TPB) { cur[b] = 0; gcur[b] = woff[(size_t) blockIdx.x * L_BK + b]; }
+
+  // batch q = the chunks blockIdx.x + (q * PT_CH + j) * owners, j < PT_CH, of this owner (fill 0: not used).
+  // The PT_PER records of a thread; `ok` = which of them exist, bit 31 = the batch's first chunk is in use.
+  auto load = [&](unsigned q, u64 (&y)[PT_PER]) -> unsigned
+  { unsigned ok = 0;
+#pragma unroll
+    for (int j = 0; j < PT_PER; j++)
+      { const unsigned cj = (unsigned) j / (PT_PER / PT_CH), r = ((unsigned) j % (PT_PER / PT_CH)) * PT_TPB + t;
+        const u64 ch = (u64) blockIdx.x + (u64) (q * PT_CH + cj) * owners;
+        const unsigned fill = ch < max_chunks ? chunk_fill[ch] : 0u;
+        const bool k = r < fill;
+        ok |= (unsigned) k << j;
+        if (j == 0 && fill) ok |= 1u << 31;
+        y[j] = k ? req[(size_t) ch * F_CH + r] : 0ull;
+      }
+    return ok;
+  };
+
+  // The barriers order LDS traffic only (lds_barrier): a __syncthreads() also drains the wave's outstanding stores,
+  // which made every batch wait for its own copy-out.  The NEXT batch is loaded while this one is sorted.
+  u64 y[PT_PER], yn[PT_PER];
+  unsigned ok = load(0u, y), okn = 0;
+  lds_barrier();
+  for (unsigned q = 0; ok >> 31; q++)
+    { // A: count per bucket
 #pragma unroll
       for (int j = 0; j < PT_PER; j++)
-        { const unsigned c = (unsigned) j / (PT_PER / PT_CH), r = ((unsigned) j % (PT_PER / PT_CH)) * PT_TPB + t;
-          const unsigned ch = bt * PT_CH + c;
-          const unsigned fill = ch < n_chunks ? chunk_fill[ch] : 0u;
-          ok[j] = r < fill;
-          y[j] = ok[j] ? req[(size_t) ch * F_CH + r] : 0ull;
-        }
+        if (ok >> j & 1u) atomicAdd(&cur[(unsigned) (y[j] >> 32) >> hsh], 1u);
+      okn = load(q + 1, yn);                                     // (in flight until the end of this batch)
+      lds_barrier();
+      // B: exclusive scan of the counts (PT_BPT buckets per thread); the owner's cursors move on
+      { unsigned cbk[PT_BPT], incl = 0;
 #pragma unroll
-      for (int j = 0; j < PT_PER; j++)
-        if (ok[j]) atomicAdd(&cur[(unsigned) (y[j] >> 32) >> hsh], 1u);
-      __syncthreads();
-      // B: exclusive scan of the counts (two buckets per thread), one global atomic per non-empty bucket
-      { const unsigned c0 = cur[2 * t], c1 = cur[2 * t + 1];
-        unsigned incl = c0 + c1;
+        for (int j = 0; j < PT_BPT; j++) { cbk[j] = cur[PT_BPT * t + j]; incl += cbk[j]; }
+        const unsigned mine = incl;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1)
           { const unsigned v = __shfl_up(incl, o, 64);
             if (lane >= o) incl += v;
           }
         if (lane == 63) wsum[wv] = incl;
-        __syncthreads();
-        unsigned woff = 0;
-        for (int w = 0; w < wv; w++) woff += wsum[w];
-        const unsigned ex = woff + incl - (c0 + c1);
-        lbase[2 * t] = ex; lbase[2 * t + 1] = ex + c0;
-        cur[2 * t] = ex; cur[2 * t + 1] = ex + c0;
-        if (c0 && 2 * t < nbk) gbase[2 * t] = (unsigned) atomicAdd(&bcur[2 * t], (u64) c0);
-        if (c1 && 2 * t + 1 < nbk) gbase[2 * t + 1] = (unsigned) atomicAdd(&bcur[2 * t + 1], (u64) c1);
+        lds_barrier();
+        unsigned woffs = 0;
+        for (int w = 0; w < wv; w++) woffs += wsum[w];
+        unsigned ex = woffs + incl - mine;
+#pragma unroll
+        for (int j = 0; j < PT_BPT; j++)
+          { const int b = PT_BPT * t + j;
+            lbase[b] = ex; cur[b] = ex;
+            const unsigned g = gcur[b];
+            gbase[b] = g; gcur[b] = g + cbk[j];
+            ex += cbk[j];
+          }
       }
-      __syncthreads();
-      const unsigned total = wsum[0] + wsum[1] + wsum[2] + wsum[3] + wsum[4] + wsum[5] + wsum[6] + wsum[7];
+      lds_barrier();
+      unsigned total = 0;
+#pragma unroll
+      for (int w = 0; w < PT_TPB / 64; w++) total += wsum[w];
       // C: sort inside LDS (the order inside a bucket is arbitrary)
 #pragma unroll
       for (int j = 0; j < PT_PER; j++)
-        if (ok[j]) sorted[atomicAdd(&cur[(unsigned) (y[j] >> 32) >> hsh], 1u)] = y[j];
-      __syncthreads();
+        if (ok >> j & 1u) sorted[atomicAdd(&cur[(unsigned) (y[j] >> 32) >> hsh], 1u)] = y[j];
+      lds_barrier();
+#pragma unroll
+      for (int j = 0; j < PT_BPT; j++) cur[PT_BPT * t + j] = 0;   // (for the next batch; D does not read them)
       // D: copy out in order
       for (unsigned i = t; i < total; i += PT_TPB)
         { const u64 v = sorted[i];
           const unsigned b = (unsigned) (v >> 32) >> hsh;
           out[(size_t) gbase[b] + (i - lbase[b])] = v;
         }
-      __syncthreads();
-      for (int b = t; b < L_BK; b += PT_TPB) cur[b] = 0;
-      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < PT_PER; j++) y[j] = yn[j];
+      ok = okn;
+      lds_barrier();
     }
 }
 

@@ -168,7 +168,9 @@ struct P1Cold                             // in device memory: what only a flush
   uint32_t *biglist;
   u64      *partials;
   FastCtl  *ctl;
-  unsigned *ghist;               // requests per bucket (leading hbits bits of the target), summed over the workgroups
+  unsigned *whist;               // look-up chain: requests of workgroup w per bucket (leading hbits bits of the target)
+                                 //   in row w: whist[w * D_HB + b]
+  unsigned  owners;              //   chunk slots are dealt out without a counter: owner w fills w, w + owners, w + 2 owners, ..
   unsigned  max_chunks, big_cap;
 };
 
@@ -777,7 +779,9 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
             { s_base = (u64) old_chunk * F_CH + old_used;          // only used when head > 0
               if (qn > head)
                 { if (old_chunk != F_NOCHUNK && old_chunk < max_chunks) cold->chunk_fill[old_chunk] = F_CH;
-                  s_chunk = atomicAdd(&cold->ctl->n_chunks, 1u);
+                  // (look-up chain: the partition kernel finds the chunks of owner w at w + j * owners, no list needed)
+                  if (D_BM && W == 1 && A.hbits()) s_chunk = old_chunk == F_NOCHUNK ? blockIdx.x : old_chunk + cold->owners;
+                  else s_chunk = atomicAdd(&cold->ctl->n_chunks, 1u);
                   s_used = qn - head;
                 }
               else s_used = old_used + qn;
@@ -814,13 +818,11 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
       if (!(D_ABL & 8192)) lds_barrier();
     }
 
-  if (D_BM && W == 1 && A.hbits())
-    for (int w = t; w < (1 << A.hbits()); w += D_TPB)
-      { const unsigned v = hist[w];
-        if (v) atomicAdd(&cold->ghist[w], v);
-      }
+  if (D_BM && W == 1 && A.hbits())                   // this workgroup's row of the request histogram (kl_tot / kl_woff)
+    for (int w = t; w < D_HB; w += D_TPB) cold->whist[(size_t) blockIdx.x * D_HB + w] = hist[w];
   if (t == 0)
     { if (s_chunk != F_NOCHUNK && s_chunk < cold->max_chunks) cold->chunk_fill[s_chunk] = s_used;
+      if (D_BM && W == 1 && A.hbits() && s_chunk != F_NOCHUNK) atomicMax(&cold->ctl->n_chunks, s_chunk + 1u);   // slots in use
       if (s_total) atomicAdd(&cold->ctl->nreq, s_total);
       if (s_unsorted) cold->ctl->unsorted = 1;
     }
