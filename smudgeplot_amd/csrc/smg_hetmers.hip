@@ -886,8 +886,9 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
     { const int nbits = bm_id_bits(e->kmer, e->bm_cap);
       // the look-up chain of smg_lookup.hpp: one-word k-mers, key-only records, a map of >= 12 id bits
       const bool chain = nbits >= 12 && e->W == 1 && e->rw == 1 && !getenv("SMG_OLD_LOOKUP");
-      // ... with the two-bit map (smg_fast.hpp) when the map stays on this GPU and the k-mer has bits below the id
-      e->bm2 = (chain && nbits == 32 && e->kmer >= 24 && !getenv("SMG_ONE_BIT_MAP")) ? 1 : 0;
+      // ... with the two-bit map (smg_fast.hpp) when the k-mer has bits below the id to hash (a function of k and the
+      // environment alone: every shard of a table decides the same)
+      e->bm2 = (chain && e->kmer >= 24 && !getenv("SMG_ONE_BIT_MAP")) ? 1 : 0;
       const int64_t bytes = (4 * (((1ll << nbits) + 31) >> 5) + 4 * D_BMW + 64) << e->bm2;
       if ((rc = grow(&e->bmap, &e->bmap_cap, bytes, errbuf, errlen))) return rc;
       HIPCHK(hipMemsetAsync(e->bmap, 0, (size_t) bytes, e->stream));
@@ -1184,7 +1185,7 @@ static int filter_presort(smg_engine *e, char *errbuf, size_t errlen)
 
 // smg_lookup.hpp: filter the partitioned requests against `map`; list = false: look the survivors up at once
 static int lookup_probe(smg_engine *e, const uint32_t *map, bool list, unsigned maxout, char *errbuf, size_t errlen)
-{ const bool two = e->bm2 && map == e->bmap;                // (a map that came from outside is a one-bit map)
+{ const bool two = e->bm2 != 0;                             // (a map that came from outside was built by the same rule)
   unsigned grid = 256;
   { int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) == hipSuccess && cus > 0) grid = (unsigned) cus;
@@ -1392,8 +1393,8 @@ extern "C" int smg_engine_set_blockmap_bits(smg_engine *e, int id_bits)
 
 extern "C" int smg_engine_blockmap(smg_engine *e, int *id_bits, int64_t *nwords)
 { if (!e || !id_bits || !nwords) return SMG_EINVAL;
-  *id_bits = (e->prepared && !e->bm2) ? e->bm_bits : 0;         // (a two-bit map is private: nothing to exchange)
-  *nwords = *id_bits ? ((1ll << *id_bits) + 31) >> 5 : 0;
+  *id_bits = e->prepared ? e->bm_bits : 0;
+  *nwords = *id_bits ? (((1ll << *id_bits) + 31) >> 5) << e->bm2 : 0;      // (two-bit map: 64 bits per 32 block ids)
   return SMG_OK;
 }
 
@@ -1401,8 +1402,7 @@ extern "C" int smg_engine_blockmap_copy(smg_engine *e, int64_t word_lo, int64_t 
                                         char *errbuf, size_t errlen)
 { NEED_FAST(e)
   if (!e->prepared || !e->bm_bits) return fail(errbuf, errlen, SMG_EINVAL, "no block map: pass 1 (hash proof, k <= 85) has not run%s");
-  if (e->bm2) return fail(errbuf, errlen, SMG_EINVAL, "the block map of a single-GPU run cannot be exchanged (smg_engine_set_blockmap_bits(30) before pass 1)%s");
-  const int64_t nwords = ((1ll << e->bm_bits) + 31) >> 5;
+  const int64_t nwords = (((1ll << e->bm_bits) + 31) >> 5) << e->bm2;
   if (word_lo < 0 || nw < 0 || word_lo + nw > nwords || (nw > 0 && !d_dst))
     return fail(errbuf, errlen, SMG_EINVAL, "block map range out of bounds%s");
   HIPCHK(hipSetDevice(e->device));
@@ -1434,7 +1434,7 @@ extern "C" int smg_engine_merge_maps(smg_engine *e, const uint32_t *d_parts, int
   if (!e->prepared || !e->bm_bits) return fail(errbuf, errlen, SMG_EINVAL, "no block map: pass 1 (hash proof, k <= 85) has not run%s");
   if (!d_parts || !d_full || !word_lo || !nwords_of || nranks < 1 || nranks > 16 || width < 1)
     return fail(errbuf, errlen, SMG_EINVAL, "bad merge_maps arguments (1..16 ranks)%s");
-  const int64_t nwords = ((1ll << e->bm_bits) + 31) >> 5;
+  const int64_t nwords = (((1ll << e->bm_bits) + 31) >> 5) << e->bm2;
   MapGeo geo;
   for (int r = 0; r < 16; r++) { geo.lo[r] = r < nranks ? word_lo[r] : 0; geo.ln[r] = r < nranks ? nwords_of[r] : 0; }
   for (int r = 0; r < nranks; r++)

@@ -107,13 +107,14 @@ static int multi_filter(MultiCtx *c, int r, smg_engine *e, const u64 *splitters,
 { const int n = c->n, bits = c->bm_bits[r];
   for (int s = 0; s < n; s++) if (c->bm_bits[s] != bits) return SMG_OK;       // (cannot happen: a function of k and the proof)
   if (!bits) return SMG_OK;
-  const int64_t nwords = ((1ll << bits) + 31) >> 5;
+  const int two = e->bm2;                            // 64-bit map words (two-bit map): twice the 32-bit words per id range
+  const int64_t nwords = (((1ll << bits) + 31) >> 5) << two;
   int64_t wlo[SMG_MAXGPU], wlen[SMG_MAXGPU], width = 1;
   for (int s = 0; s < n; s++)
     { const u64 a = s == 0 ? 0 : splitters[(size_t) (s - 1) * c->W] >> (64 - bits);
       const u64 b = s == n - 1 ? (1ull << bits) - 1 : splitters[(size_t) s * c->W] >> (64 - bits);
-      wlo[s] = (int64_t) (a >> 5);
-      wlen[s] = (int64_t) (b >> 5) - wlo[s] + 1;
+      wlo[s] = (int64_t) (a >> 5) << two;
+      wlen[s] = (((int64_t) (b >> 5) << two) - wlo[s]) + (1 << two);
       if (wlen[s] < 1) wlen[s] = 1;
       if (wlen[s] > width) width = wlen[s];
     }

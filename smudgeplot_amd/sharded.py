@@ -130,13 +130,14 @@ def fix_cut(keys_u64: np.ndarray, words: int, k: int, cut: int) -> int:
     return cut
 
 
-def blockmap_ranges(splitters, words: int, world: int, bits: int):
+def blockmap_ranges(splitters, words: int, world: int, bits: int, scale: int = 1):
     """Word ranges (first word, length) of the candidate block map that the k-mer ranges of the ranks cover.
     Block id = leading `bits` bits of a k-mer; rank r holds ids [id(first_r), id(first_{r+1})], so neighbours
-    share their boundary word (the receiver ORs the ranges together)."""
+    share their boundary word (the receiver ORs the ranges together).  scale = 32-bit words per 32 block ids
+    (2 for the engine's two-bit map: 64 bits per group)."""
     ids = [0] + [int(splitters[(r - 1) * words]) >> (64 - bits) for r in range(1, world)] + [(1 << bits) - 1]
-    wlo = [ids[r] >> 5 for r in range(world)]
-    wlen = [max((ids[r + 1] >> 5) - wlo[r] + 1, 1) for r in range(world)]
+    wlo = [(ids[r] >> 5) * scale for r in range(world)]
+    wlen = [max(((ids[r + 1] >> 5) + 1) * scale - wlo[r], 1) for r in range(world)]
     return wlo, wlen
 
 
@@ -226,7 +227,7 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
     if exchange:
         bits, nwords = eng.blockmap()
         if bits:
-            wlo, wlen = blockmap_ranges(splitters, words, world, bits)
+            wlo, wlen = blockmap_ranges(splitters, words, world, bits, nwords // (((1 << bits) + 31) >> 5))
             width = max(wlen)
             # the three map buffers live as long as the engine (a fresh 128 MB torch.zeros per step is a memset and
             # an allocator round trip; the merge kernel overwrites every word of `full`)

@@ -382,7 +382,7 @@ def _manual_sharded(k, tk, tc, cuts, dev, symcheck="hash"):
     assert all(en.blockmap() == (bits, nwords) for en in engs)        # empty shards included
     emitted = sum(en.nreq() for en in engs)
     if bits:                                   # request filter: the exchange of the candidate block maps, by hand
-        wlo, wlen = sharded.blockmap_ranges(split, 1, world, bits)
+        wlo, wlen = sharded.blockmap_ranges(split, 1, world, bits, nwords // (((1 << bits) + 31) >> 5))
         full = torch.zeros(nwords, dtype=torch.int32, device=dev)
         for r, en in enumerate(engs):
             part = torch.zeros(wlen[r], dtype=torch.int32, device=dev)

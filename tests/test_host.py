@@ -164,3 +164,6 @@ def test_blockmap_ranges_cover_the_map_and_share_only_boundary_words():
                     assert prev_end - 1 == wlo[r]
                     # the id of rank r's first k-mer falls into that shared word
                     assert (int(firsts[r - 1]) >> (64 - bits)) >> 5 == wlo[r]
+            # the engine's two-bit map: 64 bits per 32 block ids, the same ranges in units of two words
+            wlo2, wlen2 = sharded.blockmap_ranges(firsts, 1, world, bits, 2)
+            assert wlo2 == [2 * v for v in wlo] and wlen2 == [2 * v for v in wlen]
