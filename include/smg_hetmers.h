@@ -225,12 +225,15 @@ int     smg_engine_apply_own(smg_engine *e, int64_t *missing, char *errbuf, size
    whose target id has a clear bit, before the requests are routed, sorted or looked up.  Single shard:
    apply_own filters with the engine's own map.  Sharded: every rank copies out the words its k-mer
    range covers (blockmap_copy), the ranks exchange them, OR them into one map of `nwords` uint32 on
-   the device and pass that to filter, then route().  id_bits = 0: no map (exact proof or k > 64).
+   the device and pass that to filter, then route().  id_bits = 0: no map (exact proof or k > 85).
+   One-word k-mers of >= 24 bases use a TWO-BIT map: 64 bits per 32 block ids (the id bit in the low half, a
+   second bit hashed from the k-mer bits below the id in the high half; a request must find both), so
+   nwords = 2 * 2^id_bits / 32 and the words of ids [a, b] are [2 * (a >> 5), 2 * (b >> 5) + 2).
    No counterpart in the reference (it has no complement look-ups at all: PloidyPlot.c scans every
    position of every k-mer). */
 /* id bits of the block map that the NEXT smg_engine_pass1 builds (8..32; 0 = the default: 30, what a sharded run
-   exchanges -- 128 MB in total).  A caller that will not exchange maps (one rank) asks for 32: four times fewer
-   requests survive the filter, at the price of a 512 MB map that only this GPU ever reads.                    */
+   exchanges -- 128 MB, or 256 MB as a two-bit map).  A caller that will not exchange maps (one rank) asks for 32:
+   several times fewer requests survive the filter, at the price of a 0.5 - 1 GB map that only this GPU ever reads. */
 int     smg_engine_set_blockmap_bits(smg_engine *e, int id_bits);
 int     smg_engine_blockmap(smg_engine *e, int *id_bits, int64_t *nwords);
 int     smg_engine_blockmap_copy(smg_engine *e, int64_t word_lo, int64_t nw, uint32_t *d_dst,
