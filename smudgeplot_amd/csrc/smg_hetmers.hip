@@ -680,8 +680,11 @@ static int read_ctrl(smg_engine *e, char *errbuf, size_t errlen)
   return SMG_OK;
 }
 
-// directory geometry over the first key word: ~8-16 entries per bucket (one 128-byte line of k-mers)
-static int dir_geometry(smg_engine *e, char *errbuf, size_t errlen)
+// directory geometry over the first key word: `per` .. 2 `per` entries per bucket.  8 (one 128-byte line of k-mers) where
+// every entry is looked up (exact proof, counted and general paths); 64 for the hash proof, whose filter leaves a few
+// million look-ups: their bisection still stays inside one or two lines of signatures, while pass 1 writes -- and every
+// run clears -- an eighth of the directory (1 GB -> 128 MB at 2.5e9 entries: -0.5 ms per run).
+static int dir_geometry(smg_engine *e, int per, char *errbuf, size_t errlen)
 { u64 first = 0, last = 0;
   if (e->n > 0)
     { HIPCHK(hipMemcpyAsync(&first, e->keys, 8, hipMemcpyDeviceToHost, e->stream));
@@ -690,7 +693,8 @@ static int dir_geometry(smg_engine *e, char *errbuf, size_t errlen)
     }
   if (last < first) return fail(errbuf, errlen, SMG_EFORMAT, "table entries are not strictly increasing%s");
   int bits = 4;
-  while (bits < 30 && (1ll << (bits + 1)) <= e->n / 8) bits++;
+  { const char *v = getenv("SMG_DIR_PER"); if (v && atoi(v) >= 1) per = atoi(v); }       // tuning override
+  while (bits < 30 && (1ll << (bits + 1)) <= e->n / per) bits++;
   const uint32_t hf = (uint32_t) (first >> 32), hl = (uint32_t) (last >> 32);
   int dsh = 0;
   while (dsh < 31 && ((hl >> dsh) - (hf >> dsh)) >= (1u << bits)) dsh++;
@@ -719,7 +723,7 @@ static int counted_prepare(smg_engine *e, char *errbuf, size_t errlen)
   int rc = grow(&e->deg, &e->deg_cap, dbytes, errbuf, errlen);
   if (rc) return rc;
   HIPCHK(hipMemsetAsync(e->deg, 0, (size_t) dbytes, e->stream));
-  if ((rc = dir_geometry(e, errbuf, errlen))) return rc;
+  if ((rc = dir_geometry(e, 8, errbuf, errlen))) return rc;
   HIPCHK(hipMemsetAsync(e->bstart, 0xFF, sizeof(uint32_t) * ((size_t) e->dir.nb + 2), e->stream));
   Tab t = make_tab(e);
   const unsigned nblk = (unsigned) ((e->n + 1 + TPB - 1) / TPB);
@@ -876,7 +880,7 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
   if ((rc = grow(&e->deg, &e->deg_cap, ((e->n + 15) & ~15ll) + 32, errbuf, errlen))) return rc;
   const int64_t pbytes = ((e->n + 15) & ~15ll) + 32;
   if (e->W <= 2 && (rc = grow(&e->sig, &e->sig_cap, 2 * pbytes, errbuf, errlen))) return rc;
-  if ((rc = dir_geometry(e, errbuf, errlen))) return rc;
+  if ((rc = dir_geometry(e, (emit_all || e->W > 1) ? 8 : 64, errbuf, errlen))) return rc;
   // request filter: the candidate block map (an empty shard has one too -- all zero -- so that every rank of a
   // sharded run reports the same geometry and takes part in the exchange of the maps)
   e->bm_bits = 0; e->bm2 = 0;
