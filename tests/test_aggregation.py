@@ -1,0 +1,110 @@
+"""local aggregation of the .smu pixels (smudgeplot_amd/aggregation.py over csrc/smg_aggregate.c)
+against the REFERENCE's Coverages.local_aggregation: tests/golden/aggregation.json holds the reference's inputs (rows in
+the order it processed them) and labels, made by tests/golden/make_golden_aggregation.py, which imports the reference."""
+import ctypes as C
+import io
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from smudgeplot_amd import aggregation
+
+
+def cases():
+    with open(os.path.join(GOLDEN, "aggregation.json")) as f:
+        return json.load(f)
+
+
+CASES = cases()
+
+
+@pytest.mark.parametrize("i", range(len(CASES)))
+def test_labels_equal_the_reference(i):
+    c = CASES[i]
+    rows = np.array(c["rows"], dtype=np.int64)
+    peak, npk = aggregation.local_aggregation(rows[:, 0], rows[:, 1], rows[:, 2], c["distance"], c["noise_filter"], c["mask_errors"])
+    assert peak.tolist() == c["peaks"], (c["name"], c["distance"], c["noise_filter"], c["mask_errors"])
+    assert npk == max(max(c["peaks"]), 0)
+
+
+def test_golden_set_exercises_every_branch():
+    assert len(CASES) >= 20
+    labels = [set(c["peaks"]) for c in CASES]
+    assert any(-1 in s for s in labels) and any(0 in s for s in labels)          # error line, rows below the noise filter
+    assert any(c["mask_errors"] is False for c in CASES) and any(c["distance"] == 0 for c in CASES)
+    # a pixel that JOINED the error line (label -1 although it lies above it): the reference treats -1 as assigned
+    joined = 0
+    for c in CASES:
+        if not c["mask_errors"]:
+            continue
+        L = min(r[0] for r in c["rows"])
+        joined += sum(1 for r, p in zip(c["rows"], c["peaks"]) if p == -1 and r[0] >= L + c["distance"])
+    assert joined > 0
+
+
+def test_class_mirror_and_file_round_trip(tmp_path):
+    c = next(c for c in CASES if c["name"] == "tetraploid_cov18" and c["distance"] == 5 and c["noise_filter"] == 50)
+    rows = np.array(c["rows"], dtype=np.int64)
+    cov = aggregation.Coverages((rows[:, 0], rows[:, 1], rows[:, 2]))
+    cov.local_aggregation(distance=5, noise_filter=50, mask_errors=True)
+    assert [cov.cov2peak[(a, b)] for b, a, _ in c["rows"]] == c["peaks"]
+    out = io.StringIO()
+    cov.write_peaks(out)
+    lines = out.getvalue().splitlines()
+    assert len(lines) == len(rows)
+    keys = [(int(l.split("\t")[1]), int(l.split("\t")[0])) for l in lines]
+    assert keys == sorted(keys)                                                  # (covA, covB) ascending, smudgeplot.py:75
+    cov.count_kmers()
+    f = rows[:, 2]; p = np.array(c["peaks"])
+    assert cov.total_kmers == f.sum() and cov.total_error_kmers == f[p == -1].sum()
+    assert cov.total_genomic_kmers_in_smudges == f[p > 0].sum()
+    # load_hetmers: .smu text -> columns by freq descending
+    smu = tmp_path / "x.smu"
+    smu.write_text("".join(f"{b}\t{a}\t{fr}\n" for b, a, fr in sorted(c["rows"], key=lambda r: (r[0] + r[1], r[0]))))
+    b2, a2, f2 = aggregation.load_hetmers(str(smu))
+    assert len(f2) == len(rows) and np.all(np.diff(f2) <= 0) and sorted(zip(b2, a2, f2)) == sorted(map(tuple, c["rows"]))
+
+
+def test_edge_cases():
+    e = np.zeros(0, dtype=np.int64)
+    peak, npk = aggregation.local_aggregation(e, e, e, 5, 1, True)
+    assert len(peak) == 0 and npk == 0
+    peak, npk = aggregation.local_aggregation([7], [30], [12], 5, 1, False)
+    assert peak.tolist() == [1] and npk == 1
+    peak, npk = aggregation.local_aggregation([7], [30], [12], 5, 1, True)       # the only row IS the error line
+    assert peak.tolist() == [-1] and npk == 0
+    peak, npk = aggregation.local_aggregation([7], [30], [12], 5, 100, True)     # below the noise filter
+    assert peak.tolist() == [0] and npk == 0
+    with pytest.raises(RuntimeError):
+        aggregation.local_aggregation([-1], [30], [12], 5, 1, True)
+    with pytest.raises(ValueError):
+        aggregation.local_aggregation([1, 2], [30], [12], 5, 1, True)
+    # coordinates at the corner of the plot, a radius larger than the plot
+    peak, _ = aggregation.local_aggregation([499, 0], [501, 1000], [9, 8], 2000, 1, False)
+    assert peak.tolist() == [1, 1]
+
+
+def test_library_exports_what_the_header_declares():
+    hdr = open(os.path.join(ROOT, "include", "smg_aggregate.h")).read()
+    names = re.findall(r"\b(smg_[a-z_0-9]+)\s*\(", hdr)
+    assert names == ["smg_local_aggregation"]
+    lib = C.CDLL(os.path.join(ROOT, "smudgeplot_amd", "libsmg_aggregate.so"))
+    for n in names:
+        assert hasattr(lib, n)
+
+
+def test_speed_against_python_dictionaries():
+    """not a benchmark, a guard: the largest golden case (7668 rows) in well under the reference's time
+    (0.35 s in this container for distance 8)"""
+    import time
+    c = max(CASES, key=lambda c: len(c["rows"]) * (c["distance"] + 1) ** 2)
+    rows = np.array(c["rows"], dtype=np.int64)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        aggregation.local_aggregation(rows[:, 0], rows[:, 1], rows[:, 2], c["distance"], c["noise_filter"], c["mask_errors"])
+    dt = (time.perf_counter() - t0) / 20
+    assert dt < 0.05, dt
