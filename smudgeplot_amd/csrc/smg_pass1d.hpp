@@ -510,8 +510,6 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
   unsigned codes = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
 
   // ---- complement, fingerprint, requests: one entry at a time from the thread's own LDS copy ----------------------
-  // (a rolled loop: the four entries interleaved need ~30 more vector registers than the kernel has at six waves
-  //  per SIMD; the masks rotate through one register pair)
   //@mark D_RC
   D_SCHED_FENCE();
   if (!(D_ABL & 16) || A.want_fp())
@@ -529,9 +527,16 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
           base = (unsigned) __builtin_amdgcn_readfirstlane((int) base);
         }
       const bool fp = A.want_fp() && !(D_ABL & 1);
-#pragma unroll 1
+      // Unrolled, the four entries kept apart by scheduling fences (interleaved they need ~30 more vector registers
+      // than the kernel has).  The rolled loop -- the masks rotating through one register pair, a counter, two branches
+      // per entry -- cost 0.7 ms more: scalar instructions and branches are not free next to a busy vector unit
+      // (tools/issue_mix.hip).
+      const u64 EM[4] = { E0, E1, E2, E3 };
+#pragma unroll
       for (int e = 0; e < 4; e++)
-        { const Key<W> x = lds_key<W>(S.ent, slot0 + e);
+        { E0 = EM[e];
+          D_SCHED_FENCE();
+          const Key<W> x = lds_key<W>(S.ent, slot0 + e);
           const unsigned c = S.lcn[slot0 + e];
           const Key<W> rc = revcomp<W>(x, G.k);
           if (fp && owned)
@@ -558,7 +563,6 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
                 }
               base += (unsigned) __popcll(E0);
             }
-          const u64 r0 = E0; E0 = E1; E1 = E2; E2 = E3; E3 = r0;
         }
     }
   // the next tile's entries: issued here, used after the flush -- the latency of the loads (a few thousand cycles on a
