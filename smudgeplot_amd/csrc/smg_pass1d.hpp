@@ -56,6 +56,9 @@
 #else
 #define D_SCHED_FENCE()
 #endif
+#ifndef D_RC_WIDE
+#define D_RC_WIDE 1
+#endif
 #ifndef D_TAILB
 #define D_TAILB  8                         // tail: distances 4 .. D_TAILB + 3 come in batches of four LDS reads
 #endif
@@ -532,12 +535,33 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
       // per entry -- cost 0.7 ms more: scalar instructions and branches are not free next to a busy vector unit
       // (tools/issue_mix.hip).
       const u64 EM[4] = { E0, E1, E2, E3 };
+#if D_RC_WIDE
+      // the thread's four entries in two 16-byte LDS reads + one 8-byte read of the counts (four 8-byte reads at a lane
+      // stride of 32 bytes hit the same banks from eight lanes at a time)
+      Key<W> xs[4]; unsigned cs[4];
+      if constexpr (W == 1)
+        { const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(&S.ent[slot0]);
+          const ulonglong2 b = *reinterpret_cast<const ulonglong2 *>(&S.ent[slot0 + 2]);
+          xs[0].w[0] = a.x; xs[1].w[0] = a.y; xs[2].w[0] = b.x; xs[3].w[0] = b.y;
+        }
+      else
+        {
+#pragma unroll
+          for (int e = 0; e < 4; e++) xs[e] = lds_key<W>(S.ent, slot0 + e);
+        }
+      { const ushort4 c4 = *reinterpret_cast<const ushort4 *>(&S.lcn[slot0]); cs[0] = c4.x; cs[1] = c4.y; cs[2] = c4.z; cs[3] = c4.w; }
+#endif
 #pragma unroll
       for (int e = 0; e < 4; e++)
         { E0 = EM[e];
           D_SCHED_FENCE();
+#if D_RC_WIDE
+          const Key<W> x = xs[e];
+          const unsigned c = cs[e];
+#else
           const Key<W> x = lds_key<W>(S.ent, slot0 + e);
           const unsigned c = S.lcn[slot0 + e];
+#endif
           const Key<W> rc = revcomp<W>(x, G.k);
           if (fp && owned)
             { const bool lt = key_lt<W>(x, rc);
