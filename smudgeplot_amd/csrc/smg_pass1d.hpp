@@ -49,13 +49,18 @@
 #define D_BMW    (D_BMF / 32)
 #define D_HB     1024                      // bins of the request histogram (smg_lookup.hpp: L_BK)
 #define D_QCAP   1280                      // LDS request queue (records); flushed when the next tile might not fit
-// nothing is scheduled across this point: keeps the live ranges of the lane masks (SGPR pairs) short -- the machine
-// scheduler otherwise hoists every test's compare to the front and the kernel spills scalars by the dozen
+// Scheduling fences (nothing is scheduled across them).  They were put between the tests and between the phases when
+// the machine scheduler hoisted every compare to the front and the kernel spilled lane masks (SGPR pairs) by the dozen;
+// with today's kernel only the ones between the entries of the complement loop still pay (they keep its four entries
+// from being interleaved: ~30 vector registers): without the other two classes pass 1 takes 15.7 instead of 16.2 ms
+// (profiles/r02_pass1_ablation.txt, k).
 #ifndef D_NOFENCE
-#define D_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define D_SCHED_FENCE()
+#define D_NOFENCE 3                        // bit mask of fence classes LEFT OUT: 1 between tests, 2 between phases, 4 between the entries of the complement loop
 #endif
+#define D_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define D_FENCE_T() do { if (!(D_NOFENCE & 1)) D_SCHED_FENCE(); } while (0)
+#define D_FENCE_P() do { if (!(D_NOFENCE & 2)) D_SCHED_FENCE(); } while (0)
+#define D_FENCE_R() do { if (!(D_NOFENCE & 4)) D_SCHED_FENCE(); } while (0)
 #ifndef D_RC_WIDE
 #define D_RC_WIDE 1
 #endif
@@ -224,7 +229,7 @@ d_tests(const WT (&sx)[7], const unsigned (&cn)[4], const u64 (&Sm)[7], const Ge
           const unsigned w2c = ODD ? 0u : (unsigned) CODE_W2;
           code[a] = d_lane(h) ? ((unsigned) (31 + d) | w2c) : code[a];
           code[eb] = d_lane(hb) ? ((unsigned) (31 - d) | w2c) : code[eb];
-          D_SCHED_FENCE();
+          D_FENCE_T();
         }
     }
 }
@@ -331,7 +336,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
 
   // ---- order check + bucket directory (the first entry of every bucket stores its index) ------------------
   //@mark D_DIR
-  D_SCHED_FENCE();
+  D_FENCE_P();
   if (!(D_ABL & 2))
     { Key<W> nk0;
 #pragma unroll
@@ -367,7 +372,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
 
   // ---- signatures ---------------------------------------------------------------------------------------------------
   //@mark D_SIG
-  D_SCHED_FENCE();
+  D_FENCE_P();
   if (W <= 2 && !(D_ABL & 4) && owned)
     { unsigned sg[4];
 #pragma unroll
@@ -383,7 +388,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
 
   // ---- window-block structure as lane masks ---------------------------------------------------------------
   //@mark D_MASKS
-  D_SCHED_FENCE();
+  D_FENCE_P();
   // Sm[e]: entries e and e+1 share their first p0 bases (e = 4..6: the neighbour's 0..2)
   u64 Sm[7];
 #pragma unroll
@@ -426,7 +431,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
 
   // ---- the 12 one-away tests of a thread (distances 1..3), aggregated on the fly -----------------------------
   //@mark D_TESTS
-  D_SCHED_FENCE();
+  D_FENCE_P();
   // per entry e of a lane: npair[e] pairs seen (a carry-in add per hit mask), code[e]: delta code of the last pair seen
   // (the only one if the entry is unique), midM "has a pair on the self-mirrored position".  The b side of a test
   // with b >= 4 is entry b - 4 of the right neighbour lane: the same mask, shifted up by one lane.
@@ -456,7 +461,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
 
   // ---- request filter: a CANDIDATE (exactly one suffix-side pair) sets the bit of its block id -------------------
   //@mark D_BMAP
-  D_SCHED_FENCE();
+  D_FENCE_P();
   // word 0 of the tile's LDS bit map = the map word of the tile's first owned entry (a uniform, scalar load)
   const uint32_t bmbase = D_BM ? (((uint32_t) (A.keys[(g0 + D_LEAD) * W] >> 32) >> bmsh) & ~31u) : 0u;
   if (D_BM && A.bmap && !(D_ABL & 8))
@@ -514,7 +519,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
 
   // ---- complement, fingerprint, requests: one entry at a time from the thread's own LDS copy ----------------------
   //@mark D_RC
-  D_SCHED_FENCE();
+  D_FENCE_P();
   if (!(D_ABL & 16) || A.want_fp())
     { // hash proof: rc(x) of every owned entry that owns a pair at p > k-1-p.  (The tail can only ADD pairs: an entry
       // that gets its first hi-side pair there sends late, below.  The exact proof sends everything after the tail.)
@@ -554,7 +559,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
 #pragma unroll
       for (int e = 0; e < 4; e++)
         { E0 = EM[e];
-          D_SCHED_FENCE();
+          D_FENCE_R();
 #if D_RC_WIDE
           const Key<W> x = xs[e];
           const unsigned c = cs[e];
@@ -655,7 +660,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
 
   // ---- merge the tail's hand-overs (rare: a wave-uniform branch per entry), store the code bytes ------------------
   //@mark D_MERGE
-  D_SCHED_FENCE();
+  D_FENCE_P();
   { const uint4 rv = *reinterpret_cast<const uint4 *>(&S.cred[slot0]);
     const unsigned R[4] = { rv.x, rv.y, rv.z, rv.w };
     u64 VL[4] = { ~0ull, ~0ull, ~0ull, ~0ull };
