@@ -73,12 +73,22 @@ kl_scan(const unsigned *__restrict__ ghist, int nbk, u64 *__restrict__ boff /* [
 // row w into the first output slot of owner w in every bucket.  One wave per bucket, a lane per slice of the owners.
 #define LW_BPW 16                          // buckets per workgroup (one 64-byte segment of a row)
 
+// (the rows of a lane are loaded eight at a time, independent loads in flight together: a lane that walked its ~24 rows
+//  one dependent L2 round trip after the other made kl_woff take 55 us)
+#define LW_UNR 8
+
 __global__ void __launch_bounds__(64 * LW_BPW)
 kl_tot(const unsigned *__restrict__ whist, unsigned nown, unsigned *__restrict__ tot /* [L_BK] */)
 { const int lane = threadIdx.x & 63, b = blockIdx.x * LW_BPW + (threadIdx.x >> 6);
   const unsigned per = (nown + 63) / 64, w0 = lane * per, w1 = w0 + per < nown ? w0 + per : nown;
   unsigned s = 0;
-  for (unsigned w = w0; w < w1; w++) s += whist[(size_t) w * L_BK + b];
+  for (unsigned w = w0; w < w1; w += LW_UNR)
+    { unsigned v[LW_UNR];
+#pragma unroll
+      for (int j = 0; j < LW_UNR; j++) v[j] = w + j < w1 ? whist[(size_t) (w + j) * L_BK + b] : 0u;
+#pragma unroll
+      for (int j = 0; j < LW_UNR; j++) s += v[j];
+    }
 #pragma unroll
   for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o, 64);
   if (lane == 0) tot[b] = s;
@@ -89,7 +99,13 @@ kl_woff(unsigned *__restrict__ whist /* in: counts, out: first slots */, unsigne
 { const int lane = threadIdx.x & 63, b = blockIdx.x * LW_BPW + (threadIdx.x >> 6);
   const unsigned per = (nown + 63) / 64, w0 = lane * per, w1 = w0 + per < nown ? w0 + per : nown;
   unsigned s = 0;
-  for (unsigned w = w0; w < w1; w++) s += whist[(size_t) w * L_BK + b];
+  for (unsigned w = w0; w < w1; w += LW_UNR)
+    { unsigned v[LW_UNR];
+#pragma unroll
+      for (int j = 0; j < LW_UNR; j++) v[j] = w + j < w1 ? whist[(size_t) (w + j) * L_BK + b] : 0u;
+#pragma unroll
+      for (int j = 0; j < LW_UNR; j++) s += v[j];
+    }
   unsigned incl = s;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1)
@@ -97,10 +113,13 @@ kl_woff(unsigned *__restrict__ whist /* in: counts, out: first slots */, unsigne
       if (lane >= o) incl += v;
     }
   unsigned run = (unsigned) boff[b] + incl - s;               // (slots are 32-bit: a shard holds < 2^32 requests)
-  for (unsigned w = w0; w < w1; w++)
-    { const unsigned c = whist[(size_t) w * L_BK + b];
-      whist[(size_t) w * L_BK + b] = run;
-      run += c;
+  for (unsigned w = w0; w < w1; w += LW_UNR)
+    { unsigned v[LW_UNR];
+#pragma unroll
+      for (int j = 0; j < LW_UNR; j++) v[j] = w + j < w1 ? whist[(size_t) (w + j) * L_BK + b] : 0u;
+#pragma unroll
+      for (int j = 0; j < LW_UNR; j++)
+        if (w + j < w1) { whist[(size_t) (w + j) * L_BK + b] = run; run += v[j]; }
     }
 }
 
