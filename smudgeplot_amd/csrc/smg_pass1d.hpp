@@ -730,12 +730,15 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
   }
 }
 
+#ifndef D_WAVES_W2
+#define D_WAVES_W2 4                       // two-word k-mers: waves per SIMD (3: 2 % slower, 2: 35 %)
+#endif
 #ifndef D_WAVES_PER_EU
 #define D_WAVES_PER_EU 5
 #endif
 
 template <int W, int RW, bool ODD, bool KF> __global__ void __launch_bounds__(D_TPB)
-__attribute__((amdgpu_waves_per_eu(W == 2 ? 3 : (RW == 1 ? D_WAVES_PER_EU : 5), W == 2 ? 3 : (RW == 1 ? D_WAVES_PER_EU : 5))))
+__attribute__((amdgpu_waves_per_eu(W == 2 ? D_WAVES_W2 : (RW == 1 ? D_WAVES_PER_EU : 5), W == 2 ? D_WAVES_W2 : (RW == 1 ? D_WAVES_PER_EU : 5))))
 kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
 { __shared__ unsigned cred[D_CRED];      // tail hand-overs per entry: count | delta code << 8 | mid << 24 | BIG
   __shared__ uint16_t tailq[D_SCAN];     // slots of the entries whose window block goes on past distance 3
