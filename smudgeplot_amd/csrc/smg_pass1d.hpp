@@ -731,7 +731,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
 }
 
 #ifndef D_WAVES_W2
-#define D_WAVES_W2 4                       // two-word k-mers: waves per SIMD (3: 2 % slower, 2: 35 %)
+#define D_WAVES_W2 3                       // two-word k-mers: waves per SIMD (4 cannot be met: the compiler stays at 3; 2: 35 % slower)
 #endif
 #ifndef D_WAVES_PER_EU
 #define D_WAVES_PER_EU 5
