@@ -10,7 +10,8 @@
  *  of the reference).
  *
  *  Replaces: Coverages.local_aggregation, src/smudgeplot/smudgeplot.py:29-69
- *            (called from cli.py:407,411 on load_hetmers' table: rows sorted by freq, descending).
+ *            (called from cli.py:407,411 on load_hetmers' table: rows sorted by freq, descending),
+ *            and the cell statistics of the 1n-coverage grid search (get_smudge_container + get_centrality).
  *
  ********************************************************************************************/
 #ifndef SMG_AGGREGATE_H
@@ -33,6 +34,21 @@ extern "C" {
 int smg_local_aggregation(const int32_t *covB, const int32_t *covA, const int64_t *freq, int64_t n,
                           int32_t distance, int64_t noise_filter, int32_t mask_errors,
                           int32_t *peak, int32_t *npeaks);
+
+/* Fishnet centrality of a 1n-coverage candidate (the inner loop of the reference's coverage grid search).
+   Replaces: Smudges.get_smudge_container(cov, smudge_filter, "fishnet") + get_centrality(container, cov),
+             src/smudgeplot/smudgeplot.py:150-176, 307-352, 799-802, as called from get_best_coverage (:137-148).
+   rows i = 0 .. n-1 in the caller's order (the reference: sorted by covA, covB after peak_aggregation, :75); rows with
+   smudge[i] == -1 (error line) are ignored.  For every candidate cov the pixels are cut into the cells
+   (As, Bs), Bs = 1..8, As = Bs..16-Bs, by the OPEN intervals cov*(X-0.5) < c < cov*(X+0.5) (X = 1: 0 < c); a cell
+   counts if its pairs / total_genomic_kmers > smudge_filter; its centre is its first row of maximal freq; the
+   result is the freq-weighted mean of |cA - cov*As| / cov + |cB - cov*Bs| / cov over the cells in (Bs, As) order,
+   computed with exactly rounded sums like Python's statistics.fmean -- so that the doubles, and with them the
+   argmin over a coverage grid, are the reference's bit for bit.  No cell passes: 1.0.
+   returns 0, or -1 on bad arguments / out of memory                                                      */
+int smg_fishnet_centralities(const int32_t *covB, const int32_t *covA, const int64_t *freq, const int32_t *smudge,
+                             int64_t n, int64_t total_genomic_kmers, double smudge_filter,
+                             const double *cov, int64_t ncov, double *centrality);
 
 #ifdef __cplusplus
 }

@@ -95,3 +95,64 @@ class Coverages:
         self.total_genomic_kmers_in_smudges = int(f[s > 0].sum())
         self.total_error_kmers = int(f[s == -1].sum())
         self.error_fraction = self.total_error_kmers / self.total_kmers
+
+
+def fishnet_centralities(covB, covA, freq, smudge, total_genomic_kmers, covs, smudge_filter=0.0):
+    """centrality of every 1n-coverage candidate in `covs` (float64 array): smudgeplot.py:150-176 + 307-352, in C"""
+    covB = np.ascontiguousarray(covB, dtype=np.int32)
+    covA = np.ascontiguousarray(covA, dtype=np.int32)
+    freq = np.ascontiguousarray(freq, dtype=np.int64)
+    smudge = np.ascontiguousarray(smudge, dtype=np.int32)
+    covs = np.ascontiguousarray(covs, dtype=np.float64)
+    out = np.zeros(len(covs), dtype=np.float64)
+    lib = _lib()
+    lib.smg_fishnet_centralities.restype = C.c_int
+    lib.smg_fishnet_centralities.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                             C.c_double, C.c_void_p, C.c_int64, C.c_void_p]
+    rc = lib.smg_fishnet_centralities(covB.ctypes.data, covA.ctypes.data, freq.ctypes.data, smudge.ctypes.data, len(freq),
+                                      int(total_genomic_kmers), float(smudge_filter), covs.ctypes.data, len(covs),
+                                      out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("smg_fishnet_centralities failed")
+    return out
+
+
+class Smudges:
+    """The 1n-coverage grid search of the reference's class of the same name (smudgeplot.py:96-148): the same three
+    grids (step 2, then 0.2 around the best, then 0.01 around that, then best/2 "just to be sure"), the same
+    arrays in `centrality_df` (a dict of two float64 arrays instead of a DataFrame), the same `cov`.
+    cov_tab = (covB, covA, freq, smudge) in the reference's order after peak_aggregation (by covA, covB)."""
+
+    def __init__(self, cov_tab, total_genomic_kmers):
+        self.covB, self.covA, self.freq, self.smudge = (np.asarray(c) for c in cov_tab)
+        self.total_genomic_kmers = int(total_genomic_kmers)
+        self.cov = None
+        self.centrality_df = None
+
+    def get_best_coverage(self, cov_list, smudge_size_cutoff=0.02, centralities=None, last_check=False):
+        if centralities is None:
+            centralities = []
+        to_test = cov_list[-1:] if last_check else cov_list
+        centralities = list(centralities) + fishnet_centralities(self.covB, self.covA, self.freq, self.smudge,
+                                                                 self.total_genomic_kmers, to_test, smudge_size_cutoff).tolist()
+        return cov_list[int(np.argmin(centralities))], centralities
+
+    def get_centrality_df(self, min_c, max_c, smudge_size_cutoff=0.02, log=None):
+        grid_params = [(0.05, 0.05, 2), (-1.9, 1.9, 0.2), (-0.19, 0.19, 0.01)]
+        results = []
+        for i, params in enumerate(grid_params):
+            cov_list = np.arange(int(min_c) + params[0], int(max_c) + params[1], params[2])
+            best_cov, centralities = self.get_best_coverage(cov_list, smudge_size_cutoff)
+            results.append({"covs": cov_list, "centralities": centralities, "best_cov": best_cov})
+            min_c, max_c = best_cov, best_cov
+            if i > 0 and log:
+                log.write(f"Best coverage to precision of 1/{10**i}: {best_cov:.2f}\n")
+        results[-1]["covs"] = np.append(results[-1]["covs"], results[-1]["best_cov"] / 2)
+        best_cov, centralities = self.get_best_coverage(cov_list=results[-1]["covs"], smudge_size_cutoff=smudge_size_cutoff,
+                                                        centralities=results[-1]["centralities"], last_check=True)
+        results[-1]["centralities"] = centralities
+        if log:
+            log.write(f"Best coverage to precision of 1/{10**i} (just to be sure): {best_cov:.2f}\n")
+        self.cov = best_cov
+        self.centrality_df = {"coverage": np.concatenate([r["covs"] for r in results]),
+                              "centrality": np.concatenate([np.asarray(r["centralities"], dtype=np.float64) for r in results])}

@@ -12,6 +12,7 @@
  *      join the error line (smudgeplot.py:58, "if cov2peak[...]" is true for -1).
  *
  ********************************************************************************************/
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 #include "smg_aggregate.h"
@@ -67,5 +68,102 @@ int smg_local_aggregation(const int32_t *covB, const int32_t *covA, const int64_
 #undef AT
   if (npeaks) *npeaks = next_peak - 1;
   free(F); free(P);
+  return 0;
+}
+
+/* ---- fishnet centrality ------------------------------------------------------------------------------------ */
+
+/* exactly rounded sum of doubles (Shewchuk's algorithm, the one behind Python's math.fsum, which statistics.fmean
+   uses for numerator and denominator): partials hold a non-overlapping expansion of the running sum */
+typedef struct { double p[40]; int n; } fsum_t;
+
+static void fsum_add(fsum_t *f, double x)
+{ int i, j = 0;
+  for (i = 0; i < f->n; i++)
+    { double y = f->p[i], hi, lo;
+      if (fabs(x) < fabs(y)) { double t = x; x = y; y = t; }
+      hi = x + y;
+      lo = y - (hi - x);
+      if (lo != 0.0) f->p[j++] = lo;
+      x = hi;
+    }
+  f->p[j++] = x;
+  f->n = j;
+}
+
+static double fsum_result(const fsum_t *f)
+{ /* msum's final step: sum the partials from the top, then fix the round-half-even case */
+  int n = f->n;
+  double hi = 0.0, lo = 0.0;
+  if (n == 0) return 0.0;
+  hi = f->p[--n];
+  while (n > 0)
+    { const double x = hi, y = f->p[--n];
+      hi = x + y;
+      lo = y - (hi - x);
+      if (lo != 0.0) break;
+    }
+  if (n > 0 && ((lo < 0.0 && f->p[n - 1] < 0.0) || (lo > 0.0 && f->p[n - 1] > 0.0)))
+    { const double y = lo * 2.0, x = hi + y, yr = x - hi;
+      if (y == yr) hi = x;
+    }
+  return hi;
+}
+
+/* the cell index X (1-based) of coverage c on the grid of candidate cov: cov*(X-0.5) < c < cov*(X+0.5), X = 1: 0 < c;
+   0 = on a cell border, below the grid or above cell `maxX` */
+static int cell_of(int32_t c, double cov, int maxX)
+{ int X = (int) ((double) c / cov + 0.5), d;
+  for (d = -1; d <= 1; d++)                                 /* (the rounding of the quotient may be off by one: test) */
+    { const int x = X + d;
+      if (x >= 1 && x <= maxX)
+        { const double lo = x == 1 ? 0.0 : cov * ((double) x - 0.5), hi = cov * ((double) x + 0.5);
+          if ((double) c > lo && (double) c < hi) return x;
+        }
+    }
+  return 0;
+}
+
+int smg_fishnet_centralities(const int32_t *covB, const int32_t *covA, const int64_t *freq, const int32_t *smudge,
+                             int64_t n, int64_t total_genomic_kmers, double smudge_filter,
+                             const double *cov, int64_t ncov, double *centrality)
+{ int64_t q, i;
+  if (n < 0 || ncov < 0 || (n > 0 && (!covB || !covA || !freq || !smudge)) || (ncov > 0 && (!cov || !centrality))) return -1;
+  for (q = 0; q < ncov; q++)
+    { /* cells [Bs 1..8][As 1..15] */
+      int64_t sum[9][16], best_f[9][16];
+      int32_t cA[9][16], cB[9][16];
+      int Bs, As, any = 0;
+      fsum_t num, den;
+      const double c = cov[q];
+      memset(sum, 0, sizeof(sum)); memset(cA, 0, sizeof(cA)); memset(cB, 0, sizeof(cB));
+      for (Bs = 0; Bs < 9; Bs++) for (As = 0; As < 16; As++) best_f[Bs][As] = -1;
+      if (!(c > 0.0)) { centrality[q] = 1.0; continue; }
+      for (i = 0; i < n; i++)
+        { int b, a;
+          if (smudge[i] == -1) continue;
+          b = cell_of(covB[i], c, 8);
+          if (!b) continue;
+          a = cell_of(covA[i], c, 16 - b);                                  /* As in Bs .. 16-Bs: range(Bs, 17-Bs), :163 */
+          if (a < b) continue;
+          sum[b][a] += freq[i];
+          if (freq[i] > best_f[b][a]) { best_f[b][a] = freq[i]; cA[b][a] = covA[i]; cB[b][a] = covB[i]; }    /* idxmax: first maximum */
+        }
+      num.n = den.n = 0;
+      for (Bs = 1; Bs <= 8; Bs++)
+        for (As = Bs; As < 17 - Bs; As++)
+          { if (best_f[Bs][As] < 0) continue;                                   /* (an empty cell: 0 / total > filter is false for filter >= 0;
+                                                                                   for a negative filter the reference's idxmax would raise) */
+            if ((double) sum[Bs][As] / (double) total_genomic_kmers > smudge_filter)
+              { const double dA = fabs(((double) cA[Bs][As] - c * (double) As) / c);
+                const double dB = fabs(((double) cB[Bs][As] - c * (double) Bs) / c);
+                const double cen = dA + dB;
+                fsum_add(&num, cen * (double) sum[Bs][As]);
+                fsum_add(&den, (double) sum[Bs][As]);
+                any = 1;
+              }
+          }
+      centrality[q] = any ? fsum_result(&num) / fsum_result(&den) : 1.0;
+    }
   return 0;
 }

@@ -91,7 +91,7 @@ def test_edge_cases():
 def test_library_exports_what_the_header_declares():
     hdr = open(os.path.join(ROOT, "include", "smg_aggregate.h")).read()
     names = re.findall(r"\b(smg_[a-z_0-9]+)\s*\(", hdr)
-    assert names == ["smg_local_aggregation"]
+    assert names == ["smg_local_aggregation", "smg_fishnet_centralities"]
     lib = C.CDLL(os.path.join(ROOT, "smudgeplot_amd", "libsmg_aggregate.so"))
     for n in names:
         assert hasattr(lib, n)
@@ -108,3 +108,42 @@ def test_speed_against_python_dictionaries():
         aggregation.local_aggregation(rows[:, 0], rows[:, 1], rows[:, 2], c["distance"], c["noise_filter"], c["mask_errors"])
     dt = (time.perf_counter() - t0) / 20
     assert dt < 0.05, dt
+
+
+# ---- the coverage grid search (second half of the row) ---------------------------------------------------------------
+
+def centrality_cases():
+    with open(os.path.join(GOLDEN, "centrality.json")) as f:
+        return json.load(f)
+
+
+CCASES = centrality_cases()
+
+
+@pytest.mark.parametrize("i", range(len(CCASES)))
+def test_grid_search_equals_the_reference(i):
+    """every tested coverage, its centrality (the same double, bit for bit) and the winner of Smudges.get_centrality_df"""
+    c = CCASES[i]
+    rows = np.array(c["rows"], dtype=np.int64)
+    s = aggregation.Smudges((rows[:, 0], rows[:, 1], rows[:, 2], rows[:, 3]), c["total_genomic_kmers"])
+    s.get_centrality_df(c["min_c"], c["max_c"], c["cutoff"])
+    assert s.centrality_df["coverage"].tolist() == c["coverage"]
+    got, want = s.centrality_df["centrality"], np.array(c["centrality"])
+    assert got.tobytes() == want.tobytes(), np.abs(got - want).max()
+    assert float(s.cov) == c["best"]
+
+
+def test_centrality_cells_by_hand():
+    """two pixels, cov = 10: (covB 10, covA 10) is cell AB at its centre, (covB 10, covA 21) is cell AAB one off"""
+    b = np.array([10, 10]); a = np.array([10, 21]); f = np.array([300, 100]); sm = np.array([1, 2])
+    out = aggregation.fishnet_centralities(b, a, f, sm, 400, np.array([10.0]))
+    assert out[0] == (0.0 * 300 + 0.1 * 100) / 400
+    # error-line pixels do not count; nothing left: 1.0
+    out = aggregation.fishnet_centralities(b, a, f, np.array([-1, -1]), 400, np.array([10.0, 7.5]))
+    assert out.tolist() == [1.0, 1.0]
+    # a pixel exactly on a cell border (covB = 15 = 10 * 1.5) belongs to no cell
+    out = aggregation.fishnet_centralities([15], [15], [5], [1], 5, np.array([10.0]))
+    assert out[0] == 1.0
+    # the size cut-off is a strict "greater than"
+    out = aggregation.fishnet_centralities(b, a, f, sm, 400, np.array([10.0]), smudge_filter=0.25)
+    assert out[0] == 0.0                                    # only the 300-pair cell (0.75 > 0.25; 0.25 > 0.25 is false)
