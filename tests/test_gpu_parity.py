@@ -851,3 +851,24 @@ def test_exact_proof_is_not_fooled_by_a_signature_twin():
         plot, st = engine.hetmers_run(table_from(packed, nc, k), symcheck=mode)
         assert st["path"] == 2, mode
         assert np.array_equal(plot, want), mode
+
+
+@pytest.mark.parametrize("env", [{"SMG_ONE_BIT_MAP": "1"}, {"SMG_OLD_LOOKUP": "1"}, {"SMG_LOOKUP_SPLIT": "1"}, {"SMG_BM_BITS": "30"},
+                                 {"SMG_BM_BITS": "24", "SMG_ONE_BIT_MAP": "1"}, {"SMG_DIR_PER": "8"}, {"SMG_DIR_PER": "200"},
+                                 {"SMG_NO_FILTER": "1"}])
+@pytest.mark.parametrize("k,m,seed", [(31, 60000, 21), (27, 40000, 22), (24, 30000, 23)])
+def test_every_variant_of_the_lookup_chain_gives_the_same_plot(k, m, seed, env, monkeypatch):
+    """the A/B switches of the look-up chain: two-bit / one-bit map, round-1 chain, survivor list
+    instead of fused look-ups, map width, directory bucket size, no filter at all -- one answer"""
+    packed, cnt = synth.adversarial_table(k, m, 4, seed, low_complexity=60, dense=1)
+    tab = table_from(packed, cnt, k)
+    base, st0 = engine.hetmers_run(tab, symcheck="hash")
+    for name, val in env.items():
+        monkeypatch.setenv(name, val)
+    plot, st = engine.hetmers_run(tab, symcheck="hash")
+    assert np.array_equal(plot, base), env
+    assert st["path"] == st0["path"] == 1 and st["nemitted"] == st0["nemitted"]
+    if "SMG_NO_FILTER" in env:
+        assert st["nrequests"] == st["nemitted"]
+    elif env == {"SMG_ONE_BIT_MAP": "1"}:
+        assert st["nrequests"] >= st0["nrequests"]          # the second bit can only drop more
