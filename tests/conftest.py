@@ -15,6 +15,7 @@ ORACLE_BIN = os.path.join(ROOT, "oracle", "_build", "hetmers_oracle")
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "hetmers_ref")
 HETMERS_BIN = os.path.join(ROOT, "smudgeplot_amd", "bin", "hetmers")
 LIB = os.path.join(ROOT, "smudgeplot_amd", "libsmg_hetmers.so")
+AGG_LIB = os.path.join(ROOT, "smudgeplot_amd", "libsmg_aggregate.so")
 
 
 def pytest_configure(config):
@@ -52,7 +53,7 @@ def load_golden(name):
 @pytest.fixture(scope="session", autouse=True)
 def built():
     """Make sure the native pieces exist (no-op when they were built already)."""
-    if not (os.path.exists(LIB) and os.path.exists(HETMERS_BIN)):
+    if not (os.path.exists(LIB) and os.path.exists(HETMERS_BIN) and os.path.exists(AGG_LIB)):
         subprocess.run(["make", "-C", os.path.join(ROOT, "smudgeplot_amd", "csrc"), "all"], check=True)
     if not os.path.exists(ORACLE_BIN):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"], check=True)
