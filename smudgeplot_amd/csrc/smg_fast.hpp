@@ -853,20 +853,24 @@ kf_route_scatter(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk
 // Entries deferred by kf_pass1_r (their window block is longer than the +-30 entry window): exact walk by
 // binary searches, final code byte, and -- for the ones that own a pair at p > k-1-p -- a request.
 // One chunk per workgroup iteration batch, same chunk list as pass 1.
-template <int W, int RW> __global__ void __launch_bounds__(F_TPB)
+// 1024 threads per workgroup: every entry is a chain of ~800 dependent bisection steps (L2 hits), and the grid is capped
+// by the owner rows of the look-up chain (256 workgroups) -- with 256 threads a SIMD held ONE wave and 4.9e6 deferred
+// entries (5 % repeats in a 1 Gbp genome) took 8.8 ms.
+#define BF_TPB 1024
+template <int W, int RW> __global__ void __launch_bounds__(BF_TPB)
 kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, unsigned nbig, u64 *__restrict__ req,
           uint32_t *__restrict__ chunk_fill, unsigned max_chunks, FastCtl *__restrict__ ctl,
           unsigned *__restrict__ whist /* this kernel's rows */, unsigned owner0, unsigned owners, int hbits)
 { constexpr int rw = RW;
-  __shared__ u64      sq[F_TPB * RW];
+  __shared__ u64      sq[BF_TPB * RW];
   __shared__ unsigned hist[1024];       // requests of this workgroup per look-up bucket (a row of whist, like pass 1's)
   __shared__ unsigned s_qn, s_chunk, s_used;
   __shared__ u64      s_base, s_total;
   const int t = threadIdx.x;
   if (t == 0) { s_qn = 0; s_chunk = F_NOCHUNK; s_used = 0; s_total = 0; }
-  for (int b = t; b < 1024; b += F_TPB) hist[b] = 0;
+  for (int b = t; b < 1024; b += BF_TPB) hist[b] = 0;
   __syncthreads();
-  for (unsigned r0 = blockIdx.x * F_TPB; r0 < nbig; r0 += gridDim.x * F_TPB)
+  for (unsigned r0 = blockIdx.x * BF_TPB; r0 < nbig; r0 += gridDim.x * BF_TPB)
     { const unsigned r = r0 + t;
       if (r < nbig)
         { const int64_t i = biglist[r];
@@ -906,7 +910,7 @@ kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, unsigned nbig, u64 *
           __syncthreads();
           if (s_chunk < max_chunks)
             { u64 *o = req + s_base * rw;
-              for (unsigned e = t; e < qn * rw; e += F_TPB) o[e] = sq[e];
+              for (unsigned e = t; e < qn * rw; e += BF_TPB) o[e] = sq[e];
             }
         }
       __syncthreads();
@@ -917,5 +921,5 @@ kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, unsigned nbig, u64 *
       if (s_total) atomicAdd(&ctl->nreq, s_total);
     }
   if (whist && hbits)
-    for (int b = t; b < 1024; b += F_TPB) whist[(size_t) blockIdx.x * 1024 + b] = hist[b];
+    for (int b = t; b < 1024; b += BF_TPB) whist[(size_t) blockIdx.x * 1024 + b] = hist[b];
 }

@@ -456,7 +456,7 @@ k_extract(Tab t, const uint16_t *__restrict__ labels, u64 *__restrict__ out, u64
 #define FAST_MAX_K   85        // above this a uint8 degree can wrap: counted path (v1 kernels)
 #define P1_GRID      1280      // persistent workgroups of the generic kf_pass1<W> (5 per CU resident: LDS bound)
 #define P1_MAXGRID   4096      // upper bound of any pass-1 grid (partial fingerprint sums)
-#define BF_MAXGRID   256       // workgroups of kf_bigfix
+#define BF_MAXGRID   512       // workgroups of kf_bigfix (1024 threads each: two per CU)
 #define P2_GRID      512       // persistent workgroups of kf_pass2 (2 per CU: 43.7 KB plot tile + 32 KB queue each)
 
 struct smg_engine
@@ -953,6 +953,14 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
   bool done = false;
   for (int attempt = 0; attempt < 4 && !done; attempt++)
     { unsigned maxc = (unsigned) ((want_rec + F_CH - 1) / F_CH);
+      if (e->lg.nb)
+        { // look-up chain: owner w fills the slots w, w + G, w + 2G, .. (G = workgroups of this launch + those of kf_bigfix),
+          // so the list must hold G times the chunks of the busiest owner -- pass 1 deals its tiles round-robin, the owners
+          // are balanced to a few per cent -- and the slots of the kf_bigfix owners stay empty on a table without long blocks
+          const int64_t G = (int64_t) grid + BF_MAXGRID;
+          const int64_t per = ((int64_t) maxc + grid - 1) / grid + 2;
+          if (per * G > (int64_t) maxc && per * G < 0x7FFFFFFFll) maxc = (unsigned) (per * G);
+        }
       { const int64_t have = e->req_cap / ((int64_t) F_CH * (int64_t) sizeof(u64) * e->rw);
         if (e->req && have > (int64_t) maxc && have < 0x7FFFFFFFll) maxc = (unsigned) have;
       }
@@ -1020,10 +1028,10 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
       if (narrow && e->h_ctrl->fast.nbig > 0)
         { // exact redo of the entries whose window block is longer than the halo
           const unsigned nbig = e->h_ctrl->fast.nbig;
-          unsigned fb = (nbig + F_TPB - 1) / F_TPB;
+          unsigned fb = (nbig + BF_TPB - 1) / BF_TPB;
           if (fb > BF_MAXGRID) fb = BF_MAXGRID;
 
-#define BIGFIX(W_, RW_) hipLaunchKernelGGL((kf_bigfix<W_, RW_>), dim3(fb), dim3(F_TPB), 0, e->stream, a, e->biglist, nbig, e->req, \
+#define BIGFIX(W_, RW_) hipLaunchKernelGGL((kf_bigfix<W_, RW_>), dim3(fb), dim3(BF_TPB), 0, e->stream, a, e->biglist, nbig, e->req, \
                               e->chunk_fill, maxc, &e->ctrl->fast, e->lg.nb ? e->whist + (size_t) grid * L_BK : (unsigned *) NULL, \
                               grid, grid + BF_MAXGRID, e->lg.nb)
           hipEventRecord(e->ev[0], e->stream);
