@@ -49,7 +49,7 @@ extern "C" {
    PloidyPlot.c:1199-1229).  If the proof fails the engine silently switches to the general
    all-positions path, which assumes nothing, so the answer is the reference's either way. */
 #define SMG_SYM_EXACT  0     /* look up the complement of EVERY entry (exact, ~4x slower)      */
-#define SMG_SYM_HASH   1     /* 128-bit additive multiset fingerprint of T vs rc(T) + exact   */
+#define SMG_SYM_HASH   1     /* 128-bit XOR multiset fingerprint of canonical (k-mer, count) + exact */
                              /* look-ups for the entries that own a pair (what the `hetmers`  */
                              /* executable and bench.py use unless told otherwise)            */
 #define SMG_SYM_NONE   2     /* never use the symmetry identity: general path only            */
@@ -187,6 +187,29 @@ int smg_engine_bind(smg_engine *e, int kmer, int64_t nels, const uint64_t *d_key
 int smg_engine_condition(smg_engine *e, int ethresh, int do_trim, int do_symm,
                          int64_t *new_nels, char *errbuf, size_t errlen);
 
+/* ---- symmetrising a table that is cut into prefix shards (several GPUs, or more than 2^32 entries) --------------
+   The reference hands a table of any size to Symmex (PloidyPlot.c:1395-1414).  Sharded, the same closure takes one
+   exchange: every shard sends each of its entries AND the reverse complement of each to the shard whose k-mer range
+   holds it, the receivers sort and keep one entry per k-mer.
+   symm_hist  : hist[0 .. 2^bits) = this shard's entries, hist[2^bits .. 2^(bits+1)) = their reverse complements, per
+                leading `bits` (1..12, <= 2k) k-mer bits (host array).  Summed over the shards it is the shape of the
+                closed table: the caller takes balanced splitters from it (a canonical table crowds the low end of
+                the k-mer space, its closure does not).  Splitters on such a boundary are window-block boundaries
+                as long as bits <= 2 * (k / 2).
+   symm_route : 2 * nels records of (words + 1) uint64 -- the k-mer, then count | is-a-complement << 16 -- grouped by
+                destination rank into d_send (capacity in records >= 2 * nels); counts[nranks] on the host.
+                splitters as for smg_engine_route.
+   symm_finish: the records this shard received (its own share included) -> the engine's table: sorted, one entry
+                per k-mer (a k-mer that arrives both as an entry and as a complement keeps the entry's count).
+                *new_nels (may be NULL) = entries of the shard.  The engine owns the table afterwards.            */
+int smg_engine_symm_hist(smg_engine *e, int bits, int64_t *hist, char *errbuf, size_t errlen);
+int smg_engine_symm_route(smg_engine *e, const uint64_t *splitters, int nranks, uint64_t *d_send,
+                          int64_t capacity, int64_t *counts, char *errbuf, size_t errlen);
+int smg_engine_symm_finish(smg_engine *e, const uint64_t *d_recv, int64_t nrecv, int64_t *new_nels,
+                           char *errbuf, size_t errlen);
+/* the engine's current table (bound, decoded or conditioned): entries, device pointers (any may be NULL)         */
+int smg_engine_table(smg_engine *e, int64_t *nels, const uint64_t **d_keys, const uint16_t **d_counts);
+
 /* Whole single-GPU computation on the bound/decoded table; d_plot = int64[SMG_PLOT_CELLS]
    in device memory, overwritten.  Asynchronous on the engine's stream except for the small
    control read-backs between phases.                                                         */
@@ -207,8 +230,8 @@ int smg_engine_run(smg_engine *e, int symcheck, int64_t *d_plot, smg_stats *stat
              Bound device tables must be 16-byte (k-mers) / 8-byte (counts) aligned.
    apply   : adds received (or own) requests to the local degrees; *missing counts requests
              whose k-mer is absent or carries another count (=> table not symmetric).
-   symhash : out[0..1] = 128-bit signed canonical fingerprint residue of the shard (sum over ranks
-             with wrap-around: zero iff T == rc(T) with equal counts, up to a 2^-128 collision),
+   symhash : out[0..1] = 128-bit canonical XOR-fingerprint residue of the shard (XOR over the ranks
+             : zero iff T == rc(T) with equal counts, up to a 2^-128 collision),
              out[2..3] = 0 (the value to compare with).
    pass2   : histogram of unique pairs into d_plot (device int64[SMG_PLOT_CELLS], overwritten).*/
 int     smg_engine_pass1(smg_engine *e, int symcheck, char *errbuf, size_t errlen);

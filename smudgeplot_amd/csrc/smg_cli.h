@@ -154,7 +154,16 @@ __attribute__((unused)) static char *smg_cli_open_table(const smg_cli *c, const 
 
   Load_Threads = c->nthreads;
   load_or_die(SRC, T);
-  smg_ktab_examine(T, c->ethresh, &trim, &symm);
+  switch (smg_ktab_examine(T, c->ethresh, &trim, &symm))
+  { case SMG_KTAB_OK:
+      break;
+    case SMG_KTAB_NOMEM:
+      fprintf(stderr, "%s: Out of memory (Allocating k-mer table)\n", Prog_Name);
+      exit(1);
+    default:
+      fprintf(stderr, "%s: Table file %s is truncated or not a FastK table\n", Prog_Name, SRC);
+      exit(1);
+  }
 
   if (c->verbose)
     { fprintf(stderr, "\n  The input table is");

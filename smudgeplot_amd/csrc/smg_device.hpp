@@ -215,17 +215,23 @@ template <int W> SMG_DEV void arx_hash(const Key<W> &x, unsigned cnt, u64 &ha, u
   hb = (u64) c | ((u64) d << 32);
 }
 
-// Signed canonical fingerprint of one entry: +g(min(x,rc),cnt) when x < rc(x), -g when x > rc(x),
-// 0 for a self-complementary k-mer.  Summed (mod 2^64, two lanes) over a table that is closed under
-// reverse complement with equal counts, every class {x, rc(x)} cancels exactly; any entry whose
-// complement is absent or carries another count leaves a 128-bit residue.
+// Canonical fingerprint of one entry: g(min(x,rc),cnt), nothing for a self-complementary k-mer.  XORed over a
+// (strictly sorted, hence duplicate-free) table that is closed under reverse complement with equal counts, the two
+// members of every class {x, rc(x)} cancel exactly; any entry whose complement is absent or carries another count
+// leaves its 128 bits in the residue.
 template <int W> SMG_DEV void fp_accumulate(const Key<W> &x, const Key<W> &rc, unsigned cnt,
                                             u64 &fa, u64 &fb)
-{ const bool lt = key_lt<W>(x, rc), gt = key_lt<W>(rc, x);
+{ const bool lt = key_lt<W>(x, rc);
   u64 ha, hb;
   arx_hash<W>(lt ? x : rc, cnt, ha, hb);
-  if (lt) { fa += ha; fb += hb; }
-  if (gt) { fa -= ha; fb -= hb; }
+  if (!key_eq<W>(x, rc)) { fa ^= ha; fb ^= hb; }
+}
+
+SMG_DEV u64 wave_xor_u64(u64 v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v ^= __shfl_xor(v, o, 64);
+  return v;
 }
 
 SMG_DEV u64 wave_sum_u64(u64 v)

@@ -298,12 +298,12 @@ kf_pass1(FastArgs A, uint32_t *__restrict__ bstart, u64 *__restrict__ req,
       if (s_total) atomicAdd(&ctl->nreq, s_total);
     }
   if (want_fp)
-    { f0 = wave_sum_u64(f0); f1 = wave_sum_u64(f1);
+    { f0 = wave_xor_u64(f0); f1 = wave_xor_u64(f1);
       if ((t & 63) == 0) { sfp[t >> 6][0] = f0; sfp[t >> 6][1] = f1; }
       __syncthreads();
       if (t < 2)
         { u64 s = 0;
-          for (int w = 0; w < F_TPB / 64; w++) s += sfp[w][t];
+          for (int w = 0; w < F_TPB / 64; w++) s ^= sfp[w][t];
           partials[(size_t) blockIdx.x * 4 + t] = s;
           partials[(size_t) blockIdx.x * 4 + 2 + t] = 0;
         }

@@ -498,6 +498,7 @@ struct smg_engine
   u64         *boff;       //   bucket offsets [L_BK + 1] and scatter cursors [L_BK] behind them
   LookupGeo    lg;         //   geometry of the current run (lg.nb = 0: the round-1 chain is used)
   bool         counted_done; // the counted path (k > 85) has run on a closed table: deg[] holds the wrapped degrees
+  bool         use_sig;    // pass 1 writes the 2-byte look-up signatures (not worth their 5 GB when the filter leaves 1 request in 115)
   int          bm2;        //   the map is a two-bit map (smg_fast.hpp): 64-bit words, private to this engine
   int          bm_cap;     //   id bits of the block map: 32 on one GPU, 30 when the maps of several shards are exchanged
   int          bm_want;    //   ... as asked for by smg_engine_set_blockmap_bits (0: default)
@@ -857,7 +858,7 @@ static FastArgs make_fast(smg_engine *e)
 { FastArgs a;
   a.keys = e->keys; a.cnt = e->cnt; a.n = e->n; a.g = e->geo; a.dir = e->dir;
   a.code = e->deg;
-  a.sig = e->W <= 2 ? e->sig : NULL;
+  a.sig = (e->W <= 2 && e->use_sig) ? e->sig : NULL;
   a.sigsh = 16 + e->dir.dsh;               // the 16 bits right below the directory's bucket bits
   a.bmap = e->bm_bits ? e->bmap : NULL;
   a.bmsh = 32 - e->bm_bits;
@@ -879,7 +880,7 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
   e->fast = true; e->counted_done = false;
   if ((rc = grow(&e->deg, &e->deg_cap, ((e->n + 15) & ~15ll) + 32, errbuf, errlen))) return rc;
   const int64_t pbytes = ((e->n + 15) & ~15ll) + 32;
-  if (e->W <= 2 && (rc = grow(&e->sig, &e->sig_cap, 2 * pbytes, errbuf, errlen))) return rc;
+  e->use_sig = e->W <= 2;
   if ((rc = dir_geometry(e, (emit_all || e->W > 1) ? 8 : 64, errbuf, errlen))) return rc;
   // request filter: the candidate block map (an empty shard has one too -- all zero -- so that every rank of a
   // sharded run reports the same geometry and takes part in the exchange of the maps)
@@ -898,7 +899,14 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
       HIPCHK(hipMemsetAsync(e->bmap, 0, (size_t) bytes, e->stream));
       e->bm_bits = nbits;
       if (chain) e->lg = lookup_geo(nbits);
+      // Signatures (2 bytes per entry written by pass 1, so that a look-up bisects 2-byte instead of 8-byte words)
+      // pay when most requests are looked up.  With the 32-bit two-bit map of a single-GPU run 1 request in 115
+      // survives the filter: 3.9e6 look-ups at 2.5e9 entries, which can afford the k-mer lines of their bucket, while
+      // the signatures cost pass 1 5 GB of stores and four instructions per entry.  SMG_SIG=0/1 overrides.
+      if (chain && e->bm2 && nbits >= 32) e->use_sig = false;
     }
+  { const char *v = getenv("SMG_SIG"); if (v && e->W <= 2) e->use_sig = atoi(v) != 0; }
+  if (e->use_sig && (rc = grow(&e->sig, &e->sig_cap, 2 * pbytes, errbuf, errlen))) return rc;
   if (e->n > 0)
     HIPCHK(hipMemsetAsync(e->bstart, 0xFF, sizeof(uint32_t) * ((size_t) e->dir.nb + 2), e->stream));
   if (e->n == 0)
@@ -1055,7 +1063,7 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
   memset(e->fp, 0, sizeof(e->fp));
   if (want_fp)
     for (unsigned b = 0; b < grid; b++)
-      for (int q = 0; q < 4; q++) e->fp[q] += e->h_partials[b * 4 + q];
+      for (int q = 0; q < 4; q++) e->fp[q] ^= e->h_partials[b * 4 + q];     // (XOR fingerprint: smg_device.hpp)
   float ms = 0; hipEventElapsedTime(&ms, e->ev[2], e->ev[3]);
   e->st.ms_pass1 = ms;
   e->st.nrequests = (int64_t) e->h_ctrl->fast.nreq;
@@ -1230,7 +1238,15 @@ static int fast_filter(smg_engine *e, const uint32_t *map, char *errbuf, size_t 
   }
   if (grid > e->n_chunks) grid = e->n_chunks;
   unsigned maxout = e->n_chunks + grid + 16;
-  if (e->lg.nb) maxout = e->n_chunks + 256 * PB_WAVES + 16;          // kl_probe: every wave fills chunks of its own
+  if (e->lg.nb)
+    { // kl_probe: every wave of every workgroup (one per CU, lookup_probe) fills chunks of its own, each to the brim
+      // but for the < 64 records that did not fit: size the list from the launch and the request count, not from 256 CUs
+      int cus = 256;
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || cus < 1) cus = 256;
+      const int64_t need = (int64_t) cus * PB_WAVES + e->st.nrequests / (F_CH - 63) + 16;
+      maxout = need < 0x7FFFFFFFll ? (unsigned) need : 0x7FFFFFFFu;
+      if (maxout < e->n_chunks + 16) maxout = e->n_chunks + 16;
+    }
   // (the two chunk lists swap roles after every filter: keep them the same size, or pass 1 would reallocate)
   { int64_t want = (int64_t) maxout * F_CH * (int64_t) sizeof(u64) * e->rw, wantf = (int64_t) maxout * 4 + 4;
     if (want < e->req_cap) want = e->req_cap;
@@ -1483,18 +1499,12 @@ extern "C" int smg_engine_symhash(smg_engine *e, uint64_t out[4], char *errbuf, 
   return SMG_OK;
 }
 
-extern "C" int smg_engine_route(smg_engine *e, const uint64_t *splitters, int nranks,
-                                uint64_t *d_send, int64_t capacity, int64_t *counts,
-                                char *errbuf, size_t errlen)
-{ NEED_FAST(e)
-  if (!counts || nranks < 1 || nranks > 16)
-    return fail(errbuf, errlen, SMG_EINVAL, "bad route arguments (1..16 ranks)%s");
-  if (!e->prepared) return fail(errbuf, errlen, SMG_EINVAL, "route before pass1%s");
-  HIPCHK(hipSetDevice(e->device));
-  const int64_t nreq = e->st.nrequests;
-  if (nreq > capacity) return fail(errbuf, errlen, SMG_EINVAL, "send buffer too small%s");
-  for (int r = 0; r < nranks; r++) counts[r] = 0;
-  const unsigned nc = e->n_chunks;
+// records (rw words each, the first W of them a k-mer) in chunks of F_CH -> d_send, grouped by the rank whose k-mer
+// range holds the k-mer (splitters = first k-mer of ranks 1..nranks-1); counts[nranks] on the host
+static int route_records(smg_engine *e, const u64 *req, const uint32_t *chunk_fill, unsigned nc, int rw,
+                         const uint64_t *splitters, int nranks, uint64_t *d_send, int64_t *counts,
+                         char *errbuf, size_t errlen)
+{ for (int r = 0; r < nranks; r++) counts[r] = 0;
   if (nc == 0) return SMG_OK;
   int rc;
   if (nranks > 1)
@@ -1502,9 +1512,9 @@ extern "C" int smg_engine_route(smg_engine *e, const uint64_t *splitters, int nr
                           hipMemcpyHostToDevice, e->stream));
   if ((rc = grow(&e->route_cnt, &e->route_cnt_cap, (int64_t) nc * nranks * 4, errbuf, errlen))) return rc;
   if ((rc = grow(&e->route_off, &e->route_off_cap, (int64_t) nc * nranks * 8, errbuf, errlen))) return rc;
-#define CALL(WW) hipLaunchKernelGGL(kf_route_count<WW>, dim3(nc), dim3(F_TPB), 0, e->stream, e->req, \
-                   e->chunk_fill, e->rw, e->d_split, nranks, e->route_cnt)
-  DISPATCH_W3(e, CALL)
+#define CALL(WW) hipLaunchKernelGGL(kf_route_count<WW>, dim3(nc), dim3(F_TPB), 0, e->stream, req, \
+                   chunk_fill, rw, e->d_split, nranks, e->route_cnt)
+  DISPATCH_W(e, CALL)
 #undef CALL
   uint32_t *hc = (uint32_t *) malloc(sizeof(uint32_t) * (size_t) nc * nranks);
   u64 *ho = (u64 *) malloc(sizeof(u64) * (size_t) nc * nranks);
@@ -1522,15 +1532,27 @@ extern "C" int smg_engine_route(smg_engine *e, const uint64_t *splitters, int nr
   hipError_t he = hipMemcpyAsync(e->route_off, ho, sizeof(u64) * (size_t) nc * nranks, hipMemcpyHostToDevice, e->stream);
   if (he == hipSuccess)
     {
-#define CALL(WW) hipLaunchKernelGGL(kf_route_scatter<WW>, dim3(nc), dim3(F_TPB), 0, e->stream, e->req, \
-                   e->chunk_fill, e->rw, e->d_split, nranks, e->route_off, (u64 *) d_send)
-      DISPATCH_W3(e, CALL)
+#define CALL(WW) hipLaunchKernelGGL(kf_route_scatter<WW>, dim3(nc), dim3(F_TPB), 0, e->stream, req, \
+                   chunk_fill, rw, e->d_split, nranks, e->route_off, (u64 *) d_send)
+      DISPATCH_W(e, CALL)
 #undef CALL
       he = hipStreamSynchronize(e->stream);
     }
   free(hc); free(ho);
   if (he != hipSuccess) return fail(errbuf, errlen, SMG_ENODEV, "route: %s", hipGetErrorString(he));
   return SMG_OK;
+}
+
+extern "C" int smg_engine_route(smg_engine *e, const uint64_t *splitters, int nranks,
+                                uint64_t *d_send, int64_t capacity, int64_t *counts,
+                                char *errbuf, size_t errlen)
+{ NEED_FAST(e)
+  if (!counts || nranks < 1 || nranks > 16)
+    return fail(errbuf, errlen, SMG_EINVAL, "bad route arguments (1..16 ranks)%s");
+  if (!e->prepared) return fail(errbuf, errlen, SMG_EINVAL, "route before pass1%s");
+  HIPCHK(hipSetDevice(e->device));
+  if (e->st.nrequests > capacity) return fail(errbuf, errlen, SMG_EINVAL, "send buffer too small%s");
+  return route_records(e, e->req, e->chunk_fill, e->n_chunks, e->rw, splitters, nranks, d_send, counts, errbuf, errlen);
 }
 
 extern "C" int smg_engine_pass2(smg_engine *e, int64_t *d_plot, char *errbuf, size_t errlen)
@@ -1663,6 +1685,9 @@ static int cond_scan(smg_engine *e, uint32_t *flag, uint32_t *pos, int64_t n, in
   return SMG_OK;
 }
 
+static int cond_sort_dedupe(smg_engine *e, const u64 *k2, const uint16_t *c2, const uint8_t *copy, int64_t n2,
+                            int64_t *kept_out, char *errbuf, size_t errlen);
+
 extern "C" int smg_engine_condition(smg_engine *e, int ethresh, int do_trim, int do_symm,
                                     int64_t *new_nels, char *errbuf, size_t errlen)
 { if (!e) return fail(errbuf, errlen, SMG_EINVAL, "null engine%s");
@@ -1707,42 +1732,16 @@ extern "C" int smg_engine_condition(smg_engine *e, int ethresh, int do_trim, int
 
   if (do_symm && n > 0)
     { const int64_t n2 = 2 * n;
-      if (n2 >= 0xFFFFFFF0ll) { CFREE(); return fail(errbuf, errlen, SMG_EINVAL, "table too large to symmetrise on one GPU%s"); }
-      const unsigned nblk = (unsigned) ((n + TPB - 1) / TPB), nblk2 = (unsigned) ((n2 + TPB - 1) / TPB);
+      if (n2 >= 0xFFFFFFF0ll) { CFREE(); return fail(errbuf, errlen, SMG_EINVAL, "table too large to symmetrise in one shard%s"); }
+      const unsigned nblk = (unsigned) ((n + TPB - 1) / TPB);
       CCHK(hipMalloc(&k2, sizeof(u64) * (size_t) n2 * W));
       CCHK(hipMalloc(&c2, sizeof(uint16_t) * (size_t) n2));
-      CCHK(hipMalloc(&perm, sizeof(uint32_t) * (size_t) n2));
-      CCHK(hipMalloc(&perm2, sizeof(uint32_t) * (size_t) n2));
-      CCHK(hipMalloc(&wk, sizeof(u64) * (size_t) n2));
-      CCHK(hipMalloc(&wk2, sizeof(u64) * (size_t) n2));
 #define CALL(WW) hipLaunchKernelGGL(kc_append_rc<WW>, dim3(nblk), dim3(TPB), 0, e->stream, e->keys, e->cnt, n, e->kmer, k2, c2)
       DISPATCH_W(e, CALL)
 #undef CALL
-      hipLaunchKernelGGL(kc_iota, dim3(nblk2), dim3(TPB), 0, e->stream, perm, n2);
-      for (int w = W - 1; w >= 0; w--)              // LSD over the words, stable
-        { hipLaunchKernelGGL(kc_gather_word, dim3(nblk2), dim3(TPB), 0, e->stream, k2, perm, W, w, n2, wk);
-          size_t tmp = 0;
-          CCHK(rocprim::radix_sort_pairs<smg_pair_sort_config>(nullptr, tmp, wk, wk2, perm, perm2, (size_t) n2, 0u, 64u, e->stream));
-          CRC(grow((char **) &e->sort_tmp, &e->sort_tmp_cap, (int64_t) tmp + 16, errbuf, errlen));
-          CCHK(rocprim::radix_sort_pairs<smg_pair_sort_config>(e->sort_tmp, tmp, wk, wk2, perm, perm2, (size_t) n2, 0u, 64u, e->stream));
-          uint32_t *sw = perm; perm = perm2; perm2 = sw;
-        }
-      CCHK(hipMalloc(&flag, sizeof(uint32_t) * (size_t) n2));
-      CCHK(hipMalloc(&pos, sizeof(uint32_t) * (size_t) n2));
-#define CALL(WW) hipLaunchKernelGGL(kc_flag_first<WW>, dim3(nblk2), dim3(TPB), 0, e->stream, k2, perm, n2, flag)
-      DISPATCH_W(e, CALL)
-#undef CALL
       int64_t kept = 0;
-      CRC(cond_scan(e, flag, pos, n2, &kept, errbuf, errlen));
-      CCHK(hipMalloc(&ko, sizeof(u64) * (size_t) kept * W));
-      CCHK(hipMalloc(&co, sizeof(uint16_t) * (size_t) kept + 16));
-#define CALL(WW) hipLaunchKernelGGL(kc_compact<WW>, dim3(nblk2), dim3(TPB), 0, e->stream, k2, c2, perm, flag, pos, n2, ko, co)
-      DISPATCH_W(e, CALL)
-#undef CALL
-      CCHK(hipStreamSynchronize(e->stream));
-      hipFree(e->own_keys); hipFree(e->own_cnt);
-      e->own_keys = ko; e->own_cnt = co; ko = NULL; co = NULL;
-      e->keys = e->own_keys; e->cnt = e->own_cnt;
+      // (entries first, complements behind them: the stable sort keeps the entry in front of an equal complement)
+      CRC(cond_sort_dedupe(e, k2, c2, NULL, n2, &kept, errbuf, errlen));
       n = kept;
     }
   hipEventRecord(c1, e->stream);
@@ -1757,6 +1756,242 @@ extern "C" int smg_engine_condition(smg_engine *e, int ethresh, int do_trim, int
   e->st.nels = n;
   e->st.ms_decode += ms;
   if (new_nels) *new_nels = n;
+  return SMG_OK;
+}
+
+// ---- symmetrising a table that is cut into prefix shards (several GPUs, or one device and more than 2^32 entries) -----
+// The reference's Symmex has no size limit (PloidyPlot.c:1395-1414 hands it any table).  Here every shard
+//   1. counts its own entries and their reverse complements per leading `bits` k-mer bits (smg_engine_symm_hist): the
+//      sum over the shards is the shape of the CLOSED table, from which the caller takes balanced splitters -- a table
+//      of canonical k-mers crowds the low end of the k-mer space (7/8 of the k-mers that start with an a are canonical,
+//      1/8 of those that start with a t), its closure does not;
+//   2. writes one record per entry and one per complement, grouped by the shard whose range holds the k-mer
+//      (smg_engine_symm_route; records of W + 1 words: the k-mer, then count | is-a-complement << 16);
+//   3. after the exchange sorts what it received and keeps one entry per k-mer (smg_engine_symm_finish; a k-mer that
+//      arrives as an entry AND as a complement keeps the entry's count -- self-complementary k-mers, or input that was
+//      neither canonical nor closed: the same rule as the single-shard code above).
+
+#define SY_MAXBITS 12
+
+template <int W> __global__ void __launch_bounds__(TPB)
+kc_symm_hist(const u64 *__restrict__ keys, int64_t n, int k, int bits, u64 *__restrict__ hist /* [2 << bits]: own, complements */)
+{ __shared__ unsigned h[2 << SY_MAXBITS];
+  const int nb = 1 << bits;
+  for (int b = threadIdx.x; b < 2 * nb; b += TPB) h[b] = 0;
+  __syncthreads();
+  for (int64_t i = (int64_t) blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t) gridDim.x * TPB)
+    { const Key<W> x = load_key<W>(keys, i);
+      const Key<W> r = revcomp<W>(x, k);
+      atomicAdd(&h[(unsigned) (x.w[0] >> (64 - bits))], 1u);
+      atomicAdd(&h[nb + (unsigned) (r.w[0] >> (64 - bits))], 1u);
+    }
+  __syncthreads();
+  for (int b = threadIdx.x; b < 2 * nb; b += TPB)
+    if (h[b]) atomicAdd(&hist[b], (u64) h[b]);
+}
+
+// record i = (entry i, count), record n + i = (its reverse complement, count | 1 << 16)
+template <int W> __global__ void __launch_bounds__(TPB)
+kc_symm_records(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, int64_t n, int k, u64 *__restrict__ rec)
+{ const int64_t i = (int64_t) blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const Key<W> x = load_key<W>(keys, i);
+  const Key<W> r = revcomp<W>(x, k);
+  u64 *a = rec + (size_t) i * (W + 1), *b = rec + (size_t) (n + i) * (W + 1);
+#pragma unroll
+  for (int w = 0; w < W; w++) { a[w] = x.w[w]; b[w] = r.w[w]; }
+  a[W] = (u64) cnt[i];
+  b[W] = (u64) cnt[i] | (1ull << 16);
+}
+
+__global__ void __launch_bounds__(TPB) kc_fill_u32(uint32_t *__restrict__ p, int64_t n, uint32_t v, uint32_t last)
+{ const int64_t i = (int64_t) blockIdx.x * TPB + threadIdx.x;
+  if (i < n) p[i] = i == n - 1 ? last : v;
+}
+
+// records -> separate k-mer / count / is-a-complement arrays
+template <int W> __global__ void __launch_bounds__(TPB)
+kc_symm_unpack(const u64 *__restrict__ rec, int64_t n, u64 *__restrict__ keys, uint16_t *__restrict__ cnt, uint8_t *__restrict__ copy)
+{ const int64_t i = (int64_t) blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const u64 *q = rec + (size_t) i * (W + 1);
+#pragma unroll
+  for (int w = 0; w < W; w++) keys[i * W + w] = q[w];
+  cnt[i] = (uint16_t) q[W];
+  copy[i] = (uint8_t) ((q[W] >> 16) & 1u);
+}
+
+// like kc_compact, for a sorted permutation in which a k-mer occurs at most twice (once as an entry, once as a
+// complement): the survivor is the first of the two, its count the ENTRY's
+template <int W> __global__ void __launch_bounds__(TPB)
+kc_compact_pref(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, const uint8_t *__restrict__ copy,
+                const uint32_t *__restrict__ perm, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ pos,
+                int64_t n, u64 *__restrict__ okeys, uint16_t *__restrict__ ocnt)
+{ const int64_t i = (int64_t) blockIdx.x * TPB + threadIdx.x;
+  if (i >= n || !flag[i]) return;
+  const int64_t src = perm[i];
+  int64_t csrc = src;
+  if (copy[src] && i + 1 < n && !flag[i + 1]) csrc = perm[i + 1];        // (the next one is the same k-mer: the entry)
+  const int64_t dst = pos[i];
+#pragma unroll
+  for (int w = 0; w < W; w++) okeys[dst * W + w] = keys[src * W + w];
+  ocnt[dst] = cnt[csrc];
+}
+
+extern "C" int smg_engine_table(smg_engine *e, int64_t *nels, const uint64_t **d_keys, const uint16_t **d_counts)
+{ if (!e) return SMG_EINVAL;
+  if (nels) *nels = e->n;
+  if (d_keys) *d_keys = (const uint64_t *) e->keys;
+  if (d_counts) *d_counts = e->cnt;
+  return SMG_OK;
+}
+
+extern "C" int smg_engine_symm_hist(smg_engine *e, int bits, int64_t *hist, char *errbuf, size_t errlen)
+{ if (!e || !hist) return fail(errbuf, errlen, SMG_EINVAL, "null argument%s");
+  if (bits < 1 || bits > SY_MAXBITS || bits > 2 * e->kmer) return fail(errbuf, errlen, SMG_EINVAL, "symm_hist: 1..12 leading bits, at most 2k%s");
+  if (!e->keys && e->n > 0) return fail(errbuf, errlen, SMG_EINVAL, "no table bound%s");
+  HIPCHK(hipSetDevice(e->device));
+  const size_t bytes = sizeof(u64) * ((size_t) 2 << bits);
+  u64 *d = NULL;
+  HIPCHK(hipMalloc(&d, bytes));
+  hipError_t he = hipMemsetAsync(d, 0, bytes, e->stream);
+  if (he == hipSuccess && e->n > 0)
+    { int64_t nb = (e->n + TPB - 1) / TPB;
+      if (nb > 2048) nb = 2048;
+#define CALL(WW) hipLaunchKernelGGL(kc_symm_hist<WW>, dim3((unsigned) nb), dim3(TPB), 0, e->stream, e->keys, e->n, e->kmer, bits, d)
+      DISPATCH_W(e, CALL)
+#undef CALL
+      he = hipGetLastError();
+    }
+  if (he == hipSuccess) he = hipMemcpyAsync(hist, d, bytes, hipMemcpyDeviceToHost, e->stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+  hipFree(d);
+  if (he != hipSuccess) return fail(errbuf, errlen, SMG_ENODEV, "symm_hist: %s", hipGetErrorString(he));
+  return SMG_OK;
+}
+
+extern "C" int smg_engine_symm_route(smg_engine *e, const uint64_t *splitters, int nranks, uint64_t *d_send,
+                                     int64_t capacity, int64_t *counts, char *errbuf, size_t errlen)
+{ if (!e || !counts || nranks < 1 || nranks > 16) return fail(errbuf, errlen, SMG_EINVAL, "bad symm_route arguments (1..16 ranks)%s");
+  if (!e->keys && e->n > 0) return fail(errbuf, errlen, SMG_EINVAL, "no table bound%s");
+  const int64_t n2 = 2 * e->n;
+  if (capacity < n2 || (n2 > 0 && !d_send)) return fail(errbuf, errlen, SMG_EINVAL, "symm_route: the send buffer must hold two records per entry%s");
+  for (int r = 0; r < nranks; r++) counts[r] = 0;
+  if (n2 == 0) return SMG_OK;
+  HIPCHK(hipSetDevice(e->device));
+  const int rw = e->W + 1;
+  const int64_t nc = (n2 + F_CH - 1) / F_CH;
+  if (nc >= 0x7FFFFFFFll) return fail(errbuf, errlen, SMG_EINVAL, "symm_route: shard too large%s");
+  u64 *rec = NULL; uint32_t *fill = NULL;
+  int rc = SMG_OK;
+  if (hipMalloc(&rec, sizeof(u64) * (size_t) n2 * rw) != hipSuccess || hipMalloc(&fill, sizeof(uint32_t) * (size_t) nc) != hipSuccess)
+    { hipFree(rec); hipFree(fill); return fail(errbuf, errlen, SMG_ENOMEM, "out of device memory while symmetrising%s"); }
+  const unsigned nblk = (unsigned) ((e->n + TPB - 1) / TPB);
+#define CALL(WW) hipLaunchKernelGGL(kc_symm_records<WW>, dim3(nblk), dim3(TPB), 0, e->stream, e->keys, e->cnt, e->n, e->kmer, rec)
+  DISPATCH_W(e, CALL)
+#undef CALL
+  hipLaunchKernelGGL(kc_fill_u32, dim3((unsigned) ((nc + TPB - 1) / TPB)), dim3(TPB), 0, e->stream, fill, nc, (uint32_t) F_CH,
+                     (uint32_t) (n2 - (nc - 1) * F_CH));
+  if (hipGetLastError() != hipSuccess) rc = fail(errbuf, errlen, SMG_ENODEV, "symm_route: launch failed%s");
+  if (rc == SMG_OK) rc = route_records(e, rec, fill, (unsigned) nc, rw, splitters, nranks, d_send, counts, errbuf, errlen);
+  hipStreamSynchronize(e->stream);
+  hipFree(rec); hipFree(fill);
+  return rc;
+}
+
+// sorted, duplicate-free table from 2-copies-at-most material: keys[n2 * W], counts, copy flags (NULL: the first of two
+// equal k-mers in INPUT order wins, as the stable sort leaves it) -> the engine's own table.  Frees nothing of the caller's.
+static int cond_sort_dedupe(smg_engine *e, const u64 *k2, const uint16_t *c2, const uint8_t *copy, int64_t n2,
+                            int64_t *kept_out, char *errbuf, size_t errlen)
+{ const int W = e->W;
+  int rc = SMG_OK;
+  uint32_t *flag = NULL, *pos = NULL, *perm = NULL, *perm2 = NULL;
+  u64 *wk = NULL, *wk2 = NULL, *ko = NULL;
+  uint16_t *co = NULL;
+  int64_t kept = 0;
+  if (n2 >= 0xFFFFFFF0ll) return fail(errbuf, errlen, SMG_EINVAL, "shard too large to symmetrise (2^32 entries per shard)%s");
+  const unsigned nblk2 = (unsigned) ((n2 + TPB - 1) / TPB);
+#define SFREE() { hipFree(flag); hipFree(pos); hipFree(perm); hipFree(perm2); hipFree(wk); hipFree(wk2); hipFree(ko); hipFree(co); }
+#define SCHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { SFREE(); \
+                     return fail(errbuf, errlen, _e == hipErrorOutOfMemory ? SMG_ENOMEM : SMG_ENODEV, \
+                                 "HIP error while conditioning: %s", hipGetErrorString(_e)); } } while (0)
+#define SRC(call) do { if ((rc = (call))) { SFREE(); return rc; } } while (0)
+  SCHK(hipMalloc(&perm, sizeof(uint32_t) * (size_t) n2));
+  SCHK(hipMalloc(&perm2, sizeof(uint32_t) * (size_t) n2));
+  SCHK(hipMalloc(&wk, sizeof(u64) * (size_t) n2));
+  SCHK(hipMalloc(&wk2, sizeof(u64) * (size_t) n2));
+  hipLaunchKernelGGL(kc_iota, dim3(nblk2), dim3(TPB), 0, e->stream, perm, n2);
+  for (int w = W - 1; w >= 0; w--)              // LSD over the words, stable
+    { hipLaunchKernelGGL(kc_gather_word, dim3(nblk2), dim3(TPB), 0, e->stream, k2, perm, W, w, n2, wk);
+      size_t tmp = 0;
+      SCHK(rocprim::radix_sort_pairs<smg_pair_sort_config>(nullptr, tmp, wk, wk2, perm, perm2, (size_t) n2, 0u, 64u, e->stream));
+      SRC(grow((char **) &e->sort_tmp, &e->sort_tmp_cap, (int64_t) tmp + 16, errbuf, errlen));
+      SCHK(rocprim::radix_sort_pairs<smg_pair_sort_config>(e->sort_tmp, tmp, wk, wk2, perm, perm2, (size_t) n2, 0u, 64u, e->stream));
+      uint32_t *sw = perm; perm = perm2; perm2 = sw;
+    }
+  hipFree(wk); hipFree(wk2); hipFree(perm2); wk = wk2 = NULL; perm2 = NULL;
+  SCHK(hipMalloc(&flag, sizeof(uint32_t) * (size_t) n2));
+  SCHK(hipMalloc(&pos, sizeof(uint32_t) * (size_t) n2));
+#define CALL(WW) hipLaunchKernelGGL(kc_flag_first<WW>, dim3(nblk2), dim3(TPB), 0, e->stream, k2, perm, n2, flag)
+  DISPATCH_W(e, CALL)
+#undef CALL
+  SRC(cond_scan(e, flag, pos, n2, &kept, errbuf, errlen));
+  SCHK(hipMalloc(&ko, sizeof(u64) * (size_t) (kept > 0 ? kept : 1) * W));
+  SCHK(hipMalloc(&co, sizeof(uint16_t) * (size_t) (kept > 0 ? kept : 1) + 16));
+  if (copy)
+    {
+#define CALL(WW) hipLaunchKernelGGL(kc_compact_pref<WW>, dim3(nblk2), dim3(TPB), 0, e->stream, k2, c2, copy, perm, flag, pos, n2, ko, co)
+      DISPATCH_W(e, CALL)
+#undef CALL
+    }
+  else
+    {
+#define CALL(WW) hipLaunchKernelGGL(kc_compact<WW>, dim3(nblk2), dim3(TPB), 0, e->stream, k2, c2, perm, flag, pos, n2, ko, co)
+      DISPATCH_W(e, CALL)
+#undef CALL
+    }
+  SCHK(hipStreamSynchronize(e->stream));
+  hipFree(e->own_keys); hipFree(e->own_cnt);
+  e->own_keys = ko; e->own_cnt = co; ko = NULL; co = NULL;
+  e->keys = e->own_keys; e->cnt = e->own_cnt;
+  SFREE();
+#undef SFREE
+#undef SCHK
+#undef SRC
+  *kept_out = kept;
+  return SMG_OK;
+}
+
+extern "C" int smg_engine_symm_finish(smg_engine *e, const uint64_t *d_recv, int64_t nrecv, int64_t *new_nels,
+                                      char *errbuf, size_t errlen)
+{ if (!e || nrecv < 0 || (nrecv > 0 && !d_recv)) return fail(errbuf, errlen, SMG_EINVAL, "bad symm_finish arguments%s");
+  if (e->kmer < 1) return fail(errbuf, errlen, SMG_EINVAL, "no table bound%s");
+  HIPCHK(hipSetDevice(e->device));
+  int64_t kept = 0;
+  if (nrecv == 0)
+    { hipFree(e->own_keys); hipFree(e->own_cnt); e->own_keys = NULL; e->own_cnt = NULL;
+      HIPCHK(hipMalloc(&e->own_keys, sizeof(u64) * e->W)); HIPCHK(hipMalloc(&e->own_cnt, 16));
+      e->keys = e->own_keys; e->cnt = e->own_cnt;
+    }
+  else
+    { if (nrecv >= 0xFFFFFFF0ll) return fail(errbuf, errlen, SMG_EINVAL, "shard too large to symmetrise (2^32 entries per shard)%s");
+      u64 *k2 = NULL; uint16_t *c2 = NULL; uint8_t *cp = NULL;
+      if (hipMalloc(&k2, sizeof(u64) * (size_t) nrecv * e->W) != hipSuccess || hipMalloc(&c2, sizeof(uint16_t) * (size_t) nrecv + 16) != hipSuccess
+          || hipMalloc(&cp, (size_t) nrecv + 16) != hipSuccess)
+        { hipFree(k2); hipFree(c2); hipFree(cp); return fail(errbuf, errlen, SMG_ENOMEM, "out of device memory while symmetrising%s"); }
+      const unsigned nblk = (unsigned) ((nrecv + TPB - 1) / TPB);
+#define CALL(WW) hipLaunchKernelGGL(kc_symm_unpack<WW>, dim3(nblk), dim3(TPB), 0, e->stream, (const u64 *) d_recv, nrecv, k2, c2, cp)
+      DISPATCH_W(e, CALL)
+#undef CALL
+      const int rc = cond_sort_dedupe(e, k2, c2, cp, nrecv, &kept, errbuf, errlen);
+      hipStreamSynchronize(e->stream);
+      hipFree(k2); hipFree(c2); hipFree(cp);
+      if (rc) return rc;
+    }
+  e->n = kept;
+  e->prepared = false; e->counted_done = false;
+  e->st.nels = kept;
+  if (new_nels) *new_nels = kept;
   return SMG_OK;
 }
 

@@ -8,6 +8,7 @@
 #include <unistd.h>
 #include <sys/stat.h>
 #include <pthread.h>
+#include <stdint.h>
 
 #include "smg_ktab.h"
 
@@ -61,9 +62,13 @@ int smg_ktab_load_mt(const char *name, smg_ktab *t, char *what, int nthreads)
 { return ktab_open(name, t, what, 1, nthreads); }
 
 int smg_ktab_read(const smg_ktab *t, int part, int64_t first, int64_t nent, void *dst)
-{ size_t len = (size_t) nent * (size_t) t->pbyte, done = 0;
-  off_t  off = (off_t) 12 + (off_t) first * (off_t) t->pbyte;
-  if (part < 0 || part >= t->nparts || first < 0 || first + nent > t->part_nels[part]) return -1;
+{ size_t len, done = 0;
+  off_t  off;
+  if (part < 0 || part >= t->nparts || first < 0 || nent < 0 || nent > t->part_nels[part]
+      || first > t->part_nels[part] - nent)
+    return -1;
+  len = (size_t) nent * (size_t) t->pbyte;
+  off = (off_t) 12 + (off_t) first * (off_t) t->pbyte;
   if (t->part[part] != NULL)
     { memcpy(dst, t->part[part] + (size_t) first * (size_t) t->pbyte, len); return 0; }
   if (t->fd == NULL || t->fd[part] < 0) return -1;
@@ -96,7 +101,9 @@ static int ktab_open(const char *name, smg_ktab *t, char *what, int load, int nt
   if (fd < 0) { rc = SMG_KTAB_NOSTUB; goto out; }
   if (read_full(fd, hdr, sizeof(hdr))) { close(fd); rc = SMG_KTAB_SHORT; goto out; }
   t->kmer = hdr[0]; t->nparts = hdr[1]; t->minval = hdr[2]; t->ibyte = hdr[3];
-  if (t->kmer < 1 || t->nparts < 0 || t->nparts > (1 << 20) || t->ibyte < 1 || t->ibyte > 3
+  /* k is bounded by what the engine takes (SMG_KTAB_MAX_KMER = SMG_MAX_KMER): the one-record scratch buffers of
+     smg_ktab_entry / smg_ktab_find are sized from it, and a stub that claims k = 300 must not reach them */
+  if (t->kmer < 1 || t->kmer > SMG_KTAB_MAX_KMER || t->nparts < 0 || t->nparts > (1 << 20) || t->ibyte < 1 || t->ibyte > 3
       || ((t->kmer + 3) >> 2) <= t->ibyte)           /* no suffix bytes: FastK never writes such a table (hbyte >= 1) */
     { close(fd); rc = SMG_KTAB_SHORT; goto out; }
   t->kbyte = (t->kmer + 3) >> 2;
@@ -129,7 +136,8 @@ static int ktab_open(const char *name, smg_ktab *t, char *what, int load, int nt
         t->fd[p - 1] = fd;
         if (read_full(fd, &km, 4) || read_full(fd, &n, 8)) { rc = SMG_KTAB_SHORT; break; }
         if (km != t->kmer) { rc = SMG_KTAB_KMISMATCH; break; }
-        if (n < 0 || fstat(fd, &sb) != 0 || (int64_t) sb.st_size < 12 + n * (int64_t) t->pbyte)
+        if (n < 0 || n > (INT64_MAX - 12) / (int64_t) t->pbyte || t->nels > INT64_MAX - n
+            || fstat(fd, &sb) != 0 || (int64_t) sb.st_size < 12 + n * (int64_t) t->pbyte)
           { rc = SMG_KTAB_SHORT; break; }
         t->part_nels[p - 1] = n;
         t->nels += n;
@@ -214,7 +222,7 @@ static int64_t prefix_of(const smg_ktab *t, int64_t i)      /* smallest p with i
 }
 
 void smg_ktab_entry(const smg_ktab *t, int64_t i, uint8_t *kmer_out, int *count_out)
-{ uint8_t rb[64];
+{ uint8_t rb[SMG_KTAB_MAX_PBYTE];
   const uint8_t *r = record_at(t, i, rb);
   int64_t pre = prefix_of(t, i);
   int j;
@@ -226,7 +234,7 @@ void smg_ktab_entry(const smg_ktab *t, int64_t i, uint8_t *kmer_out, int *count_
 
 int64_t smg_ktab_find(const smg_ktab *t, const uint8_t *kmer)
 { int64_t m = 0, lo, hi;
-  uint8_t rb[64];
+  uint8_t rb[SMG_KTAB_MAX_PBYTE];
   int j;
   for (j = 0; j < t->ibyte; j++) m = (m << 8) | kmer[j];
   lo = m == 0 ? 0 : t->index[m - 1];
@@ -252,9 +260,13 @@ static void revcomp_packed(const uint8_t *x, uint8_t *out, int k, int kbyte)
     }
 }
 
-void smg_ktab_examine(const smg_ktab *t, int ethresh, int *trim, int *symm)
+int smg_ktab_examine(const smg_ktab *t, int ethresh, int *trim, int *symm)
 { int64_t frst, last, i, nz;
+  int     bad = 0;
   int64_t *hist = (int64_t *) calloc(0x8000, sizeof(int64_t));
+
+  *trim = 0; *symm = 0;
+  if (hist == NULL) return SMG_KTAB_NOMEM;
 
   /* "Histogram of middle 100M counts and see if trimmed to ETHRESH", PloidyPlot.c:1169-1197.
      The reference indexes with the count read as int16; counts above 32767 are outside what
@@ -265,7 +277,8 @@ void smg_ktab_examine(const smg_ktab *t, int ethresh, int *trim, int *symm)
     const int64_t blk = 65536;
     uint8_t *buf = (uint8_t *) malloc((size_t) blk * (size_t) t->pbyte);
     int p;
-    for (p = 0; p < t->nparts && buf != NULL; p++)
+    if (buf == NULL) { free(hist); return SMG_KTAB_NOMEM; }
+    for (p = 0; p < t->nparts && !bad; p++)
       { const int64_t pb = p ? t->part_end[p - 1] : 0, pe = t->part_end[p];
         int64_t a = frst > pb ? frst : pb, b = last < pe ? last : pe;
         for (i = a; i < b; i += blk)
@@ -273,18 +286,18 @@ void smg_ktab_examine(const smg_ktab *t, int ethresh, int *trim, int *symm)
             int64_t j;
             const uint8_t *r = buf;
             if (t->part[p] != NULL) r = t->part[p] + (size_t) (i - pb) * (size_t) t->pbyte;
-            else if (smg_ktab_read(t, p, i - pb, m, buf) != 0) break;
+            else if (smg_ktab_read(t, p, i - pb, m, buf) != 0) { bad = 1; break; }   /* a partial histogram would call
+                                                                                         an unreadable table "trimmed" */
             for (j = 0; j < m; j++, r += t->pbyte)
               { int c = r[t->hbyte] | (r[t->hbyte + 1] << 8);
-                if (hist && c < 0x8000) hist[c] += 1;
+                if (c < 0x8000) hist[c] += 1;
               }
           }
       }
     free(buf);
   }
-  nz = 0x8000;
-  if (hist)
-    for (nz = 1; nz < 0x8000 && hist[nz] == 0; nz++) ;
+  if (bad) { free(hist); return SMG_KTAB_SHORT; }
+  for (nz = 1; nz < 0x8000 && hist[nz] == 0; nz++) ;
   *trim = (nz >= ethresh);
   free(hist);
 
@@ -300,5 +313,7 @@ void smg_ktab_examine(const smg_ktab *t, int ethresh, int *trim, int *symm)
           *symm = smg_ktab_find(t, x + t->kbyte) >= 0;
           free(x);
         }
+      else return SMG_KTAB_NOMEM;
     }
+  return SMG_KTAB_OK;
 }

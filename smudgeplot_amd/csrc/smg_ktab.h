@@ -27,6 +27,9 @@ typedef struct smg_ktab
   int      *fd;                             /* [nparts] open part files (-1 when closed)       */
 } smg_ktab;
 
+#define SMG_KTAB_MAX_KMER   128   /* = SMG_MAX_KMER of the engine: larger k is refused at open time            */
+#define SMG_KTAB_MAX_PBYTE  ((SMG_KTAB_MAX_KMER + 3) / 4 + 2)   /* widest record (ibyte >= 1 makes it one less)  */
+
 #define SMG_KTAB_OK        0
 #define SMG_KTAB_NOSTUB    1     /* stub cannot be opened     (Open_Kmer_Stream returns NULL)   */
 #define SMG_KTAB_NOPART    2     /* "Table part %s is missing ?"            libfastk.c:850-853 */
@@ -49,7 +52,8 @@ void smg_ktab_entry(const smg_ktab *t, int64_t i, uint8_t *kmer_out, int *count_
 /* index of the entry equal to the packed k-mer, or -1 (GoTo_Kmer_Entry, libfastk.c:1320-1409)  */
 int64_t smg_ktab_find(const smg_ktab *t, const uint8_t *kmer);
 
-/* the reference's conditioning probe, PloidyPlot.c:1167-1230                                   */
-void smg_ktab_examine(const smg_ktab *t, int ethresh, int *trim, int *symm);
+/* the reference's conditioning probe, PloidyPlot.c:1167-1230.  Returns SMG_KTAB_OK, or SMG_KTAB_SHORT when the
+   records of a table left on disk cannot be read (the decisions are then meaningless), SMG_KTAB_NOMEM          */
+int smg_ktab_examine(const smg_ktab *t, int ethresh, int *trim, int *symm);
 
 #endif

@@ -73,6 +73,9 @@ struct MultiCtx
   int      rc[SMG_MAXGPU];
   char     err[SMG_MAXGPU][256];
   int      rw;
+  int64_t *symm_hist[SMG_MAXGPU];           // symmetrise: entries / complements per leading `symm_bits` bits, per shard (host)
+  int      symm_bits;
+  pthread_mutex_t big_mu;                   // virtual shards: the sort of the symmetrise step runs one shard at a time
   RcclApi  api;
   ncclComm_t comm[SMG_MAXGPU];
   int64_t *plot;                            // result (host), written by rank 0
@@ -138,6 +141,41 @@ static int multi_filter(MultiCtx *c, int r, smg_engine *e, const u64 *splitters,
   return rc;
 }
 
+// records of `rw` words: what rank r grouped for rank p in c->send[r] (counts[r][p], destination-major) -> recv of rank p.
+// Call between two multi_agree()/barriers: every rank takes part.  Sets c->failed / c->rc[r] on error.
+static void multi_exchange(MultiCtx *c, int r, smg_engine *e, uint64_t *recv, int rw, const char *what)
+{ const int n = c->n;
+  char *eb = c->err[r]; const size_t el = sizeof(c->err[r]);
+  if (c->virt)
+    { int64_t roff = 0;
+      for (int s = 0; s < n && !c->failed; s++)
+        { int64_t soff = 0;
+          for (int d = 0; d < r; d++) soff += c->counts[s][d];
+          const int64_t cnt = c->counts[s][r];
+          if (cnt && hipMemcpy(recv + roff * rw, c->send[s] + soff * rw, sizeof(uint64_t) * (size_t) cnt * rw,
+                               hipMemcpyDeviceToDevice) != hipSuccess)
+            { c->rc[r] = fail(eb, el, SMG_ENODEV, "device to device copy failed (%s)", what); c->failed = 1; }
+          roff += cnt;
+        }
+      return;
+    }
+  ncclResult_t nr = c->api.GroupStart();
+  int64_t soff = 0, roff = 0;
+  for (int p = 0; p < n && nr == ncclSuccess; p++)
+    { if (c->counts[r][p])
+        nr = c->api.Send(c->send[r] + soff * rw, (size_t) c->counts[r][p] * rw, ncclUint64, p, c->comm[r], e->stream);
+      if (nr == ncclSuccess && c->counts[p][r])
+        nr = c->api.Recv(recv + roff * rw, (size_t) c->counts[p][r] * rw, ncclUint64, p, c->comm[r], e->stream);
+      soff += c->counts[r][p]; roff += c->counts[p][r];
+    }
+  const ncclResult_t ne = c->api.GroupEnd();
+  if (nr == ncclSuccess) nr = ne;
+  if (nr != ncclSuccess || hipStreamSynchronize(e->stream) != hipSuccess)
+    { c->rc[r] = fail(eb, el, SMG_ENODEV, "RCCL exchange failed: %s", nr != ncclSuccess ? c->api.GetErrorString(nr) : "stream error");
+      c->failed = 1;
+    }
+}
+
 static void *multi_worker(void *argp)
 { MultiArg *arg = (MultiArg *) argp;
   MultiCtx *c = arg->c;
@@ -172,15 +210,67 @@ static void *multi_worker(void *argp)
     { int64_t nn = 0;
       if ((c->rc[r] = smg_engine_condition(e, c->ethresh, 1, 0, &nn, eb, el))) c->failed = 1;
     }
-  if (MOK)
-    { c->nshard[r] = e->n;
-      if (e->n > 0 && hipMemcpy(c->first[r], e->keys, sizeof(u64) * W, hipMemcpyDeviceToHost) != hipSuccess)
-        MFAIL(SMG_ENODEV, "device to host copy failed");
+  const bool symm = (c->condition & SMG_COND_SYMM) != 0;
+  if (symm)
+    { // ---- close the table under reverse complement ACROSS the shards (Symmex, PloidyPlot.c:1395-1414) ------------
+      // S1: shape of the closed table -> balanced splitters on a boundary of `symm_bits` leading bits
+      const int bits = c->symm_bits, nbin = 1 << bits;
+      c->symm_hist[r] = (int64_t *) calloc((size_t) 2 * nbin, sizeof(int64_t));
+      if (MOK && !c->symm_hist[r]) MFAIL(SMG_ENOMEM, "out of host memory");
+      if (MOK && (c->rc[r] = smg_engine_symm_hist(e, bits, c->symm_hist[r], eb, el))) c->failed = 1;
+      pthread_barrier_wait(&c->bar);                                                     // S1: histograms published
+      if (MOK && r == 0)
+        { int64_t total = 0;
+          for (int s = 0; s < n; s++) for (int b = 0; b < 2 * nbin; b++) total += c->symm_hist[s][b];
+          int64_t acc = 0; int next = 1;
+          for (int s = 0; s < n; s++) memset(c->first[s], 0, sizeof(c->first[s]));
+          for (int b = 0; b < nbin && next < n; b++)
+            { // rank `next` starts at the first bin at which the closed table has reached next / n of its entries
+              while (next < n && acc >= total / n * next) { c->first[next][0] = (u64) b << (64 - bits); next++; }
+              for (int s = 0; s < n; s++) acc += c->symm_hist[s][b] + c->symm_hist[s][nbin + b];
+            }
+          for (; next < n; next++) memset(c->first[next], 0xFF, sizeof(c->first[next]));     // (nothing left for them)
+        }
+      pthread_barrier_wait(&c->bar);                                                     // S2: splitters published
+      free(c->symm_hist[r]); c->symm_hist[r] = NULL;
+      for (int s = 1; s < n; s++) memcpy(splitters + (size_t) (s - 1) * W, c->first[s], sizeof(u64) * W);
+      // S3: two records per entry (itself, its complement), grouped by destination
+      const int rw = W + 1;
+      const int64_t n2 = MOK ? 2 * e->n : 0;
+      if (MOK && hipMalloc(&c->send[r], sizeof(uint64_t) * (size_t) (n2 > 0 ? n2 : 1) * rw) != hipSuccess)
+        MFAIL(SMG_ENOMEM, "out of device memory while symmetrising");
+      if (MOK && (c->rc[r] = smg_engine_symm_route(e, (const uint64_t *) splitters, n, c->send[r], n2, c->counts[r], eb, el))) c->failed = 1;
+      pthread_barrier_wait(&c->bar);                                                     // S3: counts known
+      int64_t nrecv = 0;
+      if (MOK)
+        { for (int s = 0; s < n; s++) nrecv += c->counts[s][r];
+          if (hipMalloc(&recv, sizeof(uint64_t) * (size_t) (nrecv > 0 ? nrecv : 1) * rw) != hipSuccess)
+            MFAIL(SMG_ENOMEM, "out of device memory while symmetrising");
+        }
+      if (multi_agree(c)) multi_exchange(c, r, e, recv, rw, "symmetrise");            // S4
+      pthread_barrier_wait(&c->bar);                                                     // S5: peers have copied
+      if (c->send[r]) { hipFree(c->send[r]); c->send[r] = NULL; }
+      if (MOK)
+        { int64_t nn = 0;
+          if (c->virt) pthread_mutex_lock(&c->big_mu);
+          if ((c->rc[r] = smg_engine_symm_finish(e, recv, nrecv, &nn, eb, el))) c->failed = 1;
+          if (c->virt) pthread_mutex_unlock(&c->big_mu);
+        }
+      if (recv) { hipFree(recv); recv = NULL; }
+      if (MOK) c->nshard[r] = e->n;
+      pthread_barrier_wait(&c->bar);                                                     // A: shards ready (splitters = first[])
     }
-  pthread_barrier_wait(&c->bar);                                                         // A: shards + first k-mers
+  else
+    { if (MOK)
+        { c->nshard[r] = e->n;
+          if (e->n > 0 && hipMemcpy(c->first[r], e->keys, sizeof(u64) * W, hipMemcpyDeviceToHost) != hipSuccess)
+            MFAIL(SMG_ENODEV, "device to host copy failed");
+        }
+      pthread_barrier_wait(&c->bar);                                                     // A: shards + first k-mers
+    }
 
   // ---- pass 1, requests grouped by destination ---------------------------------------------------------
-  if (MOK)
+  if (MOK && !symm)
     { for (int s = n - 2; s >= 0; s--)            // an empty shard inherits its successor's first k-mer
         if (c->nshard[s] == 0 && r == 0) memcpy(c->first[s], c->first[s + 1], sizeof(c->first[s]));
     }
@@ -212,39 +302,7 @@ static void *multi_worker(void *argp)
         MFAIL(SMG_ENOMEM, "out of device memory for the request exchange");
     }
   const bool go_exchange = multi_agree(c);                                               // B2: all in, or all out
-  if (go_exchange)
-    { const int rw = c->rw;
-      if (c->virt)
-        { int64_t roff = 0;
-          for (int s = 0; s < n && MOK; s++)
-            { int64_t soff = 0;
-              for (int d = 0; d < r; d++) soff += c->counts[s][d];
-              const int64_t cnt = c->counts[s][r];
-              if (cnt && hipMemcpy(recv + roff * rw, c->send[s] + soff * rw, sizeof(uint64_t) * (size_t) cnt * rw,
-                                   hipMemcpyDeviceToDevice) != hipSuccess)
-                MFAIL(SMG_ENODEV, "device to device copy failed");
-              roff += cnt;
-            }
-        }
-      else
-        { ncclResult_t nr = c->api.GroupStart();
-          int64_t soff = 0, roff = 0;
-          for (int p = 0; p < n && nr == ncclSuccess; p++)
-            { if (c->counts[r][p])
-                nr = c->api.Send(c->send[r] + soff * rw, (size_t) c->counts[r][p] * rw, ncclUint64, p, c->comm[r], e->stream);
-              if (nr == ncclSuccess && c->counts[p][r])
-                nr = c->api.Recv(recv + roff * rw, (size_t) c->counts[p][r] * rw, ncclUint64, p, c->comm[r], e->stream);
-              soff += c->counts[r][p]; roff += c->counts[p][r];
-            }
-          const ncclResult_t ne = c->api.GroupEnd();
-          if (nr == ncclSuccess) nr = ne;
-          if (nr != ncclSuccess || hipStreamSynchronize(e->stream) != hipSuccess)
-            { c->rc[r] = fail(eb, el, SMG_ENODEV, "RCCL request exchange failed: %s",
-                              nr != ncclSuccess ? c->api.GetErrorString(nr) : "stream error");
-              c->failed = 1;
-            }
-        }
-    }
+  if (go_exchange) multi_exchange(c, r, e, recv, c->rw, "requests");
   if (MOK && (c->rc[r] = smg_engine_apply(e, recv, nrecv, &c->missing[r], eb, el))) c->failed = 1;
   if (MOK) smg_engine_symhash(e, (uint64_t *) c->fp[r], eb, el);
   pthread_barrier_wait(&c->bar);                                                         // C: proof words published
@@ -254,7 +312,7 @@ static void *multi_worker(void *argp)
   // ---- symmetry proof (host reduction), pass 2, histogram reduction -------------------------------------
   if (MOK)
     { int64_t miss = 0; u64 f[4] = { 0, 0, 0, 0 };
-      for (int s = 0; s < n; s++) { miss += c->missing[s]; for (int q = 0; q < 4; q++) f[q] += c->fp[s][q]; }
+      for (int s = 0; s < n; s++) { miss += c->missing[s]; for (int q = 0; q < 4; q++) f[q] ^= c->fp[s][q]; }
       bool symmetric = miss == 0;
       if (c->symcheck == SMG_SYM_HASH) symmetric = symmetric && f[0] == f[2] && f[1] == f[3];
       if (!symmetric)
@@ -320,8 +378,6 @@ static void multi_cuts(const smg_table_source *tv, int n, int64_t *cut)
 static int host_run_multi(const smg_table_source *tv, const smg_opts *opts, int ngpus, bool force_virtual, int64_t *plot,
                           smg_stats *stats, char *errbuf, size_t errlen)
 { if (ngpus > SMG_MAXGPU) ngpus = SMG_MAXGPU;
-  if ((opts->condition & SMG_COND_SYMM))
-    return fail(errbuf, errlen, SMG_EINVAL, "a multi-GPU run cannot symmetrise the table (use one GPU, or condition it first)%s");
   if (tv->kmer > FAST_MAX_K)
     return fail(errbuf, errlen, SMG_EINVAL, "multi-GPU runs support k <= 85%s");
   MultiCtx *c = new (std::nothrow) MultiCtx();
@@ -348,6 +404,11 @@ static int host_run_multi(const smg_table_source *tv, const smg_opts *opts, int 
         { const int rc = fail(errbuf, errlen, SMG_ENODEV, "ncclCommInitAll failed: %s", c->api.GetErrorString(nr)); delete c; return rc; }
     }
   multi_cuts(tv, ngpus, c->cut);
+  { const int p0 = tv->kmer / 2;               // splitters of the symmetrise step: a boundary of <= 12 leading bits is a
+    c->symm_bits = 2 * p0 < SY_MAXBITS ? 2 * p0 : SY_MAXBITS;      // window-block boundary too (blocks share p0 bases)
+    if (c->symm_bits < 2) c->symm_bits = 2;
+  }
+  pthread_mutex_init(&c->big_mu, NULL);
   pthread_barrier_init(&c->bar, NULL, (unsigned) ngpus);
   pthread_t th[SMG_MAXGPU];
   MultiArg args[SMG_MAXGPU];
@@ -395,6 +456,7 @@ static int host_run_multi(const smg_table_source *tv, const smg_opts *opts, int 
     }
   if (!c->virt) for (int r = 0; r < ngpus; r++) c->api.CommDestroy(c->comm[r]);
   pthread_barrier_destroy(&c->bar);
+  pthread_mutex_destroy(&c->big_mu);
   delete c;
   return rc;
 }

@@ -67,6 +67,13 @@
 #ifndef D_TAILB
 #define D_TAILB  8                         // tail: distances 4 .. D_TAILB + 3 come in batches of four LDS reads
 #endif
+#ifndef D_CANDQ
+#define D_CANDQ  1                         // request filter marks: 1 = the candidates of a tile are queued in LDS (their slot numbers,
+#endif                                     //   at the end of the merge, in the array the tail queue no longer needs) and marked by a
+                                           //   dense loop, one lane per candidate, through the tile's LDS window of D_BMF block ids;
+                                           //   0 = the round-2 code: every entry of every thread walks the whole marking sequence
+                                           //   (25 vector + 35 scalar instructions per entry for 17 % candidates).  Marking straight
+                                           //   into the global map from the dense loop (4.3e8 atomics) took 20.9 instead of 15.6 ms.
 #ifndef D_ABL
 #define D_ABL    0                         // ablation mask (timing experiments only; results are WRONG when non-zero):
 #endif                                     //   1 fingerprint, 2 directory, 4 signatures, 8 block map, 16 requests, 32 tail, 64 scan,
@@ -185,6 +192,7 @@ struct P1Cold                             // in device memory: what only a flush
 struct DShared                            // the workgroup's LDS arrays (pointers: the tile body is a function)
 { unsigned *cred; uint16_t *tailq; u64 *ent; uint16_t *lcn; u64 *sq;
   unsigned *s_tn, *s_qn, *s_nbig, *s_unsorted;
+  unsigned *s_cn;                        // candidates queued in tailq at the end of the merge (D_CANDQ)
   unsigned *bm;                          // candidate-block bits of this tile: D_BMW words (2 * D_BMW: two-bit map)
   unsigned *hist;                        // requests of this workgroup per bucket (D_HB bins), for the look-up chain's partition
 };
@@ -262,7 +270,7 @@ SMG_DEV bool d_code_uq(unsigned c) { return ((c & 63u) - 1u) < 62u && c < 128u; 
 // One tile.  INNER tiles lie completely inside the table: vector loads, no bounds checks, no table-end cases.
 // RW = 64-bit words per request record: W (the complement k-mer) or W + 1 (+ count | has-hi-pair << 16).
 template <int W, int RW, bool ODD, bool KF, bool INNER> SMG_DEV void
-d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64 &fa, u64 &fb, unsigned &fneg,
+d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64 &fa, u64 &fb,
        unsigned &bigmask, DPrefetch<W> &pf)
 { typedef typename DWord<W>::type WT;
   constexpr bool D_BM = (W == 1 && RW == 1) || (W == 2 && RW == 3);     // variants that feed the request filter
@@ -373,7 +381,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
   // ---- signatures ---------------------------------------------------------------------------------------------------
   //@mark D_SIG
   D_FENCE_P();
-  if (W <= 2 && !(D_ABL & 4) && owned)
+  if (W <= 2 && !(D_ABL & 4) && A.sig && owned)     // (no signatures: the look-ups bisect the k-mers themselves)
     { unsigned sg[4];
 #pragma unroll
       for (int e = 0; e < 4; e++)
@@ -385,6 +393,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
           if (vmask >> e & 1) A.sig[i0 + e] = (uint16_t) sg[e];
     }
   const int bmsh = A.bmsh();             // (the k-mers themselves are not needed past this point)
+  (void) bmsh;
 
   // ---- window-block structure as lane masks ---------------------------------------------------------------
   //@mark D_MASKS
@@ -463,6 +472,10 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
   //@mark D_BMAP
   D_FENCE_P();
   // word 0 of the tile's LDS bit map = the map word of the tile's first owned entry (a uniform, scalar load)
+#if D_CANDQ
+  // (the candidates are queued at the end of the merge, from the final code bytes, and marked after the tile: D_FLUSH)
+  const uint32_t bmbase = 0u; (void) bmbase;
+#else
   const uint32_t bmbase = D_BM ? (((uint32_t) (A.keys[(g0 + D_LEAD) * W] >> 32) >> bmsh) & ~31u) : 0u;
   if (D_BM && A.bmap && !(D_ABL & 8))
     { // leading word of the thread's own entries, back from the staged copy (cheaper than four registers kept alive
@@ -513,6 +526,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
             }
         }
     }
+#endif
 
   // ---- complement, fingerprint, requests ---------------------------------------------------------------------------
   unsigned codes = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
@@ -569,17 +583,17 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
 #endif
           const Key<W> rc = revcomp<W>(x, G.k);
           if (fp && owned)
-            { const bool lt = key_lt<W>(x, rc);
-              const bool gt = ODD ? !lt : key_lt<W>(rc, x);          // odd k: no k-mer is its own complement
+            { // XOR of h(min(x, rc x), count) over the entries: the two members of a closed class cancel, an entry
+              // without its complement (or with another count) leaves its 128 bits behind -- no signs, no carries
+              const bool lt = key_lt<W>(x, rc);
               u64 ha, hb;
               mix_hash<W>(lt ? x : rc, c, ha, hb);
-              const u64 sg = gt ? ~0ull : 0ull;                      // -h == (h ^ ~0) + 1
-              if (ODD && INNER) { fa += ha ^ sg; fb += hb ^ sg; fneg += gt; }
+              if (ODD && INNER) { fa ^= ha; fb ^= hb; }              // odd k: no k-mer is its own complement
               else
                 { u64 keep = ~0ull;
-                  if (!ODD) keep = (lt || gt) ? ~0ull : 0ull;        // self-complementary: no term
+                  if (!ODD) keep = key_eq<W>(x, rc) ? 0ull : ~0ull;  // self-complementary: occurs once, no term
                   if (!INNER) keep = ((vmask >> e) & 1u) ? keep : 0ull;
-                  fa += (ha ^ sg) & keep; fb += (hb ^ sg) & keep; fneg += (gt && keep) ? 1u : 0u;
+                  fa ^= ha & keep; fb ^= hb & keep;
                 }
             }
           //@mark D_EMIT
@@ -685,6 +699,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
             if (touched)
               { codes = (codes & ~(0xFFu << (8 * e))) | (nc << (8 * e));
                 if (big) { bigmask |= 1u << e; atomicAdd(S.s_nbig, 1u); }
+#if !D_CANDQ
                 if (D_BM && A.bmap && d_code_uq(nc) && !d_code_uq(oc))              // a candidate only now
                   { const u64 kw0 = S.ent[(slot0 + e) * W];
                     const uint32_t id = (uint32_t) (kw0 >> 32) >> bmsh;
@@ -697,6 +712,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
                     else if (rel < D_BMF) atomicOr(&S.bm[rel >> 5], 1u << (rel & 31));
                     else atomicOr(&A.bmap[id >> 5], 1u << (id & 31));
                   }
+#endif
                 if (!A.emit_all() && d_code_hi(nc) && !d_code_hi(oc) && !(D_ABL & 16))  // its first hi-side pair: send late
                   { const Key<W> x = lds_key<W>(S.ent, slot0 + e);
                     const Key<W> r = revcomp<W>(x, G.k);
@@ -708,6 +724,31 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
               }
           }
       }
+#if D_CANDQ
+    // ---- request filter: the CANDIDATES of this tile (final code: exactly one suffix-side pair) queue their slots ----
+    // The tail queue is dead by now: its array holds the candidate queue.  Found on the packed code word: low six bits
+    // 1..62 and bit 7 clear (d_code_uq; CODE_DEFER has all six set), one flag bit per byte.
+    if (D_BM && A.bmap && !(D_ABL & 8))
+      { const unsigned low6 = codes & 0x3F3F3F3Fu;
+        unsigned cm = ((low6 + 0x3F3F3F3Fu) >> 6) & ~((low6 + 0x01010101u) >> 6) & ~(codes >> 7) & 0x01010101u;
+        if (!INNER) cm &= (vmask & 1u) | ((vmask & 2u) << 7) | ((vmask & 4u) << 14) | ((vmask & 8u) << 21);
+        u64 C[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) C[e] = __ballot((cm >> (8 * e)) & 1u) & ownM;
+        const unsigned nc = (unsigned) (__popcll(C[0]) + __popcll(C[1]) + __popcll(C[2]) + __popcll(C[3]));
+        if (nc)
+          { unsigned base = 0;
+            if (lane == 0) base = atomicAdd(S.s_cn, nc);
+            base = (unsigned) __builtin_amdgcn_readfirstlane((int) base);
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+              { if (d_lane(C[e]))
+                  S.tailq[__builtin_amdgcn_mbcnt_hi((unsigned) (C[e] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) C[e], base))] = (uint16_t) (slot0 + e);
+                base += (unsigned) __popcll(C[e]);
+              }
+          }
+      }
+#endif
     if (owned)
       { if (INNER || vmask == 0xF) *reinterpret_cast<unsigned *>(A.code + i0) = codes;
         else
@@ -748,6 +789,7 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
   __shared__ u64      sfp[D_TPB / 64][2];
   constexpr bool D_BM = (W == 1 && RW == 1) || (W == 2 && RW == 3);
   __shared__ __attribute__((aligned(16))) unsigned bm[D_BM ? 2 * D_BMW : 1];
+  __shared__ unsigned s_cn;
   __shared__ unsigned hist[(D_BM && W == 1) ? D_HB : 1];
   __shared__ unsigned s_tn, s_qn, s_nbig, s_unsorted, s_chunk, s_used, s_bigbase, s_bigcur;
   __shared__ u64      s_base, s_total;
@@ -756,16 +798,15 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
   const int lane = t & 63, wv = t >> 6;
   const int slot0 = (wv * D_WL + lane) * 4;
   const int64_t n = A.n;
-  u64 fa = 0, fb = 0;                      // fingerprint: sum of (h ^ sign); the -1's are added at the end
-  unsigned fneg = 0;
+  u64 fa = 0, fb = 0;                      // fingerprint: XOR of the entries' 128-bit terms
   DShared S;
   S.cred = cred; S.tailq = tailq; S.ent = ent; S.lcn = lcn; S.sq = sq;
   S.s_tn = &s_tn; S.s_qn = &s_qn; S.s_nbig = &s_nbig; S.s_unsorted = &s_unsorted;
-  S.bm = bm; S.hist = hist;
+  S.bm = bm; S.hist = hist; S.s_cn = &s_cn;
   if (D_BM) for (int w = t; w < 2 * D_BMW; w += D_TPB) bm[w] = 0;
   if (D_BM && W == 1) for (int w = t; w < D_HB; w += D_TPB) hist[w] = 0;
   for (int s = t; s < D_CRED; s += D_TPB) cred[s] = 0;
-  if (t == 0) { s_chunk = F_NOCHUNK; s_used = 0; s_total = 0; s_tn = 0; s_qn = 0; s_nbig = 0; s_unsorted = 0; }
+  if (t == 0) { s_chunk = F_NOCHUNK; s_used = 0; s_total = 0; s_tn = 0; s_qn = 0; s_nbig = 0; s_unsorted = 0; s_cn = 0; }
   lds_barrier();
 
   DPrefetch<W> pf;
@@ -777,11 +818,31 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
       if (tile + gridDim.x >= A.ntiles || g0n + D_SLOTS + 32 > n) g0n = -1;
       unsigned bigmask;
       if (g0 >= 0 && g0 + D_SLOTS + 32 <= n)
-        d_tile<W, RW, ODD, KF, true>(A, S, g0, g0n, t, fa, fb, fneg, bigmask, pf);
+        d_tile<W, RW, ODD, KF, true>(A, S, g0, g0n, t, fa, fb, bigmask, pf);
       else
-        d_tile<W, RW, ODD, KF, false>(A, S, g0, g0n, t, fa, fb, fneg, bigmask, pf);
+        d_tile<W, RW, ODD, KF, false>(A, S, g0, g0n, t, fa, fb, bigmask, pf);
       if (!(D_ABL & 4096)) lds_barrier();
       //@mark D_FLUSH
+#if D_CANDQ
+      if (D_BM && A.bmap)                           // this tile's candidates -> bits of the tile's LDS window: one lane per candidate
+        { const unsigned cn = s_cn;
+          const int bmsh = A.bmsh();
+          const uint32_t bmbase = ((uint32_t) (ent[D_LEAD * W] >> 32) >> bmsh) & ~31u;
+          for (unsigned q = t; q < cn; q += D_TPB)
+            { const u64 kw = ent[(unsigned) tailq[q] * W];
+              const uint32_t id = (uint32_t) (kw >> 32) >> bmsh;
+              const uint32_t rel = id - bmbase;
+              if (A.two())
+                { const u64 v = bm2_bits(id, (uint32_t) kw);
+                  if (rel < D_BMF) atomicOr(reinterpret_cast<u64 *>(bm) + (rel >> 5), v);
+                  else atomicOr(reinterpret_cast<u64 *>(A.bmap) + (id >> 5), v);           // (sparse table: outside the window)
+                }
+              else if (rel < D_BMF) atomicOr(&bm[rel >> 5], 1u << (rel & 31));
+              else atomicOr(&A.bmap[id >> 5], 1u << (id & 31));
+            }
+          lds_barrier();
+        }
+#endif
       if (D_BM && A.bmap)                           // candidate-block bits of this tile -> global map
         { const int two = A.two() ? 1 : 0;          // (two-bit map: twice the words, at twice the word offset)
           for (int w = t; w < (D_BMW << two); w += D_TPB)
@@ -850,7 +911,7 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
           for (unsigned e = t; e < nb; e += D_TPB)
             if (s_bigbase + e < cold->big_cap) cold->biglist[s_bigbase + e] = list[e];
         }
-      if (t == 0) s_tn = 0;
+      if (t == 0) { s_tn = 0; s_cn = 0; }
       if (!(D_ABL & 8192)) lds_barrier();
     }
 
@@ -863,13 +924,13 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
       if (s_unsorted) cold->ctl->unsorted = 1;
     }
   if (A.want_fp())
-    { fa = wave_sum_u64(fa + (u64) fneg);
-      fb = wave_sum_u64(fb + (u64) fneg);
+    { fa = wave_xor_u64(fa);
+      fb = wave_xor_u64(fb);
       if ((t & 63) == 0) { sfp[t >> 6][0] = fa; sfp[t >> 6][1] = fb; }
       lds_barrier();
       if (t < 2)
         { u64 s = 0;
-          for (int w2 = 0; w2 < D_TPB / 64; w2++) s += sfp[w2][t];
+          for (int w2 = 0; w2 < D_TPB / 64; w2++) s ^= sfp[w2][t];
           cold->partials[(size_t) blockIdx.x * 4 + t] = s;
           cold->partials[(size_t) blockIdx.x * 4 + 2 + t] = 0;
         }

@@ -64,6 +64,7 @@ EXPORTS = [
     "smg_engine_apply_own", "smg_engine_blockmap", "smg_engine_blockmap_copy", "smg_engine_filter",
     "smg_engine_presort", "smg_engine_merge_maps", "smg_engine_set_blockmap_bits",
     "smg_engine_symhash", "smg_engine_pass2", "smg_engine_stats",
+    "smg_engine_symm_hist", "smg_engine_symm_route", "smg_engine_symm_finish", "smg_engine_table",
     "smg_engine_extract", "smg_hetmers_extract", "smg_free", "smg_condition_table", "smg_version",
 ]
 
@@ -131,6 +132,10 @@ def load_library():
     lib.smg_engine_set_blockmap_bits.argtypes = [vp, i32]
     lib.smg_engine_merge_maps.argtypes = [vp, vp, i64, i32, C.POINTER(i64), C.POINTER(i64), vp, *err]
     lib.smg_engine_symhash.argtypes = [vp, C.POINTER(C.c_uint64), *err]
+    lib.smg_engine_symm_hist.argtypes = [vp, i32, vp, *err]
+    lib.smg_engine_symm_route.argtypes = [vp, vp, i32, vp, i64, C.POINTER(i64), *err]
+    lib.smg_engine_symm_finish.argtypes = [vp, vp, i64, C.POINTER(i64), *err]
+    lib.smg_engine_table.argtypes = [vp, C.POINTER(i64), C.POINTER(vp), C.POINTER(vp)]
     lib.smg_engine_pass2.argtypes = [vp, vp, *err]
     lib.smg_engine_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.smg_engine_extract.argtypes = [vp, vp, vp, i64, C.POINTER(i64), *err]
@@ -278,6 +283,31 @@ class Engine:
         _check(self.lib.smg_engine_condition(self.h, ethresh, int(trim), int(symm), C.byref(n), self._buf, 512),
                self._buf)
         return int(n.value)
+
+    # ---- symmetrising across shards (smg_hetmers.h) ----------------------------------------
+    def symm_hist(self, bits: int) -> np.ndarray:
+        """int64[2 << bits]: this shard's entries, then their reverse complements, per leading `bits` k-mer bits"""
+        h = np.zeros(2 << bits, dtype=np.int64)
+        _check(self.lib.smg_engine_symm_hist(self.h, bits, h.ctypes.data, self._buf, 512), self._buf)
+        return h
+
+    def symm_route(self, splitters: np.ndarray, nranks: int, send_ptr: int, capacity: int):
+        counts = (C.c_int64 * nranks)()
+        sp = np.ascontiguousarray(splitters, dtype=np.uint64)
+        _check(self.lib.smg_engine_symm_route(self.h, sp.ctypes.data if sp.size else None, nranks, send_ptr,
+                                              capacity, counts, self._buf, 512), self._buf)
+        return [int(c) for c in counts]
+
+    def symm_finish(self, recv_ptr: int, nrecv: int) -> int:
+        n = C.c_int64(0)
+        _check(self.lib.smg_engine_symm_finish(self.h, recv_ptr, nrecv, C.byref(n), self._buf, 512), self._buf)
+        return int(n.value)
+
+    def table(self):
+        """(entries, device pointer of the k-mers, device pointer of the counts) of the engine's current table"""
+        n, pk, pc = C.c_int64(0), C.c_void_p(0), C.c_void_p(0)
+        self.lib.smg_engine_table(self.h, C.byref(n), C.byref(pk), C.byref(pc))
+        return int(n.value), pk.value or 0, pc.value or 0
 
     def run(self, plot_ptr: int, symcheck: str = "exact") -> dict:
         st = Stats()

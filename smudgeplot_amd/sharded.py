@@ -13,7 +13,8 @@ Data path per run (see DESIGN.md "Multi-GPU"):
      rank that owns the reverse complement  -> all_to_all_single over xGMI;
      the symmetry proof (fingerprints 4 x u64 + missing count) rides on the final all_reduce;
   3. pass 2 on every shard;
-  4. ONE all_reduce(SUM, int64[1001*501 + 5]) of the per-GPU 2-D histograms with the proof words appended.
+  4. ONE all_reduce(SUM, int64[1001*501 + 1 + 2*world]) of the per-GPU 2-D histograms with the proof words appended
+     (missing count + one 128-bit XOR-fingerprint slot per rank).
 
 torch is plumbing here: device buffers and collectives.  The compute is the C-ABI engine
 (`engine.Engine`); `engine_factory` lets the CPU test-suite substitute a numpy stand-in so the
@@ -264,17 +265,26 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
 
     # pass 2 runs before the symmetry proof is known (its result is discarded when the proof fails): the proof
     # words ride at the end of the histogram buffer, so ONE all_reduce carries both (sums wrap mod 2^64)
-    buf = torch.zeros(PLOT_CELLS + 5, dtype=torch.int64, device=dev)
+    # Layout behind the plot: [missing count] + two words per rank.  The fingerprint is an XOR over the table, which
+    # a SUM all_reduce cannot combine -- so every rank writes its 128-bit residue into ITS OWN two words (zeros
+    # elsewhere), the sum hands every rank all residues, and the XOR over the ranks is taken on the host.
+    nslot = world if exchange else 1
+    buf = torch.zeros(PLOT_CELLS + 1 + 2 * nslot, dtype=torch.int64, device=dev)
     plot = buf[:PLOT_CELLS]
     eng.pass2(plot)
-    proof = np.array([missing] + eng.symhash(), dtype=np.uint64).view(np.int64)
-    buf[PLOT_CELLS:] = torch.from_numpy(proof.copy()).to(dev)
+    fpw = eng.symhash()
+    proof = np.zeros(1 + 2 * nslot, dtype=np.uint64)
+    proof[0] = missing
+    me = rank if exchange else 0
+    proof[1 + 2 * me] = fpw[0] ^ fpw[2]
+    proof[2 + 2 * me] = fpw[1] ^ fpw[3]
+    buf[PLOT_CELLS:] = torch.from_numpy(proof.view(np.int64).copy()).to(dev)
     if exchange:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     pv = buf[PLOT_CELLS:].cpu().numpy().view(np.uint64)
     symmetric = pv[0] == 0
     if symcheck == "hash":
-        symmetric = symmetric and pv[1] == pv[3] and pv[2] == pv[4]
+        symmetric = symmetric and int(np.bitwise_xor.reduce(pv[1::2])) == 0 and int(np.bitwise_xor.reduce(pv[2::2])) == 0
     if not symmetric:
         if not fallback:
             raise NotSymmetric("table is not closed under reverse complement with equal counts; "

@@ -93,15 +93,14 @@ class NumpyEngine:
             req.extend(self._words(self.rc[i]))
             req.append(int(cnt[i]) | (int(s_hi[i] > 0) << 16))
         self.req = np.array(req, dtype=np.uint64)
-        # signed canonical fingerprint (any function that cancels over {x, rc(x)} pairs will do)
+        # canonical XOR fingerprint (any function of (min(x, rc x), count) will do: the two members of a class cancel)
         f = 0
         for i in range(n):
             x, r = keys[i], self.rc[i]
             if x == r:
                 continue
             c = min(x, r)
-            h = _mix(_mix(c & M64) ^ _mix(c >> 64) ^ _mix(int(cnt[i])))
-            f = (f + h) & M64 if x < r else (f - h) & M64
+            f ^= _mix(_mix(c & M64) ^ _mix(c >> 64) ^ _mix(int(cnt[i])))
         self.fp = [f, 0, 0, 0]
         self.symcheck = symcheck
 

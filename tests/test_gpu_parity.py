@@ -232,7 +232,7 @@ def test_engine_object_with_torch_tensors_and_manual_two_shard_exchange():
             parts.append(sends[src][off: off + counts[src][dst] * rw])
         recv = torch.cat(parts)
         assert en.apply(recv, recv.numel() // rw) == 0
-        fps = fps + np.array(en.symhash(), dtype=np.uint64)
+        fps = fps ^ np.array(en.symhash(), dtype=np.uint64)          # the shards' residues combine by XOR
     assert fps[0] == fps[2] and fps[1] == fps[3]
     for en in engs:
         pl = torch.zeros(engine.PLOT_CELLS, dtype=torch.int64, device=dev)
@@ -404,8 +404,7 @@ def _manual_sharded(k, tk, tc, cuts, dev, symcheck="hash"):
             parts.append(sends[src][off: off + counts[src][dst] * rw])
         recv = torch.cat(parts)
         assert en.apply(recv, recv.numel() // rw) == 0
-        with np.errstate(over="ignore"):
-            fps = fps + np.array(en.symhash(), dtype=np.uint64)
+        fps = fps ^ np.array(en.symhash(), dtype=np.uint64)          # the shards' residues combine by XOR
     assert fps[0] == fps[2] and fps[1] == fps[3]
     total = torch.zeros(engine.PLOT_CELLS, dtype=torch.int64, device=dev)
     for en in engs:

@@ -167,3 +167,29 @@ def test_blockmap_ranges_cover_the_map_and_share_only_boundary_words():
             # the engine's two-bit map: 64 bits per 32 block ids, the same ranges in units of two words
             wlo2, wlen2 = sharded.blockmap_ranges(firsts, 1, world, bits, 2)
             assert wlo2 == [2 * v for v in wlo] and wlen2 == [2 * v for v in wlen]
+
+
+def test_hostile_stub_is_refused_before_any_record_is_touched(tmp_path):
+    """A stub that claims k = 300 (records wider than the loader's one-record scratch buffers), a part header whose
+    entry count overflows the size check, and a part that shrinks after the probe's open: all are errors with the
+    loader's message and exit code 1 -- never a crash, never a table that is silently called "trimmed"."""
+    import struct
+    packed, cnt = synth.adversarial_table(31, 200, 4, seed=8)
+    ktab.write_ktab(str(tmp_path / "t"), 31, packed, cnt, ibyte=1, nparts=1)
+    stub = bytearray((tmp_path / "t.ktab").read_bytes())
+    part = bytearray((tmp_path / ".t.ktab.1").read_bytes())
+    # k = 300 in stub and part (consistent, so only the bound can stop it)
+    (tmp_path / "big.ktab").write_bytes(struct.pack("<i", 300) + bytes(stub[4:]))
+    (tmp_path / ".big.ktab.1").write_bytes(struct.pack("<i", 300) + bytes(part[4:]))
+    r = run(["-e4", "-obig", "big"], tmp_path)
+    assert r.returncode == 1 and r.stderr == "hetmers: Table file ./big.ktab is truncated or not a FastK table\n"
+    # a part that claims 2^62 entries: 12 + n * pbyte overflows int64
+    (tmp_path / "ovf.ktab").write_bytes(bytes(stub))
+    (tmp_path / ".ovf.ktab.1").write_bytes(bytes(part[:4]) + struct.pack("<q", 1 << 62) + bytes(part[12:]))
+    r = run(["-e4", "-oovf", "ovf"], tmp_path)
+    assert r.returncode == 1 and r.stderr == "hetmers: Table file ./.ovf.ktab.1 is truncated or not a FastK table\n"
+    r = run(["-e4", "-oneg", "ovf"], tmp_path)
+    assert r.returncode == 1
+    (tmp_path / ".ovf.ktab.1").write_bytes(bytes(part[:4]) + struct.pack("<q", -5) + bytes(part[12:]))
+    r = run(["-e4", "-oneg", "ovf"], tmp_path)
+    assert r.returncode == 1 and "truncated or not a FastK table" in r.stderr

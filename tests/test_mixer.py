@@ -1,10 +1,10 @@
 """The 128-bit mixer of the symmetry fingerprint (`mix_hash`, smudgeplot_amd/csrc/smg_pass1d.hpp).
 
-The hash proof stands on one property: the +-h(min(x, rc x), count) terms of a table cancel if and only if the
-table is closed under reverse complement with equal counts -- which needs h to behave like a random function of the
-(k-mer, count) pair.  Here: a numpy restatement of the device function (same constants, same order of operations),
-an avalanche measurement over every input bit, and -- on the GPU -- the engine's own fingerprint of small tables
-that are NOT closed, which must equal the signed sum of the restatement's values entry by entry.
+The hash proof stands on one property: the XOR of the h(min(x, rc x), count) terms of a (sorted, duplicate-free) table
+is zero if and only if the table is closed under reverse complement with equal counts -- which needs h to behave like
+a random function of the (k-mer, count) pair.  Here: a numpy restatement of the device function (same constants, same
+order of operations), an avalanche measurement over every input bit, and -- on the GPU -- the engine's own fingerprint
+of small tables that are NOT closed, which must equal the XOR of the restatement's values entry by entry.
 """
 import numpy as np
 import pytest
@@ -113,8 +113,8 @@ def _rc_words(keys, k):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("k", [31, 32, 21, 40, 51, 64])
-def test_engine_fingerprint_is_the_signed_sum_of_the_restatement(k):
-    """a table that is NOT closed: the residue the engine reports is sum(+-h) of exactly this function"""
+def test_engine_fingerprint_is_the_xor_of_the_restatement(k):
+    """a table that is NOT closed: the residue the engine reports is the XOR of exactly this function over its entries"""
     import torch
     from smudgeplot_amd import engine
     W = (k + 31) // 32
@@ -133,9 +133,8 @@ def test_engine_fingerprint_is_the_signed_sum_of_the_restatement(k):
             ha, hb = mix_hash([m], [int(c)])
         else:
             ha, hb = mix_hash([m >> 64], [int(c)], [m & M])
-        s = 1 if x < r else -1
-        fa = (fa + s * int(ha[0])) & M
-        fb = (fb + s * int(hb[0])) & M
+        fa ^= int(ha[0])
+        fb ^= int(hb[0])
     words = np.array([[(x >> (64 * (W - 1 - j))) & M for j in range(W)] for x in vals], dtype=np.uint64)
     dev = torch.device("cuda:0")
     tk = torch.from_numpy(words.view(np.int64).reshape(-1).copy()).to(dev)
@@ -146,4 +145,4 @@ def test_engine_fingerprint_is_the_signed_sum_of_the_restatement(k):
     got = e.symhash()
     torch.cuda.synchronize()
     e.close()
-    assert ((got[0] - got[2]) & M, (got[1] - got[3]) & M) == (fa, fb)
+    assert (got[0] ^ got[2], got[1] ^ got[3]) == (fa, fb)

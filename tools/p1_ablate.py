@@ -37,6 +37,7 @@ for spec in sys.argv[3:]:
                 st = e.run(plot.data_ptr(), "hash")
                 res.append((st["ms_pass1"], st["ms_rclookup"], st["ms_pass2"], st["ms_total"], st["nrequests"], st.get("ms_filter", 0)))
             else:
+                e.set_blockmap_bits(32)        # what a whole single-GPU run uses (the phase API defaults to the 30-bit exchange map)
                 e.pass1("hash"); st = e.stats(); res.append((st["ms_pass1"],))
         torch.cuda.synchronize()
         r = res[1:]
