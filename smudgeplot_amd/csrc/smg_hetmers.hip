@@ -478,7 +478,8 @@ struct smg_engine
   uint32_t    *chunk_off; int64_t chunk_off_cap;
   uint32_t    *skey[2]; int64_t skey_cap[2];   // index sort of wide records: leading k-mer bits (in, out)
   uint32_t    *sidx[2]; int64_t sidx_cap[2];   //                                  record numbers (in, out)
-  uint32_t    *biglist; int64_t biglist_cap;    // bytes
+  uint32_t    *dbits;  int64_t dbits_cap;      // deferred entries of kf_pass1_d: one bit per table entry (bytes); all zero between runs
+  bool         dbits_dirty;                     //   ... unless a run was abandoned between pass 1 and kf_bigfix
   int          rw;                           // 64-bit words per request record
   uint32_t    *chunk_fill; int64_t chunk_cap; // bytes
   unsigned     max_chunks;
@@ -582,7 +583,7 @@ extern "C" void smg_engine_destroy(smg_engine *e)
   hipSetDevice(e->device);
   hipStreamSynchronize(e->stream);
   hipFree(e->own_keys); hipFree(e->own_cnt); hipFree(e->deg); hipFree(e->sig); hipFree(e->bstart);
-  hipFree(e->req); hipFree(e->req2); hipFree(e->sort_tmp); hipFree(e->dense); hipFree(e->chunk_off); hipFree(e->skey[0]); hipFree(e->skey[1]); hipFree(e->sidx[0]); hipFree(e->sidx[1]); hipFree(e->biglist); hipFree(e->chunk_fill); hipFree(e->bmap); hipFree(e->reqf); hipFree(e->chunk_fillf); hipFree(e->route_cnt); hipFree(e->route_off);
+  hipFree(e->req); hipFree(e->req2); hipFree(e->sort_tmp); hipFree(e->dense); hipFree(e->chunk_off); hipFree(e->skey[0]); hipFree(e->skey[1]); hipFree(e->sidx[0]); hipFree(e->sidx[1]); hipFree(e->dbits); hipFree(e->chunk_fill); hipFree(e->bmap); hipFree(e->reqf); hipFree(e->chunk_fillf); hipFree(e->route_cnt); hipFree(e->route_off);
   hipFree(e->partials); hipFree(e->ctrl); hipFree(e->d_split); hipFree(e->p1cold); hipFree(e->ghist); hipFree(e->boff);
   hipFree(e->whist);
   hipHostFree(e->h_ctrl); hipHostFree(e->h_partials); hipHostFree(e->h_p1cold);
@@ -948,6 +949,7 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
           if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || cus < 1) cus = 256;
           { const char *g = getenv("SMG_P1_WGS_PER_CU"); if (g && atoi(g) > 0) nb = atoi(g); }
           cached = (unsigned) (nb * cus);
+          if (getenv("SMG_DEBUG")) fprintf(stderr, "  [smg] kf_pass1_d<%d,%d>: %d workgroups per CU x %d CUs\n", e->W, e->rw, nb, cus);
         }
       grid = cached;
     }
@@ -957,7 +959,11 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
   // chunks fill to >= 75 %: size the list for that, and never below what is already allocated
   // (an engine that is reused on the same table must not redo pass 1 every time)
   int64_t want_rec = (emit_all ? e->n + e->n / 24 : e->n / 4) + (int64_t) (grid + 16 + 256) * F_CH;
-  int64_t big_cap = e->biglist_cap / 4 > (1 << 20) ? e->biglist_cap / 4 : (1 << 20);
+  const int64_t dwords = ((((e->n + 31) >> 5) + 2) + 3) & ~3ll;          // (kf_bigfix reads the map four words at a time)
+  if (narrow)
+    { if (e->dbits_cap < dwords * 4) e->dbits_dirty = true;                 // (fresh memory)
+      if ((rc = grow(&e->dbits, &e->dbits_cap, dwords * 4, errbuf, errlen))) return rc;
+    }
   bool done = false;
   for (int attempt = 0; attempt < 4 && !done; attempt++)
     { unsigned maxc = (unsigned) ((want_rec + F_CH - 1) / F_CH);
@@ -975,7 +981,8 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
       if ((rc = grow(&e->req, &e->req_cap, (int64_t) maxc * F_CH * (int64_t) sizeof(u64) * e->rw, errbuf, errlen))) return rc;
       if ((rc = grow(&e->chunk_fill, &e->chunk_cap, (int64_t) maxc * 4 + 4, errbuf, errlen))) return rc;
       e->max_chunks = maxc;
-      if ((rc = grow(&e->biglist, &e->biglist_cap, big_cap * 4, errbuf, errlen))) return rc;
+      if (narrow && e->dbits_dirty)
+        { HIPCHK(hipMemsetAsync(e->dbits, 0, (size_t) e->dbits_cap, e->stream)); e->dbits_dirty = false; }
       FastArgs a = make_fast(e);
       if (e->lg.nb)
         { // owners of the request chunks: the workgroups of this launch, then those of kf_bigfix (rows zero unless it runs)
@@ -992,10 +999,10 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
           hot.bmap = a.bmap; hot.b0 = e->dir.b0; hot.nb = e->dir.nb; hot.shifts = (unsigned) e->dir.dsh | ((unsigned) a.sigsh << 6) | (((unsigned) a.bmsh & 31u) << 12)
                        | ((emit_all ? 1u : 0u) << 18) | ((want_fp ? 1u : 0u) << 19) | ((unsigned) e->lg.nb << 20) | ((unsigned) e->bm2 << 24);
           hot.G = gr; hot.ntiles = ntiles;
-          e->h_p1cold->req = e->req; e->h_p1cold->chunk_fill = e->chunk_fill; e->h_p1cold->biglist = e->biglist;
+          e->h_p1cold->req = e->req; e->h_p1cold->chunk_fill = e->chunk_fill; e->h_p1cold->dbits = e->dbits;
+          e->dbits_dirty = true;                                               // until kf_bigfix has cleared the bits again
           e->h_p1cold->partials = e->partials; e->h_p1cold->ctl = &e->ctrl->fast; e->h_p1cold->max_chunks = maxc;
           e->h_p1cold->whist = e->whist; e->h_p1cold->owners = grid + BF_MAXGRID;
-          e->h_p1cold->big_cap = (unsigned) big_cap;
           HIPCHK(hipMemcpyAsync(e->p1cold, e->h_p1cold, sizeof(P1Cold), hipMemcpyHostToDevice, e->stream));
 #define LAUNCH_R(W_, RW_, ODD_, KF_) hipLaunchKernelGGL((kf_pass1_d<W_, RW_, ODD_, KF_>), dim3(grid), dim3(D_TPB), 0, e->stream, hot, \
                               (const P1Cold *) e->p1cold)
@@ -1018,40 +1025,30 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
       HIPCHK(hipGetLastError());
       if (want_fp)
         HIPCHK(hipMemcpyAsync(e->h_partials, e->partials, sizeof(u64) * 4 * grid, hipMemcpyDeviceToHost, e->stream));
-      if ((rc = read_ctrl(e, errbuf, errlen))) return rc;
-      if (e->h_ctrl->fast.unsorted)
-        return fail(errbuf, errlen, SMG_EFORMAT, "table entries are not strictly increasing%s");
-      bool redo = false;
-      if (e->h_ctrl->fast.n_chunks > maxc)
-        { // the request list outgrew its first-guess capacity: size it from the count and redo
-          want_rec = (int64_t) (e->h_ctrl->fast.n_chunks + 16 + 256) * F_CH;
-          redo = true;
-        }
-      if ((int64_t) e->h_ctrl->fast.nbig > big_cap)
-        { big_cap = (int64_t) e->h_ctrl->fast.nbig + 1024; redo = true; }
-      if (redo)
-        { HIPCHK(hipMemsetAsync(&e->ctrl->fast, 0, sizeof(FastCtl), e->stream));
-          continue;
-        }
-      if (narrow && e->h_ctrl->fast.nbig > 0)
-        { // exact redo of the entries whose window block is longer than the halo
-          const unsigned nbig = e->h_ctrl->fast.nbig;
-          unsigned fb = (nbig + BF_TPB - 1) / BF_TPB;
+      if (narrow)
+        { // exact redo of the deferred entries (a pair at distance 4..30, or a window block longer than the window): the
+          // kernel scans the bit map pass 1 marked them in and leaves it cleared.  Launched without waiting for pass 1's
+          // control words (a request list that overflowed is guarded on the device; the run is redone below either way).
+          unsigned fb = (unsigned) ((dwords / 4 + BF_TPB - 1) / BF_TPB);
           if (fb > BF_MAXGRID) fb = BF_MAXGRID;
-
-#define BIGFIX(W_, RW_) hipLaunchKernelGGL((kf_bigfix<W_, RW_>), dim3(fb), dim3(BF_TPB), 0, e->stream, a, e->biglist, nbig, e->req, \
+#define BIGFIX(W_, RW_) hipLaunchKernelGGL((kf_bigfix<W_, RW_>), dim3(fb), dim3(BF_TPB), 0, e->stream, a, e->dbits, dwords, e->req, \
                               e->chunk_fill, maxc, &e->ctrl->fast, e->lg.nb ? e->whist + (size_t) grid * L_BK : (unsigned *) NULL, \
                               grid, grid + BF_MAXGRID, e->lg.nb)
           hipEventRecord(e->ev[0], e->stream);
           if (e->W == 2) BIGFIX(2, 3); else if (e->rw == 1) BIGFIX(1, 1); else BIGFIX(1, 2);
 #undef BIGFIX
           hipEventRecord(e->ev[3], e->stream);
-          if ((rc = read_ctrl(e, errbuf, errlen))) return rc;
-          if (e->h_ctrl->fast.n_chunks > maxc)
-            { want_rec = (int64_t) (e->h_ctrl->fast.n_chunks + 16 + 256) * F_CH;
-              HIPCHK(hipMemsetAsync(&e->ctrl->fast, 0, sizeof(FastCtl), e->stream));
-              continue;
-            }
+          HIPCHK(hipGetLastError());
+        }
+      if ((rc = read_ctrl(e, errbuf, errlen))) return rc;
+      e->dbits_dirty = false;
+      if (e->h_ctrl->fast.unsorted)
+        return fail(errbuf, errlen, SMG_EFORMAT, "table entries are not strictly increasing%s");
+      if (e->h_ctrl->fast.n_chunks > maxc)
+        { // the request list outgrew its first-guess capacity: size it from the count and redo
+          want_rec = (int64_t) (e->h_ctrl->fast.n_chunks + 16 + 256) * F_CH;
+          HIPCHK(hipMemsetAsync(&e->ctrl->fast, 0, sizeof(FastCtl), e->stream));
+          continue;
         }
       done = true;
     }
@@ -1071,7 +1068,7 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
   e->st.ms_filter = 0;
   e->st.nbig = narrow ? (int64_t) e->h_ctrl->fast.nbig : 0;
   e->st.ms_bigfix = 0;
-  if (e->st.nbig > 0) { float mb = 0; hipEventElapsedTime(&mb, e->ev[0], e->ev[3]); e->st.ms_bigfix = mb; }
+  if (narrow) { float mb = 0; hipEventElapsedTime(&mb, e->ev[0], e->ev[3]); e->st.ms_bigfix = mb; }
   e->prepared = true;
   return SMG_OK;
 }
@@ -2064,27 +2061,28 @@ static int host_run(const smg_table_source *tv, const smg_opts *opts, int64_t *p
     { int64_t limit = 0xFFFFFFF0ll - 16;
       const char *sl = getenv("SMG_SHARD_LIMIT");
       if (sl && atoll(sl) > 0) limit = atoll(sl);
-      if (ng <= 1 && tv->nels >= limit && !labels)
+      // (a table that still has to be symmetrised closes to at most twice its entries: shard it for that size)
+      const bool want_symm = opts && (opts->condition & SMG_COND_SYMM);
+      const int64_t closed = want_symm ? 2 * tv->nels : tv->nels;
+      if (ng <= 1 && closed >= limit && !labels)
         { int64_t per = limit > 3000000000ll ? 3000000000ll : limit;     // ~3e9 entries per shard
           if (per < 1) per = 1;
-          ng = (int) ((tv->nels + per - 1) / per);
+          ng = (int) ((closed + per - 1) / per);
           if (ng < 2) ng = 2;
           if (ng > SMG_MAXGPU)
             return fail(errbuf, errlen, SMG_EINVAL, "table too large for one GPU (more than 16 shards of 3e9 entries): use SMUDGEPLOT_GPUS%s");
           virt = true;
-          if (verbose) fprintf(stderr, "  [smg] %lld entries: %d prefix shards on one device\n", (long long) tv->nels, ng);
-          if ((opts && (opts->condition & SMG_COND_SYMM)) || tv->kmer > FAST_MAX_K)
-            return fail(errbuf, errlen, SMG_EINVAL, "a table of more than 2^32 entries must be symmetric already and have k <= 85 "
-                        "(symmetrise it in pieces with smg_condition, or use the FastK tools)%s");
+          if (verbose) fprintf(stderr, "  [smg] %lld entries%s: %d prefix shards on one device\n", (long long) tv->nels,
+                               want_symm ? " before the table is symmetrised" : "", ng);
+          if (tv->kmer > FAST_MAX_K)
+            return fail(errbuf, errlen, SMG_EINVAL, "a table of more than 2^32 entries needs k <= 85%s");
         }
     }
     // SMG_FORCE_MULTI=1 (tests): take the multi-GPU code path even with one GPU -- a one-rank RCCL
     // communicator, send/recv to self, all-reduce: checks the dlopen'ed RCCL entry points on a 1-GPU box
     if (ng <= 1 && getenv("SMG_FORCE_MULTI") && !v) ng = -1;
     if ((ng > 1 || ng == -1) && !labels)
-      { if (opts && (opts->condition & SMG_COND_SYMM))
-          { if (verbose) fprintf(stderr, "  [smg] the table has to be symmetrised first: using one GPU\n"); }
-        else if (tv->kmer > FAST_MAX_K)
+      { if (tv->kmer > FAST_MAX_K)
           { if (verbose) fprintf(stderr, "  [smg] k > 85: using one GPU\n"); }
         else
           { smg_opts o; memset(&o, 0, sizeof(o));

@@ -19,9 +19,16 @@
 //     byte from a select chain over the masks, signature, directory, fingerprint, request), the requests of a
 //     wave get their queue slots from one LDS atomic per wave + mbcnt.
 //
-// Entries whose window block goes on past distance 3 (~6 % on the diploid table) are finished from an LDS copy
-// of the tile by a short tail loop (distances 4..30) that hands its (rare) hits over as packed counters in one
-// LDS word per entry; blocks longer than that go to kf_bigfix.
+// Entries whose window block goes on past distance 3 (~6 % on the diploid table) are NOT finished inside their tile
+// any more (round 2 did: a tail phase by one wave while three waited, hand-over words in LDS, a merge phase and two
+// more workgroup barriers per tile: 2.9 of 15.6 ms).  Their owners queue their slots; after the tile one dense pass
+// (a lane per queued entry, partners from the staged LDS copy) only DETECTS whether such an entry has a pair at
+// distance 4..30 or a block beyond 30 -- rare: 0.8 % of the pairs of the diploid table -- and sets the bits of the
+// entry and of its partner in a one-bit-per-entry map; kf_bigfix recomputes the marked entries exactly after the
+// launch (code byte, map bit, request).  Until then their code bytes are the provisional ones of the register scan:
+// any request or map bit those caused is a superset of what the final state needs.
+// (Collecting the queued entries over several tiles and detecting 256 at a time from global memory was tried first:
+//  the passes -- 18 dependent-latency loads per entry -- cost 3.2 ms.)
 //
 // The fingerprint mixer is two dependent 32x32->64 multiply-adds (v_mad_u64_u32 is full rate on gfx950) and one
 // ChaCha quarter round: same avalanche as the three quarter rounds it replaces (tests/test_mixer.py), 21
@@ -41,14 +48,14 @@
 #define D_SLOTS  (D_SCAN + 8)              // staged entries: scanned + the two outer halo threads
 #define D_LEAD   (D_HALO + 4)              // staged entries in front of the first owned one
 #define D_WIN    30                        // partners are searched within +-30 entries
-#define D_CRED   (D_SLOTS + 32)
-#define D_BIG    0x80000000u
 #ifndef D_BMF
 #define D_BMF    4096                      // block ids per tile with a bit in LDS (request filter)
 #endif
 #define D_BMW    (D_BMF / 32)
 #define D_HB     1024                      // bins of the request histogram (smg_lookup.hpp: L_BK)
+#ifndef D_QCAP
 #define D_QCAP   1280                      // LDS request queue (records); flushed when the next tile might not fit
+#endif
 // Scheduling fences (nothing is scheduled across them).  They were put between the tests and between the phases when
 // the machine scheduler hoisted every compare to the front and the kernel spilled lane masks (SGPR pairs) by the dozen;
 // with today's kernel only the ones between the entries of the complement loop still pay (they keep its four entries
@@ -67,17 +74,12 @@
 #ifndef D_TAILB
 #define D_TAILB  8                         // tail: distances 4 .. D_TAILB + 3 come in batches of four LDS reads
 #endif
-#ifndef D_CANDQ
-#define D_CANDQ  1                         // request filter marks: 1 = the candidates of a tile are queued in LDS (their slot numbers,
-#endif                                     //   at the end of the merge, in the array the tail queue no longer needs) and marked by a
-                                           //   dense loop, one lane per candidate, through the tile's LDS window of D_BMF block ids;
-                                           //   0 = the round-2 code: every entry of every thread walks the whole marking sequence
-                                           //   (25 vector + 35 scalar instructions per entry for 17 % candidates).  Marking straight
-                                           //   into the global map from the dense loop (4.3e8 atomics) took 20.9 instead of 15.6 ms.
+#define D_RD     3                         // distances tested register-to-register; the deferred tail starts at D_RD + 1 (a fourth
+                                           //   distance in registers: ten vector registers spill, 16.4 instead of 14.7 ms)
 #ifndef D_ABL
 #define D_ABL    0                         // ablation mask (timing experiments only; results are WRONG when non-zero):
 #endif                                     //   1 fingerprint, 2 directory, 4 signatures, 8 block map, 16 requests, 32 tail, 64 scan,
-                                           //   256 tail continuation, 512 tail processing, 1024/2048/4096/8192 the four barriers, 16384 merge of the tail's results
+                                           //   512 tail detection passes, 4096/8192 the two barriers of a tile
 
 template <int W> struct DWord;
 template <> struct DWord<1> { typedef unsigned type; };
@@ -180,19 +182,19 @@ struct P1Hot                              // kernel argument: what every tile to
 struct P1Cold                             // in device memory: what only a flush touches (kept out of the register file)
 { u64      *req;
   uint32_t *chunk_fill;
-  uint32_t *biglist;
   u64      *partials;
   FastCtl  *ctl;
   unsigned *whist;               // look-up chain: requests of workgroup w per bucket (leading hbits bits of the target)
                                  //   in row w: whist[w * D_HB + b]
   unsigned  owners;              //   chunk slots are dealt out without a counter: owner w fills w, w + owners, w + 2 owners, ..
-  unsigned  max_chunks, big_cap;
+  unsigned  max_chunks;
+  uint32_t *dbits;               // deferred entries: one bit per table entry (kf_bigfix redoes them exactly and clears the bits)
 };
 
 struct DShared                            // the workgroup's LDS arrays (pointers: the tile body is a function)
-{ unsigned *cred; uint16_t *tailq; u64 *ent; uint16_t *lcn; u64 *sq;
-  unsigned *s_tn, *s_qn, *s_nbig, *s_unsorted;
-  unsigned *s_cn;                        // candidates queued in tailq at the end of the merge (D_CANDQ)
+{ uint16_t *tailq;                       // deferred tail: slots of this tile's entries whose block goes on past distance 3
+  u64 *ent; uint16_t *lcn; u64 *sq;
+  unsigned *s_tn, *s_qn, *s_unsorted;
   unsigned *bm;                          // candidate-block bits of this tile: D_BMW words (2 * D_BMW: two-bit map)
   unsigned *hist;                        // requests of this workgroup per bucket (D_HB bins), for the look-up chain's partition
 };
@@ -200,14 +202,14 @@ struct DShared                            // the workgroup's LDS arrays (pointer
 // The 12 one-away tests of a thread (distances 1..3; entries 4..6 are the right neighbour's 0..2), aggregated on the
 // fly.  Straight-line code: every test is a handful of instructions whose result mask dies at once.
 template <typename WT, bool ODD, bool CHECK> SMG_DEV void
-d_tests(const WT (&sx)[7], const unsigned (&cn)[4], const u64 (&Sm)[7], const GeoR &G,
+d_tests(const WT (&sx)[4 + D_RD], const unsigned (&cn)[4], const u64 (&Sm)[4 + D_RD], const GeoR &G,
         unsigned (&code)[4], unsigned (&npair)[4], u64 (&midM)[4])
 { const WT AA = (WT) 0xAAAAAAAAAAAAAAAAull;
-  unsigned cx[7] = { cn[0], cn[1], cn[2], cn[3], 0, 0, 0 };
+  unsigned cx[8] = { cn[0], cn[1], cn[2], cn[3], 0, 0, 0, 0 };
   if (CHECK)
     {
 #pragma unroll
-      for (int e = 0; e < 3; e++) cx[4 + e] = d_next(cn[e]);
+      for (int e = 0; e < D_RD; e++) cx[4 + e] = d_next(cn[e]);
     }
   // odd k: a pair sits on the self-mirrored position (the top suffix base) iff the one differing 2-bit group is the
   // top one: tt >= TOPB (one more compare per test; keeping "top bases of e and e+1 differ" masks instead costs
@@ -217,7 +219,7 @@ d_tests(const WT (&sx)[7], const unsigned (&cn)[4], const u64 (&Sm)[7], const Ge
   for (int a = 3; a >= 0; a--)               // descending: the neighbour's masks (indices 4..6) die first
     {
 #pragma unroll
-      for (int d = 1; d <= 3; d++)
+      for (int d = 1; d <= D_RD; d++)
         { const int b = a + d, eb = b & 3;
           const WT dd = sx[a] ^ sx[b];
           const WT tt = ((dd << 1) | dd) & AA;
@@ -270,8 +272,7 @@ SMG_DEV bool d_code_uq(unsigned c) { return ((c & 63u) - 1u) < 62u && c < 128u; 
 // One tile.  INNER tiles lie completely inside the table: vector loads, no bounds checks, no table-end cases.
 // RW = 64-bit words per request record: W (the complement k-mer) or W + 1 (+ count | has-hi-pair << 16).
 template <int W, int RW, bool ODD, bool KF, bool INNER> SMG_DEV void
-d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64 &fa, u64 &fb,
-       unsigned &bigmask, DPrefetch<W> &pf)
+d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64 &fa, u64 &fb, DPrefetch<W> &pf)
 { typedef typename DWord<W>::type WT;
   constexpr bool D_BM = (W == 1 && RW == 1) || (W == 2 && RW == 3);     // variants that feed the request filter
   const GeoR &G = A.G;
@@ -282,7 +283,6 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
   const u64 scanM = 0x7FFFFFFFFFFFFFFEull;                   // lanes 1..62
   const u64 ownM = wv == 0 ? scanM & ~((1ull << (D_LEAD / 4)) - 1ull) : scanM;
   const bool owned = d_lane(ownM);
-  bigmask = 0;
 
   // ---- loads ----------------------------------------------------------------------------------------------
   //@mark D_LOAD
@@ -307,7 +307,8 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
           cn[e] = ok ? (unsigned) A.cnt[i] : 0xFFFFu;
         }
     }
-  // LDS copy for the tail loop (halo lanes store what their twin in the neighbouring wave stores)
+  // LDS copy: the complement loop re-reads the thread's own entries from it (cheaper than four live registers), the
+  // dense block-map loop after the tile reads the candidates' k-mers
   if constexpr (W == 1)
     { ulonglong2 w0, w1;
       w0.x = kk[0].w[0]; w0.y = kk[1].w[0]; w1.x = kk[2].w[0]; w1.y = kk[3].w[0];
@@ -326,12 +327,12 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
                                                            (unsigned short) cn[2], (unsigned short) cn[3]);
 
   //@mark D_UNPACK
-  WT pre[4], sx[7];                        // sx[4..6]: the suffixes of the right neighbour's entries 0..2
+  WT pre[4], sx[4 + D_RD];                 // sx[4..]: the suffixes of the right neighbour's entries 0..D_RD-1
 #pragma unroll
   for (int e = 0; e < 4; e++) d_unpack<W, KF>(kk[e], G, pre[e], sx[e]);
   const WT npre0 = d_next(pre[0]);
 #pragma unroll
-  for (int e = 0; e < 3; e++) sx[4 + e] = d_next(sx[e]);
+  for (int e = 0; e < D_RD; e++) sx[4 + e] = d_next(sx[e]);
 
   // entry e exists (edge tiles only; V[4..6] are the neighbour's)
   u64 V[7];
@@ -399,7 +400,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
   //@mark D_MASKS
   D_FENCE_P();
   // Sm[e]: entries e and e+1 share their first p0 bases (e = 4..6: the neighbour's 0..2)
-  u64 Sm[7];
+  u64 Sm[4 + D_RD];
 #pragma unroll
   for (int e = 0; e < 3; e++) Sm[e] = __ballot(pre[e] == pre[e + 1]);
   Sm[3] = __ballot(pre[3] == npre0);
@@ -408,15 +409,14 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
 #pragma unroll
       for (int e = 0; e < 4; e++) Sm[e] &= V[e] & V[e + 1];
     }
-  Sm[4] = Sm[0] >> 1; Sm[5] = Sm[1] >> 1; Sm[6] = Sm[2] >> 1;
+#pragma unroll
+  for (int e = 0; e < D_RD; e++) Sm[4 + e] = Sm[e] >> 1;
 
-  // entries whose block continues past distance 3: tail items (scanned lanes only)
+  // entries whose block continues past distance 3: deferred (their owner queues their slot)
   if (!(D_ABL & 32))
     { u64 Al[4];
 #pragma unroll
-      for (int e = 0; e < 4; e++) Al[e] = Sm[e] & Sm[e + 1] & Sm[e + 2] & Sm[e + 3] & scanM;
-      // one queue entry per ENTRY (its slot), so that the tail runs with every lane busy: a wave pays for the whole
-      // tail body whenever one of its lanes has work
+      for (int e = 0; e < 4; e++) Al[e] = Sm[e] & Sm[e + 1] & Sm[e + 2] & Sm[e + 3] & ownM;
       const unsigned na = (unsigned) (__popcll(Al[0]) + __popcll(Al[1]) + __popcll(Al[2]) + __popcll(Al[3]));
       if (na)
         { unsigned base = 0;
@@ -432,11 +432,6 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
             }
         }
     }
-
-  // The staged copy and the tail queue are complete for every wave from here on.  The tail itself runs at the END of
-  // this phase, without a barrier of its own: between two barriers every wave has the same long stretch of work (tests,
-  // fingerprints, requests) plus its share of the tail items, instead of three waves idling while one walks the queue.
-  if (!(D_ABL & 1024)) lds_barrier();
 
   // ---- the 12 one-away tests of a thread (distances 1..3), aggregated on the fly -----------------------------
   //@mark D_TESTS
@@ -472,10 +467,6 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
   //@mark D_BMAP
   D_FENCE_P();
   // word 0 of the tile's LDS bit map = the map word of the tile's first owned entry (a uniform, scalar load)
-#if D_CANDQ
-  // (the candidates are queued at the end of the merge, from the final code bytes, and marked after the tile: D_FLUSH)
-  const uint32_t bmbase = 0u; (void) bmbase;
-#else
   const uint32_t bmbase = D_BM ? (((uint32_t) (A.keys[(g0 + D_LEAD) * W] >> 32) >> bmsh) & ~31u) : 0u;
   if (D_BM && A.bmap && !(D_ABL & 8))
     { // leading word of the thread's own entries, back from the staged copy (cheaper than four registers kept alive
@@ -526,7 +517,6 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
             }
         }
     }
-#endif
 
   // ---- complement, fingerprint, requests ---------------------------------------------------------------------------
   unsigned codes = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
@@ -535,11 +525,13 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
   //@mark D_RC
   D_FENCE_P();
   if (!(D_ABL & 16) || A.want_fp())
-    { // hash proof: rc(x) of every owned entry that owns a pair at p > k-1-p.  (The tail can only ADD pairs: an entry
-      // that gets its first hi-side pair there sends late, below.  The exact proof sends everything after the tail.)
+    { // hash proof: rc(x) of every owned entry that owns a pair at p > k-1-p; exact proof: of every owned entry, with
+      // that flag.  (A deferred entry that turns out to own more pairs than the register scan saw sends again from
+      // kf_bigfix: the flag of a request is only ever ORed into its target.)
       u64 E0 = 0, E1 = 0, E2 = 0, E3 = 0;
-      if (!A.emit_all() && !(D_ABL & 16))
-        { E0 = hiM[0] & ownM; E1 = hiM[1] & ownM; E2 = hiM[2] & ownM; E3 = hiM[3] & ownM;
+      if (!(D_ABL & 16))
+        { const u64 all = A.emit_all() ? ~0ull : 0ull;
+          E0 = (hiM[0] | all) & ownM; E1 = (hiM[1] | all) & ownM; E2 = (hiM[2] | all) & ownM; E3 = (hiM[3] | all) & ownM;
           if (!INNER) { E0 &= V[0]; E1 &= V[1]; E2 &= V[2]; E3 &= V[3]; }
         }
       const unsigned cnt_w = (unsigned) (__popcll(E0) + __popcll(E1) + __popcll(E2) + __popcll(E3));
@@ -602,173 +594,70 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
                 { const unsigned q = __builtin_amdgcn_mbcnt_hi((unsigned) (E0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) E0, base));
 #pragma unroll
                   for (int w = 0; w < W; w++) S.sq[q * RW + w] = rc.w[w];
-                  if (RW > W) S.sq[q * RW + W] = (u64) c | (1ull << 16);     // (hash proof: only hi entries send)
+                  if (RW > W) S.sq[q * RW + W] = (u64) c | (d_lane(hiM[e]) ? 1ull << 16 : 0ull);
                 }
               base += (unsigned) __popcll(E0);
             }
         }
     }
   // the next tile's entries: issued here, used after the flush -- the latency of the loads (a few thousand cycles on a
-  // busy chip) disappears behind the tail, the merge and the barriers instead of stalling the head of the next tile
+  // busy chip) disappears behind the flush phase and the barriers instead of stalling the head of the next tile
   pf.valid = false;
   if (g0_next >= 0) { pf.load(A.keys, A.cnt, g0_next + slot0); pf.valid = true; }
 
-  //@mark D_TAIL
-  // ---- tail: distances 4..30 from the LDS copy (global memory past the staged range); rare --------------------
-  // One lane per queued entry, the partners at distances 4..7 fetched in ONE batch (a loop that walked the partners
-  // one LDS round trip at a time cost 5.6 of 19.4 ms; four sparsely filled waves instead of one or two dense ones 3).
-  { const unsigned tn = *S.s_tn;
-    for (unsigned q = (unsigned) t; q < tn && !(D_ABL & 512); q += D_TPB)
-      { const int sa = (int) S.tailq[q];
-        WT pa, sfa;
-        d_unpack<W, KF>(lds_key<W>(S.ent, sa), G, pa, sfa);
-        const unsigned ca = S.lcn[sa];
-        int d = 4;
-        bool done = false;
-#pragma unroll
-        for (int base = 4; base <= D_TAILB; base += 4)           // distances 4..7 (and 8..11), each fetched as ONE batch
-          { if (done || sa + base + 3 >= D_SLOTS) break;          // (not staged: the loop below reads global memory)
-            Key<W> kb[4]; unsigned cb[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) { kb[j] = lds_key<W>(S.ent, sa + base + j); cb[j] = S.lcn[sa + base + j]; }
-            bool same = true;                   // (the entry at distance 4 shares the prefix: that is why sa is queued)
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-              { WT pb, sfb;
-                d_unpack<W, KF>(kb[j], G, pb, sfb);
-                same = same && pb == pa && (INNER || g0 + sa + base + j < n);
-                const WT dd = sfa ^ sfb;
-                const WT tt = ((dd << 1) | dd) & (WT) 0xAAAAAAAAAAAAAAAAull;
-                if (same && d_popc(tt) == 1 && ca + cb[j] <= SMG_SMAX)
-                  { unsigned v = 1u | ((unsigned) (31 + base + j) << 8);
-                    if (ODD) v += (unsigned) (dd >> G.mshift) << 24;
-                    atomicAdd(&S.cred[sa], v);
-                    atomicAdd(&S.cred[sa + base + j], v - ((unsigned) (2 * (base + j)) << 8));
-                  }
-              }
-            d = base + 4;
-            if (!same || (D_ABL & 256)) done = true;
-          }
-        if (done) continue;
-        for (; d <= D_WIN + 1; d++)             // longer blocks, and entries next to the end of the staged range
-          { const int sb = sa + d;
-            WT pb, sfb; unsigned cb;
-            if (!INNER && g0 + sb >= n) break;
-            if (sb < D_SLOTS) { d_unpack<W, KF>(lds_key<W>(S.ent, sb), G, pb, sfb); cb = S.lcn[sb]; }
-            else              { d_unpack<W, KF>(load_key<W>(A.keys, g0 + sb), G, pb, sfb); cb = A.cnt[g0 + sb]; }
-            if (pb != pa) break;
-            if (d > D_WIN) { atomicOr(&S.cred[sa], D_BIG); atomicOr(&S.cred[sb], D_BIG); break; }
-            const WT dd = sfa ^ sfb;
-            const WT tt = ((dd << 1) | dd) & (WT) 0xAAAAAAAAAAAAAAAAull;
-            if (d_popc(tt) == 1 && ca + cb <= SMG_SMAX)
-              { // count 1 | delta code << 8 | mid << 24: with exactly one pair the delta field IS the code byte
-                unsigned v = 1u | ((unsigned) (31 + d) << 8);
-                if (ODD) v += (unsigned) (dd >> G.mshift) << 24;
-                atomicAdd(&S.cred[sa], v);
-                atomicAdd(&S.cred[sb], v - ((unsigned) (2 * d) << 8));
-              }
-          }
-      }
-  }
-  if (!(D_ABL & 2048)) lds_barrier();
-
-  // ---- merge the tail's hand-overs (rare: a wave-uniform branch per entry), store the code bytes ------------------
-  //@mark D_MERGE
-  D_FENCE_P();
-  { const uint4 rv = *reinterpret_cast<const uint4 *>(&S.cred[slot0]);
-    const unsigned R[4] = { rv.x, rv.y, rv.z, rv.w };
-    u64 VL[4] = { ~0ull, ~0ull, ~0ull, ~0ull };
-    if (!INNER)
-      {
-#pragma unroll
-        for (int e = 0; e < 4; e++) VL[e] = __ballot((vmask >> e) & 1u);
-      }
-#pragma unroll
-    for (int e = 0; e < 4; e++)
-      { const u64 tM = __ballot(R[e] != 0u) & ownM & VL[e];
-        if (tM && !(D_ABL & 16384))
-          { const bool touched = d_lane(tM);
-            const unsigned oc = (codes >> (8 * e)) & 0xFFu;
-            const unsigned cnt_t = R[e] & 0xFFu;
-            const bool big = (R[e] & D_BIG) != 0u;
-            const bool w2 = !ODD || ((R[e] >> 24) & 0x7Fu) == 0u;
-            unsigned nc = ((oc & 63u) != 0u || cnt_t >= 2u) ? (unsigned) CODE_MULTI
-                                                          : (((R[e] >> 8) & 0x7Fu) | (w2 ? (unsigned) CODE_W2 : 0u));
-            if (cnt_t == 0u) nc = oc;                                                // BIG flag only
-            if (big) nc = CODE_DEFER;
-            if (touched)
-              { codes = (codes & ~(0xFFu << (8 * e))) | (nc << (8 * e));
-                if (big) { bigmask |= 1u << e; atomicAdd(S.s_nbig, 1u); }
-#if !D_CANDQ
-                if (D_BM && A.bmap && d_code_uq(nc) && !d_code_uq(oc))              // a candidate only now
-                  { const u64 kw0 = S.ent[(slot0 + e) * W];
-                    const uint32_t id = (uint32_t) (kw0 >> 32) >> bmsh;
-                    const uint32_t rel = id - bmbase;
-                    if (A.two())
-                      { const u64 v = bm2_bits(id, (uint32_t) kw0);
-                        if (rel < D_BMF) atomicOr(reinterpret_cast<u64 *>(S.bm) + (rel >> 5), v);
-                        else atomicOr(reinterpret_cast<u64 *>(A.bmap) + (id >> 5), v);
-                      }
-                    else if (rel < D_BMF) atomicOr(&S.bm[rel >> 5], 1u << (rel & 31));
-                    else atomicOr(&A.bmap[id >> 5], 1u << (id & 31));
-                  }
-#endif
-                if (!A.emit_all() && d_code_hi(nc) && !d_code_hi(oc) && !(D_ABL & 16))  // its first hi-side pair: send late
-                  { const Key<W> x = lds_key<W>(S.ent, slot0 + e);
-                    const Key<W> r = revcomp<W>(x, G.k);
-                    const unsigned q = atomicAdd(S.s_qn, 1u);
-#pragma unroll
-                    for (int w = 0; w < W; w++) S.sq[q * RW + w] = r.w[w];
-                    if (RW > W) S.sq[q * RW + W] = (u64) S.lcn[slot0 + e] | (1ull << 16);
-                  }
-              }
-          }
-      }
-#if D_CANDQ
-    // ---- request filter: the CANDIDATES of this tile (final code: exactly one suffix-side pair) queue their slots ----
-    // The tail queue is dead by now: its array holds the candidate queue.  Found on the packed code word: low six bits
-    // 1..62 and bit 7 clear (d_code_uq; CODE_DEFER has all six set), one flag bit per byte.
-    if (D_BM && A.bmap && !(D_ABL & 8))
-      { const unsigned low6 = codes & 0x3F3F3F3Fu;
-        unsigned cm = ((low6 + 0x3F3F3F3Fu) >> 6) & ~((low6 + 0x01010101u) >> 6) & ~(codes >> 7) & 0x01010101u;
-        if (!INNER) cm &= (vmask & 1u) | ((vmask & 2u) << 7) | ((vmask & 4u) << 14) | ((vmask & 8u) << 21);
-        u64 C[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) C[e] = __ballot((cm >> (8 * e)) & 1u) & ownM;
-        const unsigned nc = (unsigned) (__popcll(C[0]) + __popcll(C[1]) + __popcll(C[2]) + __popcll(C[3]));
-        if (nc)
-          { unsigned base = 0;
-            if (lane == 0) base = atomicAdd(S.s_cn, nc);
-            base = (unsigned) __builtin_amdgcn_readfirstlane((int) base);
-#pragma unroll
-            for (int e = 0; e < 4; e++)
-              { if (d_lane(C[e]))
-                  S.tailq[__builtin_amdgcn_mbcnt_hi((unsigned) (C[e] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) C[e], base))] = (uint16_t) (slot0 + e);
-                base += (unsigned) __popcll(C[e]);
-              }
-          }
-      }
-#endif
-    if (owned)
-      { if (INNER || vmask == 0xF) *reinterpret_cast<unsigned *>(A.code + i0) = codes;
-        else
-          for (int e = 0; e < 4; e++)
-            if (vmask >> e & 1) A.code[i0 + e] = (uint8_t) (codes >> (8 * e));
-      }
-    // exact proof: every owned entry sends (rc(x), count | hi << 16), with the final hi flag
-    if (A.emit_all() && !(D_ABL & 16))
-      { Key<W> rc[4]; unsigned c2[4]; u64 E[4], hM[4];
-#pragma unroll
+  //@mark D_STORE
+  if (owned)
+    { if (INNER || vmask == 0xF) *reinterpret_cast<unsigned *>(A.code + i0) = codes;
+      else
         for (int e = 0; e < 4; e++)
-          { const unsigned ce = (codes >> (8 * e)) & 0xFFu;
-            rc[e] = revcomp<W>(lds_key<W>(S.ent, slot0 + e), G.k);
-            c2[e] = S.lcn[slot0 + e];
-            hM[e] = __ballot(d_code_hi(ce));
-            E[e] = ownM & VL[e] & ~__ballot(ce == (unsigned) CODE_DEFER);        // deferred entries send from kf_bigfix
-          }
-        d_emit<W, RW>(S, E, rc, c2, hM, lane);
-      }
-  }
+          if (vmask >> e & 1) A.code[i0 + e] = (uint8_t) (codes >> (8 * e));
+    }
+}
+
+// ---- deferred tail: does the entry in slot sa own a pair at distance 4..30, or does its block go on past 30? -------
+// hm: bit d - (D_RD + 1) set for a pair with the entry d slots on; big: the entry 31 slots on still shares the prefix (block
+// beyond the window: both are redone by bisection, as every entry of such a block is in one of these two roles).
+// Partners come from the staged copy (global memory past its end: the last few slots of a tile).
+template <int W, bool ODD, bool KF> SMG_DEV void
+d_detect(const P1Hot &A, const u64 *ent, const uint16_t *lcn, int64_t g0, int sa, unsigned &hm, bool &big)
+{ typedef typename DWord<W>::type WT;
+  const GeoR &G = A.G;
+  const int64_t n = A.n;
+  hm = 0; big = false;
+  WT pa, sfa;
+  d_unpack<W, KF>(lds_key<W>(ent, sa), G, pa, sfa);
+  const unsigned ca = lcn[sa];
+  constexpr int D0 = D_RD + 1;                      // first distance the register scan did not cover
+  int d = D0;
+  if (sa + D0 + D_TAILB <= D_SLOTS)                 // distances D0 .. D0 + D_TAILB - 1 in one batch of LDS reads
+    { Key<W> kb[D_TAILB]; unsigned cb[D_TAILB];
+#pragma unroll
+      for (int j = 0; j < D_TAILB; j++) { kb[j] = lds_key<W>(ent, sa + D0 + j); cb[j] = lcn[sa + D0 + j]; }
+      bool same = true;
+#pragma unroll
+      for (int j = 0; j < D_TAILB; j++)
+        { WT pb, sfb;
+          d_unpack<W, KF>(kb[j], G, pb, sfb);
+          same = same && g0 + sa + D0 + j < n && pb == pa;
+          const WT dd = sfa ^ sfb;
+          const WT tt = ((dd << 1) | dd) & (WT) 0xAAAAAAAAAAAAAAAAull;
+          if (same && d_popc(tt) == 1 && ca + cb[j] <= SMG_SMAX) hm |= 1u << j;
+        }
+      if (!same) return;
+      d = D0 + D_TAILB;
+    }
+  for (; d <= D_WIN + 1; d++)
+    { const int sb = sa + d;
+      if (g0 + sb >= n) break;
+      WT pb, sfb; unsigned cb;
+      if (sb < D_SLOTS) { d_unpack<W, KF>(lds_key<W>(ent, sb), G, pb, sfb); cb = lcn[sb]; }
+      else              { d_unpack<W, KF>(load_key<W>(A.keys, g0 + sb), G, pb, sfb); cb = A.cnt[g0 + sb]; }
+      if (pb != pa) break;
+      if (d > D_WIN) { big = true; break; }
+      const WT dd = sfa ^ sfb;
+      const WT tt = ((dd << 1) | dd) & (WT) 0xAAAAAAAAAAAAAAAAull;
+      if (d_popc(tt) == 1 && ca + cb <= SMG_SMAX) hm |= 1u << (d - D0);
+    }
 }
 
 #ifndef D_WAVES_W2
@@ -781,17 +670,15 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
 template <int W, int RW, bool ODD, bool KF> __global__ void __launch_bounds__(D_TPB)
 __attribute__((amdgpu_waves_per_eu(W == 2 ? D_WAVES_W2 : (RW == 1 ? D_WAVES_PER_EU : 5), W == 2 ? D_WAVES_W2 : (RW == 1 ? D_WAVES_PER_EU : 5))))
 kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
-{ __shared__ unsigned cred[D_CRED];      // tail hand-overs per entry: count | delta code << 8 | mid << 24 | BIG
-  __shared__ uint16_t tailq[D_SCAN];     // slots of the entries whose window block goes on past distance 3
+{ __shared__ uint16_t tailq[D_OWN + 8];   // deferred tail: slots of this tile's queued entries
   __shared__ u64      ent[D_SLOTS * W];  // the staged k-mers
   __shared__ uint16_t lcn[D_SLOTS];
   __shared__ u64      sq[(RW == 1 ? D_QCAP : D_OWN) * RW];
   __shared__ u64      sfp[D_TPB / 64][2];
   constexpr bool D_BM = (W == 1 && RW == 1) || (W == 2 && RW == 3);
   __shared__ __attribute__((aligned(16))) unsigned bm[D_BM ? 2 * D_BMW : 1];
-  __shared__ unsigned s_cn;
   __shared__ unsigned hist[(D_BM && W == 1) ? D_HB : 1];
-  __shared__ unsigned s_tn, s_qn, s_nbig, s_unsorted, s_chunk, s_used, s_bigbase, s_bigcur;
+  __shared__ unsigned s_tn[2], s_qn, s_unsorted, s_chunk, s_used;      // (s_tn: one counter per tile parity)
   __shared__ u64      s_base, s_total;
 
   const int t = threadIdx.x;
@@ -800,49 +687,33 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
   const int64_t n = A.n;
   u64 fa = 0, fb = 0;                      // fingerprint: XOR of the entries' 128-bit terms
   DShared S;
-  S.cred = cred; S.tailq = tailq; S.ent = ent; S.lcn = lcn; S.sq = sq;
-  S.s_tn = &s_tn; S.s_qn = &s_qn; S.s_nbig = &s_nbig; S.s_unsorted = &s_unsorted;
-  S.bm = bm; S.hist = hist; S.s_cn = &s_cn;
+  S.tailq = tailq; S.ent = ent; S.lcn = lcn; S.sq = sq;
+  S.s_tn = &s_tn[0]; S.s_qn = &s_qn; S.s_unsorted = &s_unsorted;
+  S.bm = bm; S.hist = hist;
   if (D_BM) for (int w = t; w < 2 * D_BMW; w += D_TPB) bm[w] = 0;
   if (D_BM && W == 1) for (int w = t; w < D_HB; w += D_TPB) hist[w] = 0;
-  for (int s = t; s < D_CRED; s += D_TPB) cred[s] = 0;
-  if (t == 0) { s_chunk = F_NOCHUNK; s_used = 0; s_total = 0; s_tn = 0; s_qn = 0; s_nbig = 0; s_unsorted = 0; s_cn = 0; }
+  if (t == 0) { s_chunk = F_NOCHUNK; s_used = 0; s_total = 0; s_tn[0] = 0; s_tn[1] = 0; s_qn = 0; s_unsorted = 0; }
   lds_barrier();
+  (void) lane; (void) slot0; (void) n;
 
   DPrefetch<W> pf;
   pf.valid = false;
-  for (int64_t tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x)
+  int par = 0;
+  for (int64_t tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x, par ^= 1)
     { const int64_t g0 = tile * D_OWN - D_LEAD;
+      S.s_tn = &s_tn[par];
       // the tile after this one, if it is an inner tile too (-1: none, or an edge tile, which loads for itself)
       int64_t g0n = g0 + (int64_t) gridDim.x * D_OWN;
       if (tile + gridDim.x >= A.ntiles || g0n + D_SLOTS + 32 > n) g0n = -1;
-      unsigned bigmask;
       if (g0 >= 0 && g0 + D_SLOTS + 32 <= n)
-        d_tile<W, RW, ODD, KF, true>(A, S, g0, g0n, t, fa, fb, bigmask, pf);
+        d_tile<W, RW, ODD, KF, true>(A, S, g0, g0n, t, fa, fb, pf);
       else
-        d_tile<W, RW, ODD, KF, false>(A, S, g0, g0n, t, fa, fb, bigmask, pf);
-      if (!(D_ABL & 4096)) lds_barrier();
+        d_tile<W, RW, ODD, KF, false>(A, S, g0, g0n, t, fa, fb, pf);
+      if (!(D_ABL & 4096)) lds_barrier();          // the staged copy and the queues of this tile are complete
       //@mark D_FLUSH
-#if D_CANDQ
-      if (D_BM && A.bmap)                           // this tile's candidates -> bits of the tile's LDS window: one lane per candidate
-        { const unsigned cn = s_cn;
-          const int bmsh = A.bmsh();
-          const uint32_t bmbase = ((uint32_t) (ent[D_LEAD * W] >> 32) >> bmsh) & ~31u;
-          for (unsigned q = t; q < cn; q += D_TPB)
-            { const u64 kw = ent[(unsigned) tailq[q] * W];
-              const uint32_t id = (uint32_t) (kw >> 32) >> bmsh;
-              const uint32_t rel = id - bmbase;
-              if (A.two())
-                { const u64 v = bm2_bits(id, (uint32_t) kw);
-                  if (rel < D_BMF) atomicOr(reinterpret_cast<u64 *>(bm) + (rel >> 5), v);
-                  else atomicOr(reinterpret_cast<u64 *>(A.bmap) + (id >> 5), v);           // (sparse table: outside the window)
-                }
-              else if (rel < D_BMF) atomicOr(&bm[rel >> 5], 1u << (rel & 31));
-              else atomicOr(&A.bmap[id >> 5], 1u << (id & 31));
-            }
-          lds_barrier();
-        }
-#endif
+      const bool last = tile + gridDim.x >= A.ntiles;
+      const unsigned tn = s_tn[par];               // (zeroed again behind the barrier at the end of this iteration: the
+      const unsigned qn = s_qn;                    //  next tile counts in the other one)
       if (D_BM && A.bmap)                           // candidate-block bits of this tile -> global map
         { const int two = A.two() ? 1 : 0;          // (two-bit map: twice the words, at twice the word offset)
           for (int w = t; w < (D_BMW << two); w += D_TPB)
@@ -853,16 +724,31 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
                 }
             }
         }
-      // zero the hand-over words for the next tile (every thread its own four; the tail past the staged range)
-      *reinterpret_cast<uint4 *>(&cred[slot0]) = make_uint4(0, 0, 0, 0);
-      if (t < (D_CRED - D_SLOTS) / 4) *reinterpret_cast<uint4 *>(&cred[D_SLOTS + 4 * t]) = make_uint4(0, 0, 0, 0);
 
-      // ---- flush the request queue into this workgroup's chunk; publish deferred entries -----------------
+      // ---- deferred tail: one dense detection pass over this tile's queued entries (a lane each) ---------------------
+      // A hit sets the bits of the entry and of its partners in the deferred-entry map (one bit per table entry, so an
+      // entry named twice is redone once).
+      for (unsigned q = t; q < tn && !(D_ABL & 512); q += D_TPB)
+        { const int sa = (int) tailq[q];
+          unsigned hm; bool big;
+          d_detect<W, ODD, KF>(A, ent, lcn, g0, sa, hm, big);
+          if (hm | (unsigned) big)                           // rare: mark the entry and its partners for kf_bigfix
+            { uint32_t *db = cold->dbits;
+              const int64_t it = g0 + sa;
+              atomicOr(&db[it >> 5], 1u << (it & 31));
+              for (unsigned m = hm; m; m &= m - 1)
+                { const int64_t j = it + D_RD + __ffs(m);
+                  atomicOr(&db[j >> 5], 1u << (j & 31));
+                }
+              if (big) { const int64_t j = it + D_WIN + 1; atomicOr(&db[j >> 5], 1u << (j & 31)); }
+            }
+        }
+
+      // ---- flush the request queue into this workgroup's chunk -------------------------------------------------------
       // (RW == 1: only when the next tile might overflow the queue, or after this workgroup's last tile --
       //  the barriers and the chunk bookkeeping of a flush cost as much as the copy itself)
-      const unsigned qn = s_qn;
       const unsigned qcap = RW == 1 ? D_QCAP : D_OWN;
-      if (qn > 0 && (qn + D_OWN > qcap || tile + gridDim.x >= A.ntiles))
+      if (qn > 0 && (qn + D_OWN > qcap || last))
         { // a batch that does not fit is SPLIT: its head fills the current chunk to the brim, the rest opens a new
           // one -- every chunk but a workgroup's last is full, so the host can sort the chunk array as it is
           // (holes filled with a sentinel) instead of compacting it first
@@ -899,20 +785,8 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
               for (unsigned e = t; e < (qn - head) * RW; e += D_TPB) o[e] = sq[head * RW + e];
             }
         }
-      const unsigned nb = s_nbig;
-      if (nb > 0)                                   // rare: list the deferred entries (the k-mer copy is free now)
-        { uint32_t *list = reinterpret_cast<uint32_t *>(ent);
-          lds_barrier();
-          if (t == 0) { s_bigbase = atomicAdd(&cold->ctl->nbig, nb); s_nbig = 0; s_bigcur = 0; }
-          lds_barrier();
-          for (unsigned m = bigmask; m; m &= m - 1)
-            list[atomicAdd(&s_bigcur, 1u)] = (uint32_t) (g0 + slot0 + __ffs(m) - 1);
-          lds_barrier();
-          for (unsigned e = t; e < nb; e += D_TPB)
-            if (s_bigbase + e < cold->big_cap) cold->biglist[s_bigbase + e] = list[e];
-        }
-      if (t == 0) { s_tn = 0; s_cn = 0; }
       if (!(D_ABL & 8192)) lds_barrier();
+      if (t == 0) s_tn[par] = 0;
     }
 
   if (D_BM && W == 1 && A.hbits())                   // this workgroup's row of the request histogram (kl_tot / kl_woff)

@@ -50,6 +50,7 @@ class TorchEngine:
 
     def bind(self, k, keys, counts):
         self._keep = (keys, counts)
+        self.words = (k + 31) // 32
         self.e.bind(k, counts.numel(), keys.data_ptr(), counts.data_ptr())
 
     def pass1(self, symcheck, exchange=True):
@@ -94,6 +95,22 @@ class TorchEngine:
 
     def symhash(self):
         return self.e.symhash()
+
+    # ---- conditioning across shards (condition_sharded) ----
+    def trim(self, ethresh):
+        return self.e.condition(ethresh, True, False)
+
+    def symm_hist(self, bits):
+        return self.e.symm_hist(bits)
+
+    def symm_route(self, splitters, nranks, send):
+        return self.e.symm_route(splitters, nranks, send.data_ptr(), send.numel() // (self.words + 1))
+
+    def symm_finish(self, recv, nrecv):
+        return self.e.symm_finish(recv.data_ptr(), nrecv)
+
+    def nels(self):
+        return self.e.table()[0]
 
     def pass2(self, plot):
         self.e.pass2(plot.data_ptr())
@@ -171,8 +188,73 @@ def _general_on_rank0(k, keys, counts, sizes, eng, plot, group, rank, world, wor
         dist.broadcast(plot, src=0, group=group)
 
 
+def symm_splitters(hist: np.ndarray, bits: int, world: int, words: int) -> np.ndarray:
+    """Balanced splitters for the CLOSED table from the summed histogram of smg_engine_symm_hist (entries, then
+    complements, per leading `bits` k-mer bits): rank r starts at the first bin in front of which the closed table
+    holds r / world of its entries; a rank for which nothing is left gets the all-ones k-mer.  The same rule as the
+    in-process driver (smg_multi.hpp)."""
+    nb = 1 << bits
+    tot = hist[:nb].astype(np.int64) + hist[nb:].astype(np.int64)
+    before = np.concatenate([[0], np.cumsum(tot)[:-1]])
+    total = int(tot.sum())
+    out = np.zeros((max(world - 1, 0), words), dtype=np.uint64)
+    for r in range(1, world):
+        b = int(np.searchsorted(before, (total // world) * r, side="left"))
+        if b >= nb:
+            out[r - 1, :] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        else:
+            out[r - 1, 0] = np.uint64(b) << np.uint64(64 - bits)
+    return out.reshape(-1)
+
+
+def condition_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, ethresh: int = 0, trim: bool = False,
+                      symm: bool = True, engine_factory=TorchEngine, group=None, eng=None):
+    """Condition a table that is spread over the ranks (any cut between k-mers will do: the entries are dealt out
+    again): drop the entries below `ethresh` (Logex 'A[e-]') and / or close the table under reverse complement
+    (Symmex) -- what the reference shells out for, PloidyPlot.c:1381-1414, without a size limit.  Collective.
+
+    Returns (eng, splitters): the engine OWNS this rank's shard of the conditioned table afterwards (sorted, one
+    entry per k-mer, ranges given by `splitters`); hand both to hetmers_sharded(k, None, None, eng=eng,
+    splitters=splitters)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    dev = keys.device
+    words = (k + 31) // 32
+    rw = words + 1
+    if eng is None:
+        eng = engine_factory(dev)
+    eng.bind(k, keys, counts)
+    n = counts.numel()
+    if trim:
+        n = eng.trim(ethresh)
+    if not symm:
+        raise ValueError("condition_sharded(symm=False): trim a closed table with the engine's own condition()")
+    bits = max(2, min(12, 2 * (k // 2)))
+    hist = torch.from_numpy(eng.symm_hist(bits).astype(np.int64)).to(dev)
+    if world > 1:
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
+    splitters = symm_splitters(hist.cpu().numpy(), bits, world, words)
+    send = torch.empty(max(2 * n, 1) * rw, dtype=torch.int64, device=dev)
+    send_counts = eng.symm_route(splitters, world, send)
+    if world > 1:
+        sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
+        rcnt = torch.empty_like(sc)
+        dist.all_to_all_single(rcnt, sc, group=group)
+        recv_counts = [int(v) for v in rcnt.cpu().tolist()]
+        nrecv = sum(recv_counts)
+        recv = torch.empty(max(nrecv, 1) * rw, dtype=torch.int64, device=dev)
+        dist.all_to_all_single(recv[: nrecv * rw], send[: 2 * n * rw],
+                               output_split_sizes=[c * rw for c in recv_counts],
+                               input_split_sizes=[c * rw for c in send_counts], group=group)
+    else:
+        recv, nrecv = send, 2 * n
+    eng.symm_finish(recv, nrecv)
+    eng._splitter_cache = None
+    return eng, splitters
+
+
 def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: str = "hash",
-                    engine_factory=TorchEngine, group=None, eng=None, fallback: bool = True):
+                    engine_factory=TorchEngine, group=None, eng=None, fallback: bool = True, splitters=None):
     """Run hetmers on this rank's shard; returns (plot int64[1001*501] on the shard's device,
     summed over all ranks, and a stats dict).  Collective: every rank must call it.
 
@@ -182,25 +264,35 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
              allocation is set-up cost, not part of a step)
     fallback: a table that fails the symmetry proof is collected on rank 0 and run through the general path
              (False: raise NotSymmetric instead)
+    keys = counts = None with `eng` and `splitters` from condition_sharded: the engine owns the shard already
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     # SMG_FORCE_EXCHANGE=1 (tests): run the collectives of the exchange even in a one-rank group, so that the
     # real backend (RCCL) sees every call of the multi-rank protocol on a single-GPU box
     exchange = world > 1 or (dist.is_initialized() and os.environ.get("SMG_FORCE_EXCHANGE") == "1")
-    dev = keys.device
     words = (k + 31) // 32
-    n = counts.numel()
-
-    if eng is None:
-        eng = engine_factory(dev)
-    eng.bind(k, keys, counts)
+    owned = keys is None
+    if owned:
+        if eng is None or splitters is None:
+            raise ValueError("hetmers_sharded without a table needs the engine and the splitters of condition_sharded")
+        dev = eng.device
+        n = eng.nels()
+        fallback = False                      # (a table this module closed itself cannot fail the proof)
+    else:
+        dev = keys.device
+        n = counts.numel()
+        if eng is None:
+            eng = engine_factory(dev)
+        eng.bind(k, keys, counts)
 
     # splitters = first k-mer of ranks 1..world-1 (an empty shard inherits its successor's).  They depend
     # on the table only: an engine that is reused on the same shard (bench.py) keeps them.
-    tag = (keys.data_ptr(), n, world, rank)
+    tag = (0 if owned else keys.data_ptr(), n, world, rank)
     cached = getattr(eng, "_splitter_cache", None)
-    if cached is not None and cached[0] == tag:
+    if splitters is not None:
+        splitters, sizes = np.ascontiguousarray(splitters, dtype=np.uint64).reshape(-1), None
+    elif cached is not None and cached[0] == tag:
         splitters, sizes = cached[1], cached[2]
     elif exchange:
         first = torch.full((words,), -1, dtype=torch.int64, device=dev)       # all ones = +inf
@@ -221,7 +313,7 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
     else:
         splitters, sizes = np.zeros(0, np.uint64), [n]
 
-    eng.pass1(symcheck, exchange) if engine_factory is TorchEngine or isinstance(eng, TorchEngine) else eng.pass1(symcheck)
+    eng.pass1(symcheck, exchange)
     rw = eng.record_words()
     nreq = eng.nreq()
 

@@ -62,7 +62,58 @@ class NumpyEngine:
     def record_words(self):
         return self.W + 1
 
-    def pass1(self, symcheck):
+    # ---- conditioning across shards (sharded.condition_sharded) --------------------------------------------
+    def nels(self):
+        return self.n
+
+    def trim(self, ethresh):
+        keep = self.cnt >= ethresh
+        self.keys, self.cnt = self.keys[keep], self.cnt[keep]
+        self.n = len(self.cnt)
+        return self.n
+
+    def symm_hist(self, bits):
+        h = np.zeros(2 << bits, dtype=np.int64)
+        sh = 64 * self.W - bits
+        for x in self.keys:
+            h[x >> sh] += 1
+            h[(1 << bits) + (self._rc(x) >> sh)] += 1
+        return h
+
+    def symm_route(self, splitters, nranks, send):
+        """two records per entry (itself; its complement with bit 16 of the count word), grouped by destination"""
+        sp = list(self._ints(np.asarray(splitters, dtype=np.uint64))) if len(splitters) else []
+        rec = []
+        for x, c in zip(self.keys, self.cnt):
+            rec.append((x, int(c)))
+            rec.append((self._rc(x), int(c) | (1 << 16)))
+        dest = np.array([sum(1 for s_ in sp if t >= s_) for t, _ in rec], dtype=np.int64)
+        out = []
+        for r in range(nranks):
+            for (t, m), d in zip(rec, dest):
+                if d == r:
+                    out.extend(self._words(t)); out.append(m)
+        if out:
+            send[: len(out)] = torch.from_numpy(np.array(out, dtype=np.uint64).view(np.int64))
+        return [int((dest == r).sum()) for r in range(nranks)]
+
+    def symm_finish(self, recv, nrecv):
+        rw = self.W + 1
+        rec = recv[: nrecv * rw].cpu().numpy().view(np.uint64).reshape(-1, rw)
+        best = {}
+        ks = self._ints(rec[:, : self.W].reshape(-1)) if len(rec) else []
+        for x, m in zip(ks, rec[:, self.W]):
+            m = int(m)
+            cur = best.get(x)
+            if cur is None or ((cur >> 16) & 1 and not (m >> 16) & 1):      # an entry beats a complement
+                best[x] = m
+        xs = sorted(best)
+        self.keys = np.array(xs, dtype=object)
+        self.cnt = np.array([best[x] & 0xFFFF for x in xs], dtype=np.int64)
+        self.n = len(xs)
+        return self.n
+
+    def pass1(self, symcheck, exchange=True):
         k, keys, cnt, n = self.k, self.keys, self.cnt, self.n
         bits = 64 * self.W
         p0 = k // 2

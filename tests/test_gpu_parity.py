@@ -361,6 +361,106 @@ def test_hetmers_on_raw_table_equals_reference_on_conditioned_table(k, tmp_path)
     assert (tmp_path / "gpu.smu").read_text() != ""
 
 
+# ---- conditioning across shards (row A0 beyond one shard: several GPUs, or more than 2^32 entries) -----------------
+
+def _golden_raw(name, L_extra=3):
+    """the canonical half of a golden table, some entries pushed below the threshold: what FastK would have written;
+    and the table a correct Logex + Symmex makes of it"""
+    g = load_golden(name)
+    k, L = g["k"], g["L"] + L_extra
+    packed, cnt = g["packed"], g["counts"]
+    rc = ktab.revcomp_packed(packed, k)
+    canon = np.array([bytes(a) <= bytes(b) for a, b in zip(packed, rc)])
+    rp, rcnt = packed[canon], cnt[canon].copy()
+    rng = np.random.default_rng(len(cnt))
+    low = rng.random(len(rcnt)) < 0.15
+    rcnt[low] = rng.integers(1, L, size=int(low.sum()))
+    keep = rcnt >= L
+    cp, cc = ktab.symmetrize(rp[keep], rcnt[keep], k)
+    return k, L, (rp, rcnt), (cp, cc)
+
+
+@pytest.mark.parametrize("shards", [2, 3, 7])
+@pytest.mark.parametrize("name", ["k31_i1", "k31_i3_p4", "k21_i2_p2", "k51_i1_p3", "k32_i1_p2", "k65_i1", "k17_i1"])
+def test_raw_table_is_trimmed_and_symmetrised_across_virtual_shards(name, shards, monkeypatch):
+    """PloidyPlot.c:1381-1414 conditions a table of any size.  Raw canonical table, cut into shards anywhere: every
+    shard trims, the shards exchange entries + complements (balanced splitters from the shape of the closed table),
+    sort, and run -- the plot must be the oracle's on the numpy-conditioned table."""
+    k, L, (rp, rcnt), (cp, cc) = _golden_raw(name)
+    want = brute.hetmers_plot(cp, cc, k)
+    assert want.sum() > 0
+    monkeypatch.setenv("SMG_VIRTUAL_SHARDS", str(shards))
+    for mode in ("hash", "exact"):
+        plot, st = engine.hetmers_run(table_from(rp, rcnt, k), symcheck=mode,
+                                      condition=engine.COND_TRIM | engine.COND_SYMM, ethresh=L)
+        assert st["path"] == 1, "a table closed by the engine must pass the symmetry proof"
+        assert st["nels"] == len(cc), (name, shards, mode)
+        assert np.array_equal(plot, want), (name, shards, mode)
+
+
+@pytest.mark.parametrize("name", ["k31_i1", "k51_i1_p3"])
+def test_raw_table_beyond_the_shard_limit_and_on_one_rank_rccl(name, monkeypatch, tmp_path):
+    """the same through the automatic shards of a table whose CLOSED size exceeds the shard limit (the 2^32-entry case
+    with the threshold lowered), through the RCCL calls with one rank, and through the executable with SMUDGEPLOT_GPUS
+    (which used to fall back to one GPU for a raw table): byte-identical .smu against the reference binary (or the C
+    oracle) on the conditioned table"""
+    from conftest import REF_BIN
+    k, L, (rp, rcnt), (cp, cc) = _golden_raw(name)
+    want = brute.hetmers_plot(cp, cc, k)
+    monkeypatch.setenv("SMG_SHARD_LIMIT", str(len(cc) // 3 + 1))          # closed size / 3: three or more shards
+    plot, st = engine.hetmers_run(table_from(rp, rcnt, k), symcheck="hash", condition=engine.COND_TRIM | engine.COND_SYMM, ethresh=L)
+    assert np.array_equal(plot, want) and st["nels"] == len(cc)
+    monkeypatch.delenv("SMG_SHARD_LIMIT")
+    monkeypatch.setenv("SMG_FORCE_MULTI", "1")
+    plot, st = engine.hetmers_run(table_from(rp, rcnt, k), symcheck="hash", condition=engine.COND_TRIM | engine.COND_SYMM, ethresh=L)
+    assert np.array_equal(plot, want) and st["nels"] == len(cc)
+    monkeypatch.delenv("SMG_FORCE_MULTI")
+    ktab.write_ktab(str(tmp_path / "raw"), k, rp, rcnt, ibyte=1, nparts=2)
+    ktab.write_ktab(str(tmp_path / "cond"), k, cp, cc, ibyte=1, nparts=2)
+    r = subprocess.run([HETMERS_BIN, f"-e{L}", "-T4", "-v", "-ogpu", "raw"], cwd=tmp_path, capture_output=True, text=True,
+                       env=dict(os.environ, SMUDGEPLOT_GPUS="3", SMG_VIRTUAL_SHARDS="3"))
+    assert r.returncode == 0, r.stderr
+    assert "  Making trimmed table symmetric\n" in r.stderr and "gpus=3" in r.stderr
+    if os.path.exists(REF_BIN):
+        q = subprocess.run([REF_BIN, f"-e{L}", "-T4", "-oref", "cond"], cwd=tmp_path, capture_output=True, text=True)
+        assert q.returncode == 0, q.stderr
+    else:
+        subprocess.run([ORACLE_BIN, f"-e{L}", f"-o{tmp_path}/ref", str(tmp_path / "cond")], check=True)
+    assert (tmp_path / "gpu.smu").read_text() == (tmp_path / "ref.smu").read_text() != ""
+
+
+@pytest.mark.parametrize("k,seed", [(31, 11), (40, 12), (70, 13)])
+def test_condition_sharded_driver_one_rank_and_engine_primitives(k, seed):
+    """sharded.condition_sharded on the real engine (one rank: symm_hist / symm_route / symm_finish without the
+    collectives), then hetmers_sharded on the table the engine owns; and the histogram of symm_hist against numpy"""
+    import torch
+    from smudgeplot_amd import sharded
+    L = 5
+    (rp, rcnt), (cp, cc) = _raw_table(k, seed, L)
+    want = brute.hetmers_plot(cp, cc, k)
+    W = (k + 31) // 32
+    buf = np.zeros((len(rcnt), 8 * W), dtype=np.uint8)
+    buf[:, : rp.shape[1]] = rp
+    keys = np.ascontiguousarray(buf.view(">u8").astype(np.uint64))
+    dev = torch.device("cuda:0")
+    tk = torch.from_numpy(keys.view(np.int64).reshape(-1).copy()).to(dev)
+    tc = torch.from_numpy(rcnt.view(np.int16).copy()).to(dev)
+    eng = sharded.TorchEngine(dev)
+    eng.bind(k, tk, tc)
+    bits = 8
+    h = eng.symm_hist(bits)
+    own = np.bincount((keys[:, 0] >> np.uint64(64 - bits)).astype(np.int64), minlength=1 << bits)
+    rcp = ktab.revcomp_packed(rp, k)
+    rcs = np.bincount(rcp[:, 0].astype(np.int64), minlength=1 << bits)
+    assert np.array_equal(h[: 1 << bits], own) and np.array_equal(h[1 << bits:], rcs)
+    eng2, split = sharded.condition_sharded(k, tk, tc, ethresh=L, trim=True, symm=True)
+    assert eng2.nels() == len(cc) and len(split) == 0
+    plot, st = sharded.hetmers_sharded(k, None, None, symcheck="hash", eng=eng2, splitters=split)
+    torch.cuda.synchronize()
+    assert st["path"] == 1
+    assert np.array_equal(plot.cpu().numpy().reshape(1001, 501), want)
+
+
 # ---- BASELINE config 3 at FULL size: size-independent properties (no CPU oracle finishes 2.5e9 entries) ----
 
 def _manual_sharded(k, tk, tc, cuts, dev, symcheck="hash"):

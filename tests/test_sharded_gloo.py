@@ -137,3 +137,81 @@ def test_two_and_three_word_kmers_through_the_sharded_driver(world, k, symcheck)
         assert status == "ok"
         assert np.array_equal(plot.reshape(1001, 501), want), f"rank {rank}"
     assert sum(r[3] for r in res) == sum(r[4] for r in res)
+
+
+# ---- conditioning across shards: raw canonical table in, every rank ends up with its range of the closed table ----
+
+def _cond_worker(rank, world, port, k, keys, cnt, cuts, L, q):
+    sys.path.insert(0, HERE)
+    from fake_engine import NumpyEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = cuts[rank], cuts[rank + 1]
+        tk = torch.from_numpy(np.ascontiguousarray(keys[lo:hi]).view(np.int64).reshape(-1).copy())
+        tc = torch.from_numpy(cnt[lo:hi].view(np.int16).copy())
+        eng, split = sharded.condition_sharded(k, tk, tc, ethresh=L, trim=True, symm=True, engine_factory=NumpyEngine)
+        shard = [int(x) for x in eng.keys]
+        plot, st = sharded.hetmers_sharded(k, None, None, symcheck="hash", eng=eng, splitters=split)
+        q.put((rank, "ok" if st["path"] == 1 else "general", plot.numpy().copy(), shard, [int(c) for c in eng.cnt]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,k", [(2, 31), (3, 31), (2, 21), (2, 51)])
+def test_raw_table_is_conditioned_across_the_ranks(world, k):
+    """PloidyPlot.c:1381-1414 hands a raw table of any size to Logex + Symmex.  Sharded: every rank trims its piece of
+    the RAW canonical table (cut anywhere), sends entries and complements to the rank that owns them, sorts what it
+    receives.  The union of the shards must be the numpy-conditioned table, entry for entry, and the plot the oracle's
+    on that table."""
+    L = 5
+    packed, cnt = synth.adversarial_table(k, 600, L, seed=300 + k + world, low_complexity=30, dense=1)
+    rc = ktab.revcomp_packed(packed, k)
+    canon = np.array([bytes(a) <= bytes(b) for a, b in zip(packed, rc)])
+    rp, rcnt = packed[canon], cnt[canon].copy()
+    rng = np.random.default_rng(k)
+    low = rng.random(len(rcnt)) < 0.2
+    rcnt[low] = rng.integers(1, L, size=int(low.sum()))
+    keep = rcnt >= L
+    cp, cc = ktab.symmetrize(rp[keep], rcnt[keep], k)
+    want = brute.hetmers_plot(cp, cc, k)
+    assert want.sum() > 0
+    W = (k + 31) // 32
+    buf = np.zeros((len(rcnt), 8 * W), dtype=np.uint8)
+    buf[:, : rp.shape[1]] = rp
+    keys = np.ascontiguousarray(buf.view(">u8").astype(np.uint64))
+    n = len(rcnt)
+    cuts = [(n * r) // world for r in range(world + 1)]                  # raw pieces: any cut will do
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cond_worker, args=(r, world, port, k, keys, rcnt, cuts, L, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, status, plot, _, _ in out:
+        assert status == "ok"
+        assert np.array_equal(plot.reshape(1001, 501), want), f"rank {rank}"
+    # the shards, in rank order, ARE the conditioned table
+    cbuf = np.zeros((len(cc), 8 * W), dtype=np.uint8)
+    cbuf[:, : cp.shape[1]] = cp
+    ck = np.ascontiguousarray(cbuf.view(">u8").astype(np.uint64))
+    want_keys = [int.from_bytes(b"".join(int(w).to_bytes(8, "big") for w in row), "big") for row in ck]
+    got_keys = [x for o in out for x in o[3]]
+    got_cnt = [c for o in out for c in o[4]]
+    assert got_keys == want_keys and got_cnt == [int(c) for c in cc]
+    assert min(len(o[3]) for o in out) > 0.25 * len(cc) / world          # balanced splitters: nobody is left (nearly) empty
+
+
+def test_symm_splitters_follow_the_closed_table():
+    """a canonical table crowds the low end of the k-mer space: splitters taken from entries + complements do not"""
+    bits = 6
+    own = np.zeros(1 << bits, dtype=np.int64); own[:16] = 100          # every entry starts with an a
+    rcs = np.zeros(1 << bits, dtype=np.int64); rcs[48:] = 100          # ... so every complement starts with a t
+    sp = sharded.symm_splitters(np.concatenate([own, rcs]), bits, 4, 1)
+    assert [int(v) >> (64 - bits) for v in sp] == [8, 16, 56]         # (bins 16..47 are empty: 16 and 48 cut the same place)
+    assert list(sharded.symm_splitters(np.concatenate([own, rcs * 0]), bits, 2, 1)) == [np.uint64(8) << np.uint64(58)]

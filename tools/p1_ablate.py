@@ -35,17 +35,18 @@ for spec in sys.argv[3:]:
         for it in range(4):
             if full:
                 st = e.run(plot.data_ptr(), "hash")
-                res.append((st["ms_pass1"], st["ms_rclookup"], st["ms_pass2"], st["ms_total"], st["nrequests"], st.get("ms_filter", 0)))
+                res.append((st["ms_pass1"], st["ms_rclookup"], st["ms_pass2"], st["ms_total"], st["nrequests"], st.get("ms_filter", 0),
+                            st.get("ms_bigfix", 0), st.get("nbig", 0)))
             else:
                 e.set_blockmap_bits(32)        # what a whole single-GPU run uses (the phase API defaults to the 30-bit exchange map)
-                e.pass1("hash"); st = e.stats(); res.append((st["ms_pass1"],))
+                e.pass1("hash"); st = e.stats(); res.append((st["ms_pass1"], st.get("ms_bigfix", 0), st.get("nbig", 0)))
         torch.cuda.synchronize()
         r = res[1:]
         mean = [sum(x[i] for x in r) / len(r) for i in range(len(r[0]))]
         if full:
-            print(f"{spec:60s} pass1 {mean[0]:7.3f} lookup {mean[1]:7.3f} (filter {mean[5]:6.3f}) pass2 {mean[2]:6.3f} total {mean[3]:7.3f} ms  kept {int(mean[4])} pairs {int(plot.sum().item())}", flush=True)
+            print(f"{spec:60s} pass1 {mean[0]:7.3f} (bigfix {mean[6]:5.3f}, {int(mean[7])} entries) lookup {mean[1]:7.3f} (filter {mean[5]:6.3f}) pass2 {mean[2]:6.3f} total {mean[3]:7.3f} ms  kept {int(mean[4])} pairs {int(plot.sum().item())}", flush=True)
         else:
-            print(f"{spec:60s} pass1 {mean[0]:7.3f} ms", flush=True)
+            print(f"{spec:60s} pass1 {mean[0]:7.3f} ms (bigfix {mean[1]:5.3f}, {int(mean[2])} entries)", flush=True)
         e.close()
     except Exception as ex:
         print(f"{spec:60s} FAILED {ex}", flush=True)
