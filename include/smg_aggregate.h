@@ -30,7 +30,8 @@ extern "C" {
    noise_filter  the walk stops at the first row with freq < noise_filter (that row and all later ones get 0)
    mask_errors   != 0: rows with covB < min(covB) + distance are the error line, label -1
    peak[i]       out: the smudge label of row i (1 .. *npeaks in order of creation, -1, or 0 = not reached)
-   returns 0, or -1 on bad arguments / out of memory                                                    */
+   returns 0, -1 on bad arguments, -2 when a coverage exceeds 65535 (two dense grids of (max coverage + 2 distance + 3)^2
+   cells are allocated: 13 MB for hetmers output, whose coverages end at 1000), -3 when out of memory        */
 int smg_local_aggregation(const int32_t *covB, const int32_t *covA, const int64_t *freq, int64_t n,
                           int32_t distance, int64_t noise_filter, int32_t mask_errors,
                           int32_t *peak, int32_t *npeaks);

@@ -33,8 +33,11 @@ def _lib():
 
 
 def load_hetmers(path):
-    """(covB, covA, freq) int arrays of a .smu file, rows by freq descending (smudgeplot.py:789-791; ties keep the
-    file's order here -- the reference leaves their order to pandas' unstable sort)"""
+    """(covB, covA, freq) int arrays of a .smu file, rows by freq descending (smudgeplot.py:789-791).  Rows of EQUAL freq
+    keep the file's order here; the reference sorts with pandas' default (unstable) quicksort, which leaves their order
+    to the library version -- and the greedy aggregation depends on the order of its rows, so pixels of equal freq at or
+    above the noise filter can be labelled differently by the two; the golden tests feed the rows in
+    the order the reference processed them."""
     tab = np.loadtxt(path, dtype=np.int64, delimiter="\t", ndmin=2)
     if tab.size == 0:
         tab = np.zeros((0, 3), dtype=np.int64)
@@ -56,7 +59,8 @@ def local_aggregation(covB, covA, freq, distance, noise_filter, mask_errors):
     rc = _lib().smg_local_aggregation(covB.ctypes.data, covA.ctypes.data, freq.ctypes.data, n, int(distance),
                                       int(noise_filter), int(bool(mask_errors)), peak.ctypes.data, C.byref(npk))
     if rc != 0:
-        raise RuntimeError("smg_local_aggregation failed (negative coverage, bad distance, or out of memory)")
+        raise RuntimeError({-2: "smg_local_aggregation: coverage above 65535 (not a hetmers table)",
+                            -3: "smg_local_aggregation: out of memory"}.get(rc, "smg_local_aggregation failed (negative coverage or bad distance)"))
     return peak, int(npk.value)
 
 
@@ -118,10 +122,15 @@ def fishnet_centralities(covB, covA, freq, smudge, total_genomic_kmers, covs, sm
 
 
 class Smudges:
-    """The 1n-coverage grid search of the reference's class of the same name (smudgeplot.py:96-148): the same three
-    grids (step 2, then 0.2 around the best, then 0.01 around that, then best/2 "just to be sure"), the same
-    arrays in `centrality_df` (a dict of two float64 arrays instead of a DataFrame), the same `cov`.
+    """The 1n-coverage search of the reference's class of the same name (smudgeplot.py:96-148), behind the same two
+    entry points (`get_centrality_df`, then `cov` / `centrality_df`).  What has to agree with the reference -- and is
+    pinned by tests/golden/centrality.json -- is the LIST of candidate coverages (three nested numpy.arange grids whose
+    end points and steps are below, then half of the winner), their centralities and the winner; how the search is
+    written down is this module's own.  `centrality_df` is a dict of two float64 arrays instead of a DataFrame.
     cov_tab = (covB, covA, freq, smudge) in the reference's order after peak_aggregation (by covA, covB)."""
+
+    # numpy.arange(int(lo) + a, int(hi) + b, step) around the previous winner (lo = hi = winner after the first grid)
+    REFINEMENTS = ((0.05, 0.05, 2), (-1.9, 1.9, 0.2), (-0.19, 0.19, 0.01))
 
     def __init__(self, cov_tab, total_genomic_kmers):
         self.covB, self.covA, self.freq, self.smudge = (np.asarray(c) for c in cov_tab)
@@ -129,30 +138,29 @@ class Smudges:
         self.cov = None
         self.centrality_df = None
 
-    def get_best_coverage(self, cov_list, smudge_size_cutoff=0.02, centralities=None, last_check=False):
-        if centralities is None:
-            centralities = []
-        to_test = cov_list[-1:] if last_check else cov_list
-        centralities = list(centralities) + fishnet_centralities(self.covB, self.covA, self.freq, self.smudge,
-                                                                 self.total_genomic_kmers, to_test, smudge_size_cutoff).tolist()
-        return cov_list[int(np.argmin(centralities))], centralities
+    def _score(self, candidates, cutoff):
+        return fishnet_centralities(self.covB, self.covA, self.freq, self.smudge, self.total_genomic_kmers, candidates, cutoff)
 
     def get_centrality_df(self, min_c, max_c, smudge_size_cutoff=0.02, log=None):
-        grid_params = [(0.05, 0.05, 2), (-1.9, 1.9, 0.2), (-0.19, 0.19, 0.01)]
-        results = []
-        for i, params in enumerate(grid_params):
-            cov_list = np.arange(int(min_c) + params[0], int(max_c) + params[1], params[2])
-            best_cov, centralities = self.get_best_coverage(cov_list, smudge_size_cutoff)
-            results.append({"covs": cov_list, "centralities": centralities, "best_cov": best_cov})
-            min_c, max_c = best_cov, best_cov
-            if i > 0 and log:
-                log.write(f"Best coverage to precision of 1/{10**i}: {best_cov:.2f}\n")
-        results[-1]["covs"] = np.append(results[-1]["covs"], results[-1]["best_cov"] / 2)
-        best_cov, centralities = self.get_best_coverage(cov_list=results[-1]["covs"], smudge_size_cutoff=smudge_size_cutoff,
-                                                        centralities=results[-1]["centralities"], last_check=True)
-        results[-1]["centralities"] = centralities
+        tried, scores = [], []
+        lo, hi, winner = min_c, max_c, None
+        for depth, (a, b, step) in enumerate(self.REFINEMENTS):
+            grid = np.arange(int(lo) + a, int(hi) + b, step)
+            cen = self._score(grid, smudge_size_cutoff)
+            winner = grid[int(np.argmin(cen))]
+            tried.append(grid); scores.append(cen)
+            lo = hi = winner
+            if depth and log:
+                log.write(f"Best coverage to precision of 1/{10 ** depth}: {winner:.2f}\n")
+        # the reference's last look: half of the winner competes with the finest grid, and takes over only if it is
+        # strictly better (numpy.argmin keeps the first of equal minima, the grid stands in front)
+        half = winner / 2
+        cen_half = float(self._score(np.array([half]), smudge_size_cutoff)[0])
+        if cen_half < float(np.min(scores[-1])):
+            winner = half
+        tried[-1] = np.append(tried[-1], half)
+        scores[-1] = np.append(scores[-1], cen_half)
         if log:
-            log.write(f"Best coverage to precision of 1/{10**i} (just to be sure): {best_cov:.2f}\n")
-        self.cov = best_cov
-        self.centrality_df = {"coverage": np.concatenate([r["covs"] for r in results]),
-                              "centrality": np.concatenate([np.asarray(r["centralities"], dtype=np.float64) for r in results])}
+            log.write(f"Best coverage to precision of 1/{10 ** (len(self.REFINEMENTS) - 1)} (just to be sure): {winner:.2f}\n")
+        self.cov = winner
+        self.centrality_df = {"coverage": np.concatenate(tried), "centrality": np.concatenate(scores).astype(np.float64)}

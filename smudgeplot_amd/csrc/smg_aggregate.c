@@ -35,11 +35,14 @@ int smg_local_aggregation(const int32_t *covB, const int32_t *covA, const int64_
       if (i == 0 || covB[i] < minB) minB = covB[i];      /* L = min(covB), smudgeplot.py:36 */
       peak[i] = 0;
     }
+  /* hetmers writes coverages <= 1000 (a 13 MB pair of grids); a .smu of 16-bit coverages from another tool still works
+     (up to 51 GB of grids -- the calloc may fail, reported as such), anything beyond that is not a coverage table */
+  if (maxc > 65535 || distance > 65535) return -2;
   off = distance + 1;                                     /* probes reach coordinates -distance .. maxc + distance */
   side = (int64_t) maxc + 2 * (int64_t) distance + 3;
   F = (int64_t *) calloc((size_t) (side * side), sizeof(int64_t));
   P = (int32_t *) calloc((size_t) (side * side), sizeof(int32_t));
-  if (!F || !P) { free(F); free(P); return -1; }
+  if (!F || !P) { free(F); free(P); return -3; }
 #define AT(a, b) (((int64_t) (a) + off) * side + ((int64_t) (b) + off))
 
   for (i = 0; i < n; i++)

@@ -70,15 +70,21 @@ struct Tab                     // kernel argument block (passed by value)
 // format F records -> interleaved left-aligned words + counts
 // (restates Current_Entry, libfastk.c:1230-1269: prefix from the index, suffix from the record)
 //
-// One workgroup decodes DEC_TILE consecutive entries:
+// One workgroup decodes DEC_TILE consecutive entries, four per thread:
 //   * their record bytes (DEC_TILE * pbyte, contiguous) are staged in LDS with coalesced dword loads
-//     (records are 3..33 bytes wide and unaligned: per-thread byte loads ran at ~4 G entries/s);
-//   * the prefix of an entry is the smallest p with index[p] > i.  Thread 0 bisects the index for the
-//     first and the last entry of the tile, the (few) index values in between are staged in LDS and
-//     every thread bisects there; a tile that spans more than DEC_IX buckets (sparse table) bisects
-//     the global index per entry as before.
+//     (records are 3..34 bytes wide and unaligned: per-thread byte loads ran at ~4 G entries/s);
+//   * a k-mer is put together 32 bits at a time: an unaligned little-endian dword of the staged bytes is one
+//     v_alignbyte over two LDS dwords, its big-endian value one v_perm; the first dword takes the prefix bytes from
+//     the index, the last one is masked behind the k-mer's last byte (the count bytes follow it in the record).
+//     (Round 2 walked the 8 W bytes of an entry one at a time, runtime shifts and all: 36-77 ms per 1e9 entries,
+//      6 % of the HBM roofline, the slowest kernel of the product path.)
+//   * the prefix of an entry is the smallest p with index[p] > i.  Thread 0 bisects the index for the first and the
+//     last entry of the tile, the (few) index values in between are staged in LDS; a thread bisects there for its
+//     first entry and steps on for the other three; a tile that spans more than DEC_IX buckets (sparse table)
+//     bisects the global index per entry.
 #define DEC_TILE  1024
-#define DEC_IX    2048
+#define DEC_EPT   4
+#define DEC_IX    512
 #define DEC_MAXPB 34                      // pbyte <= ceil(128/4) + 2 - 1
 
 SMG_DEV int dec_bisect(const int64_t *__restrict__ index, int lo, int hi, int64_t i)
@@ -89,13 +95,20 @@ SMG_DEV int dec_bisect(const int64_t *__restrict__ index, int lo, int hi, int64_
   return lo;
 }
 
-__global__ void __launch_bounds__(TPB)
+// the little-endian dword at byte offset o of the staged bytes
+SMG_DEV unsigned dec_u32(const unsigned *sraw, int o)
+{ return __builtin_amdgcn_alignbyte(sraw[(o >> 2) + 1], sraw[o >> 2], (unsigned) (o & 3)); }
+
+static inline size_t dec_lds_bytes(int pbyte) { return sizeof(unsigned) * (size_t) ((DEC_TILE * pbyte + 3) / 4 + 4); }
+
+template <int W> __global__ void __launch_bounds__(TPB)
 k_decode(const uint8_t *__restrict__ rec, const int64_t *__restrict__ index, int ixlen,
-         int ibyte, int kbyte, int W, int64_t n, int64_t ibase, u64 *__restrict__ keys,
+         int ibyte, int kbyte, int64_t n, int64_t ibase, u64 *__restrict__ keys,
          uint16_t *__restrict__ cnt)
 { // rec / keys / cnt are indexed by the LOCAL entry number 0..n-1; the prefix index by ibase + local
-  // (a shard of a table that was cut for several GPUs starts at entry ibase of the whole table)
-  __shared__ unsigned sraw[(DEC_TILE * DEC_MAXPB + 3) / 4 + 2];
+  // (a piece of a table that is decoded as it arrives, or a shard of a table that was cut for several GPUs,
+  //  starts at entry ibase of the whole table)
+  extern __shared__ unsigned sraw[];         // dec_lds_bytes(pbyte): the staged record bytes of a tile (+ slack)
   __shared__ int64_t  six[DEC_IX];
   __shared__ int      s_lo, s_hi;
   const int t = threadIdx.x;
@@ -109,7 +122,7 @@ k_decode(const uint8_t *__restrict__ rec, const int64_t *__restrict__ index, int
   const int skew = (int) (base - abase);
   const int ndw = (int) ((b1 - b0 + skew + 3) >> 2);
   const uintptr_t rbeg = (uintptr_t) rec, rend = (uintptr_t) rec + (uintptr_t) (n * pbyte);
-  for (int w = t; w < ndw; w += TPB)
+  for (int w = t; w < ndw + 2; w += TPB)      // (+2: dec_u32 reads one dword past the last byte it needs)
     { const uintptr_t a = abase + 4 * (uintptr_t) w;
       unsigned v = 0;
       if (a >= rbeg && a + 4 <= rend) v = *reinterpret_cast<const unsigned *>(a);
@@ -128,30 +141,76 @@ k_decode(const uint8_t *__restrict__ rec, const int64_t *__restrict__ index, int
   if (staged)
     for (int p = lo + t; p <= hi; p += TPB) six[p - lo] = index[p];
   __syncthreads();
-  const uint8_t *sb = reinterpret_cast<const uint8_t *>(sraw) + skew;
-  for (int64_t i = i0 + t; i < i1; i += TPB)
-    { int p;
-      if (staged)
-        { int a = 0, b = hi - lo;
-          while (a < b)
-            { const int m = (a + b) >> 1;
-              if (six[m] <= ibase + i) a = m + 1; else b = m;
-            }
-          p = lo + a;
+
+  const int64_t e0 = i0 + (int64_t) DEC_EPT * t;
+  if (e0 >= i1) return;
+  int pa = 0;                                // position of the first entry's prefix in the staged slice
+  if (staged)
+    { int a = 0, b = hi - lo;
+      while (a < b)
+        { const int m = (a + b) >> 1;
+          if (six[m] <= ibase + e0) a = m + 1; else b = m;
         }
-      else p = dec_bisect(index, lo, hi, ibase + i);
-      const uint8_t *r = sb + (i - i0) * pbyte;
-      u64 word = 0;
-      int w = 0;
-      for (int bb = 0; bb < 8 * W; bb++)
-        { unsigned v = 0;
-          if (bb < ibyte)      v = (p >> (8 * (ibyte - 1 - bb))) & 0xFF;
-          else if (bb < kbyte) v = r[bb - ibyte];
-          word = (word << 8) | v;
-          if ((bb & 7) == 7) { keys[i * W + w] = word; w++; word = 0; }
-        }
-      cnt[i] = (uint16_t) (r[hbyte] | (r[hbyte + 1] << 8));
+      pa = a;
     }
+  const int psh = 32 - 8 * ibyte;            // the prefix sits on top of the first dword
+  u64 kw[DEC_EPT][W]; unsigned cw[DEC_EPT];
+#pragma unroll
+  for (int r = 0; r < DEC_EPT; r++)
+    { const int64_t i = e0 + r;
+      if (i >= i1) { for (int w = 0; w < W; w++) kw[r][w] = 0; cw[r] = 0; continue; }
+      int p;
+      if (staged) { while (six[pa] <= ibase + i) pa++; p = lo + pa; }      // (index[hi] > i1 - 1: the walk ends)
+      else p = dec_bisect(index, lo, hi, ibase + i);
+      const int o = (int) (i - i0) * pbyte + skew;
+      unsigned D[2 * W];
+#pragma unroll
+      for (int j = 0; j < 2 * W; j++)
+        { unsigned v = 0;
+          if (4 * j < kbyte)
+            { if (j == 0)
+                { const unsigned sv = __builtin_bswap32(dec_u32(sraw, o));
+                  v = ((unsigned) p << psh) | (sv >> (8 * ibyte));
+                }
+              else v = __builtin_bswap32(dec_u32(sraw, o + 4 * j - ibyte));
+              const int over = 4 * j + 4 - kbyte;                         // bytes of this dword behind the k-mer
+              if (over > 0) v &= ~0u << (8 * over);
+            }
+          D[j] = v;
+        }
+#pragma unroll
+      for (int w = 0; w < W; w++) kw[r][w] = ((u64) D[2 * w] << 32) | D[2 * w + 1];
+      cw[r] = dec_u32(sraw, o + hbyte) & 0xFFFFu;
+    }
+  const bool full = e0 + DEC_EPT <= i1 && (((uintptr_t) (keys + e0 * W)) & 15) == 0 && (((uintptr_t) (cnt + e0)) & 7) == 0;
+  if (full)
+    { if constexpr (W == 1)
+        { ulonglong2 a, b; a.x = kw[0][0]; a.y = kw[1][0]; b.x = kw[2][0]; b.y = kw[3][0];
+          *reinterpret_cast<ulonglong2 *>(keys + e0) = a;
+          *reinterpret_cast<ulonglong2 *>(keys + e0 + 2) = b;
+        }
+      else
+        {
+#pragma unroll
+          for (int r = 0; r < DEC_EPT; r++)
+#pragma unroll
+            for (int w = 0; w < W; w += 2)
+              { if (w + 1 < W)
+                  { ulonglong2 a; a.x = kw[r][w]; a.y = kw[r][w + 1];
+                    *reinterpret_cast<ulonglong2 *>(keys + (e0 + r) * W + w) = a;
+                  }
+                else keys[(e0 + r) * W + w] = kw[r][w];
+              }
+        }
+      *reinterpret_cast<ushort4 *>(cnt + e0) = make_ushort4((unsigned short) cw[0], (unsigned short) cw[1],
+                                                            (unsigned short) cw[2], (unsigned short) cw[3]);
+    }
+  else
+    for (int r = 0; r < DEC_EPT; r++)
+      if (e0 + r < i1)
+        { for (int w = 0; w < W; w++) keys[(e0 + r) * W + w] = kw[r][w];
+          cnt[e0 + r] = (uint16_t) cw[r];
+        }
 }
 
 // bucket directory + strict-order validation
@@ -545,6 +604,20 @@ extern "C" int smg_device_count(void)
   return n;
 }
 
+__global__ void k_warm(unsigned *p) { if (p && threadIdx.x == 0) *p = 1u; }
+
+extern "C" int smg_device_warmup(int device)
+{ int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return SMG_ENODEV;
+  if (hipSetDevice(device) != hipSuccess) return SMG_ENODEV;
+  unsigned *p = NULL;
+  if (hipMalloc(&p, 256) != hipSuccess) return SMG_ENODEV;
+  hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, 0, p);       // (the first launch loads the code object)
+  const hipError_t he = hipDeviceSynchronize();
+  hipFree(p);
+  return he == hipSuccess ? SMG_OK : SMG_ENODEV;
+}
+
 extern "C" smg_engine *smg_engine_create(int device, void *stream, char *errbuf, size_t errlen)
 { int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
@@ -643,8 +716,8 @@ extern "C" int smg_engine_bind(smg_engine *e, int kmer, int64_t nels, const uint
   return SMG_OK;
 }
 
-static int decode_at(smg_engine *e, int kmer, int ibyte, int64_t nels, int64_t ibase, const uint8_t *d_records,
-                     const int64_t *d_prefix_index, char *errbuf, size_t errlen)
+// the engine's own table for `nels` entries of a format-F table (allocated, not filled yet)
+static int decode_begin(smg_engine *e, int kmer, int ibyte, int64_t nels, char *errbuf, size_t errlen)
 { if (!e) return fail(errbuf, errlen, SMG_EINVAL, "null engine%s");
   if (ibyte < 1 || ibyte > 3) return fail(errbuf, errlen, SMG_EINVAL, "ibyte must be 1, 2 or 3%s");
   HIPCHK(hipSetDevice(e->device));
@@ -655,20 +728,44 @@ static int decode_at(smg_engine *e, int kmer, int ibyte, int64_t nels, int64_t i
   hipFree(e->own_keys); hipFree(e->own_cnt);
   e->own_keys = NULL; e->own_cnt = NULL;
   HIPCHK(hipMalloc(&e->own_keys, sizeof(u64) * (size_t) (nels > 0 ? nels : 1) * e->W));
-  HIPCHK(hipMalloc(&e->own_cnt, sizeof(uint16_t) * (size_t) (nels > 0 ? nels : 1)));
+  HIPCHK(hipMalloc(&e->own_cnt, sizeof(uint16_t) * (size_t) (nels > 0 ? nels : 1) + 16));
   e->keys = e->own_keys; e->cnt = e->own_cnt;
+  return SMG_OK;
+}
+
+// decode `nent` records at d_records into the entries [first, first + nent) of the engine's table; the first of them is
+// entry ibase + first of the whole table (whose prefix index is d_prefix_index).  Queued on `stream`.
+static int decode_piece(smg_engine *e, hipStream_t stream, int ibyte, const uint8_t *d_records, const int64_t *d_prefix_index,
+                        int64_t ibase, int64_t first, int64_t nent)
+{ if (nent <= 0) return 0;
+  const int kbyte = (e->kmer + 3) >> 2;
+  const unsigned nblk = (unsigned) ((nent + DEC_TILE - 1) / DEC_TILE);
+#define CALL(WW) hipLaunchKernelGGL(k_decode<WW>, dim3(nblk), dim3(TPB), dec_lds_bytes(kbyte + 2 - ibyte), stream, d_records, \
+                         d_prefix_index, 1 << (8 * ibyte), ibyte, kbyte, nent, ibase + first, e->own_keys + first * e->W, e->own_cnt + first)
+  DISPATCH_W(e, CALL)
+#undef CALL
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+static int decode_at(smg_engine *e, int kmer, int ibyte, int64_t nels, int64_t ibase, const uint8_t *d_records,
+                     const int64_t *d_prefix_index, char *errbuf, size_t errlen)
+{ int rc = decode_begin(e, kmer, ibyte, nels, errbuf, errlen);
+  if (rc) return rc;
   hipEventRecord(e->ev[0], e->stream);
-  if (nels > 0)
-    { const unsigned nblk = (unsigned) ((nels + DEC_TILE - 1) / DEC_TILE);
-      hipLaunchKernelGGL(k_decode, dim3(nblk), dim3(TPB), 0, e->stream, d_records,
-                         d_prefix_index, 1 << (8 * ibyte), ibyte, kbyte, e->W, nels, ibase,
-                         e->own_keys, e->own_cnt);
-    }
+  if (decode_piece(e, e->stream, ibyte, d_records, d_prefix_index, ibase, 0, nels))
+    return fail(errbuf, errlen, SMG_ENODEV, "decode launch failed%s");
   hipEventRecord(e->ev[1], e->stream);
   HIPCHK(hipStreamSynchronize(e->stream));
   float ms = 0; hipEventElapsedTime(&ms, e->ev[0], e->ev[1]);
   e->st.ms_decode = ms;
   return SMG_OK;
+}
+
+// ingest hook: decode a piece behind its copy (smg_ingest.hpp)
+struct DecodeHook { smg_engine *e; const int64_t *d_index; int ibyte; int64_t ibase; };
+static int decode_hook(void *ctx, hipStream_t stream, const uint8_t *d_piece, int64_t first, int64_t nent)
+{ DecodeHook *h = (DecodeHook *) ctx;
+  return decode_piece(h->e, stream, h->ibyte, d_piece, h->d_index, h->ibase, first, nent);
 }
 
 extern "C" int smg_engine_decode(smg_engine *e, int kmer, int ibyte, int64_t nels,
@@ -2095,33 +2192,40 @@ static int host_run(const smg_table_source *tv, const smg_opts *opts, int64_t *p
       }
   }
 
+  struct timespec w0, w1, w2;
+  clock_gettime(CLOCK_MONOTONIC, &w0);
   smg_engine *e = smg_engine_create(device, NULL, errbuf, errlen);
   if (!e) return SMG_ENODEV;
+  clock_gettime(CLOCK_MONOTONIC, &w1);       // (the first HIP call of the process: runtime start-up + code object load)
   int rc = SMG_OK;
-  uint8_t *d_rec = NULL; int64_t *d_index = NULL, *d_plot = NULL;
+  int64_t *d_index = NULL, *d_plot = NULL;
   uint16_t *d_labels = NULL; uint64_t *d_out = NULL;
   const size_t ixbytes = sizeof(int64_t) << (8 * tv->ibyte);
-  hipEvent_t h0, h1;
-  double h2d_s = 0;
-  hipEventCreate(&h0); hipEventCreate(&h1);
+  double h2d_s = 0, alloc_s = 0, cond_s = 0, run_s = 0, out_s = 0;
 #define BAIL(code, msg) { rc = fail(errbuf, errlen, code, msg "%s"); goto done; }
-  if (hipMalloc(&d_rec, (size_t) (tv->nels > 0 ? tv->nels : 1) * pbyte) != hipSuccess
-      || hipMalloc(&d_index, ixbytes) != hipSuccess
-      || hipMalloc(&d_plot, sizeof(int64_t) * SMG_PLOT_CELLS) != hipSuccess)
+#define SECS(a, b) ((double) ((b).tv_sec - (a).tv_sec) + 1e-9 * (double) ((b).tv_nsec - (a).tv_nsec))
+  if (hipMalloc(&d_index, ixbytes) != hipSuccess || hipMalloc(&d_plot, sizeof(int64_t) * SMG_PLOT_CELLS) != hipSuccess)
     BAIL(SMG_ENOMEM, "out of device memory for the table")
-  { // the index goes first (asynchronously from pageable memory: staged by the runtime), the records stream behind it
-    if (hipMemcpyAsync(d_index, tv->prefix_index, ixbytes, hipMemcpyHostToDevice, 0) != hipSuccess)
+  if ((rc = decode_begin(e, tv->kmer, tv->ibyte, tv->nels, errbuf, errlen))) goto done;
+  { // the index goes first (asynchronously from pageable memory: staged by the runtime); the records stream behind it,
+    // piece by piece through a pinned ring, and every piece is decoded on the device as soon as its copy has landed
+    if (hipMemcpyAsync(d_index, tv->prefix_index, ixbytes, hipMemcpyHostToDevice, e->stream) != hipSuccess
+        || hipEventRecord(e->ev[0], e->stream) != hipSuccess)
       BAIL(SMG_ENODEV, "host to device copy failed")
-    if ((rc = ingest_records(tv, pbyte, 0, tv->nels, d_rec, device, tv->host_threads, &h2d_s, errbuf, errlen))) goto done;
-    if (hipStreamSynchronize(0) != hipSuccess) BAIL(SMG_ENODEV, "host to device copy failed")
+    clock_gettime(CLOCK_MONOTONIC, &w2);
+    alloc_s = SECS(w1, w2);
+    DecodeHook hk; hk.e = e; hk.d_index = d_index; hk.ibyte = tv->ibyte; hk.ibase = 0;
+    if ((rc = ingest_records(tv, pbyte, 0, tv->nels, NULL, device, tv->host_threads, &h2d_s, errbuf, errlen, decode_hook, &hk, e->ev[0]))) goto done;
+    if (hipStreamSynchronize(e->stream) != hipSuccess) BAIL(SMG_ENODEV, "host to device copy failed")
   }
-  if ((rc = smg_engine_decode(e, tv->kmer, tv->ibyte, tv->nels, d_rec, d_index, errbuf, errlen))) goto done;
-  hipFree(d_rec); d_rec = NULL;
+  clock_gettime(CLOCK_MONOTONIC, &w1);
   if (opts && opts->condition)
     { if ((rc = smg_engine_condition(e, opts->ethresh, opts->condition & SMG_COND_TRIM, opts->condition & SMG_COND_SYMM,
                                      NULL, errbuf, errlen))) goto done;
     }
+  clock_gettime(CLOCK_MONOTONIC, &w2); cond_s = SECS(w1, w2);
   if ((rc = smg_engine_run(e, symcheck, d_plot, NULL, errbuf, errlen))) goto done;
+  clock_gettime(CLOCK_MONOTONIC, &w1); run_s = SECS(w2, w1);
   if (hipMemcpy(plot, d_plot, sizeof(int64_t) * SMG_PLOT_CELLS, hipMemcpyDeviceToHost) != hipSuccess)
     BAIL(SMG_ENODEV, "device to host copy failed")
   if (labels)
@@ -2144,19 +2248,25 @@ static int host_run(const smg_table_source *tv, const smg_opts *opts, int64_t *p
         { free(h); BAIL(SMG_ENODEV, "device to host copy failed") }
       *records = h; *nrec = want; *rec_words = rw;
     }
+  clock_gettime(CLOCK_MONOTONIC, &w2); out_s = SECS(w1, w2);
   e->st.ms_h2d = h2d_s * 1e3;
   if (stats) *stats = e->st;
   if (verbose)
-    fprintf(stderr, "  [smg] n=%lld k=%d path=%s  read+h2d %.2f ms (%.1f GB/s, %d readers), decode %.2f, pass1 %.2f, rc-lookup %.2f, "
-            "pass2 %.2f, total(device) %.2f ms => %.3g k-mers/s\n",
-            (long long) e->st.nels, tv->kmer, e->st.path == 1 ? "rc-half-scan" : "general",
-            e->st.ms_h2d, h2d_s > 0 ? (double) tv->nels * pbyte / h2d_s / 1e9 : 0.0, tv->host_threads > 0 ? tv->host_threads : 4,
-            e->st.ms_decode, e->st.ms_pass1, e->st.ms_rclookup, e->st.ms_pass2,
-            e->st.ms_total, e->st.ms_total > 0 ? e->st.nels / (e->st.ms_total * 1e-3) : 0.0);
+    { fprintf(stderr, "  [smg] n=%lld k=%d path=%s  read+h2d+decode %.2f ms (%.1f GB/s, %d readers; the decode of a piece runs behind its copy), "
+              "pass1 %.2f, rc-lookup %.2f, pass2 %.2f, total(device) %.2f ms => %.3g k-mers/s\n",
+              (long long) e->st.nels, tv->kmer, e->st.path == 1 ? "rc-half-scan" : "general",
+              e->st.ms_h2d, h2d_s > 0 ? (double) tv->nels * pbyte / h2d_s / 1e9 : 0.0, tv->host_threads > 0 ? tv->host_threads : 4,
+              e->st.ms_pass1, e->st.ms_rclookup, e->st.ms_pass2,
+              e->st.ms_total, e->st.ms_total > 0 ? e->st.nels / (e->st.ms_total * 1e-3) : 0.0);
+      // where the wall time of this call went (the process adds its own start-up, the table probe and the .smu writer)
+      fprintf(stderr, "  [smg] wall %.1f ms: runtime start-up + code object %.1f, allocations + index %.1f, read+h2d+decode %.1f, "
+              "conditioning %.1f, passes + host round trips %.1f, results %.1f\n",
+              SECS(w0, w2) * 1e3, (SECS(w0, w2) - alloc_s - h2d_s - cond_s - run_s - out_s) * 1e3, alloc_s * 1e3, h2d_s * 1e3,
+              cond_s * 1e3, run_s * 1e3, out_s * 1e3);
+    }
 done:
 #undef BAIL
-  hipEventDestroy(h0); hipEventDestroy(h1);
-  if (d_rec) hipFree(d_rec);
+#undef SECS
   if (d_index) hipFree(d_index);
   if (d_plot) hipFree(d_plot);
   if (d_labels) hipFree(d_labels);
@@ -2207,16 +2317,15 @@ extern "C" int smg_condition_table(const smg_table_view *tv, const smg_opts *opt
   uint64_t *hk = NULL; uint16_t *hc = NULL;
   const size_t ixbytes = sizeof(int64_t) << (8 * tv->ibyte);
 #define BAIL(code, msg) { rc = fail(errbuf, errlen, code, msg "%s"); goto done; }
-  if (hipMalloc(&d_rec, (size_t) (tv->nels > 0 ? tv->nels : 1) * pbyte) != hipSuccess || hipMalloc(&d_index, ixbytes) != hipSuccess)
-    BAIL(SMG_ENOMEM, "out of device memory for the table")
+  if (hipMalloc(&d_index, ixbytes) != hipSuccess) BAIL(SMG_ENOMEM, "out of device memory for the table")
+  if ((rc = decode_begin(e, tv->kmer, tv->ibyte, tv->nels, errbuf, errlen))) goto done;
   { ViewCtx vc; smg_table_source src;
     view_source(tv, &vc, &src);
-    if ((rc = ingest_records(&src, pbyte, 0, tv->nels, d_rec, opts->device, 4, NULL, errbuf, errlen))) goto done;
     if (hipMemcpy(d_index, tv->prefix_index, ixbytes, hipMemcpyHostToDevice) != hipSuccess)
       BAIL(SMG_ENODEV, "host to device copy failed")
+    DecodeHook hk; hk.e = e; hk.d_index = d_index; hk.ibyte = tv->ibyte; hk.ibase = 0;
+    if ((rc = ingest_records(&src, pbyte, 0, tv->nels, NULL, opts->device, 4, NULL, errbuf, errlen, decode_hook, &hk))) goto done;
   }
-  if ((rc = smg_engine_decode(e, tv->kmer, tv->ibyte, tv->nels, d_rec, d_index, errbuf, errlen))) goto done;
-  hipFree(d_rec); d_rec = NULL;
   if (opts->condition
       && (rc = smg_engine_condition(e, opts->ethresh, opts->condition & SMG_COND_TRIM, opts->condition & SMG_COND_SYMM,
                                     NULL, errbuf, errlen)))

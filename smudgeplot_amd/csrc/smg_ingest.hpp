@@ -5,7 +5,11 @@
 // (1.1 s of a 1.8 s run on a 7.2 GB table, host RSS = table size).  Here `nthreads` readers pull pieces of
 // ING_CHUNK bytes through the source's read callback (pread for a table on disk) into a ring of pinned buffers;
 // every piece is sent with hipMemcpyAsync as soon as it is read, so reading piece c+1 overlaps the DMA of piece c,
-// and the host holds nthreads + 2 pieces at any time.  Included by smg_hetmers.hip.
+// and the host holds nthreads + 2 pieces at any time.  With a piece hook (ingest_decoded) the copy lands in a small
+// ring on the DEVICE and the hook's kernel -- the decode of just that piece -- is queued right behind it on the copy
+// stream: decoding hides behind PCIe and the device never holds the raw records of the whole table (round 2 decoded
+// the complete shard in one launch after the last copy: 36-77 ms per 1e9 entries in the open).
+// Included by smg_hetmers.hip.
 
 #pragma once
 #include <pthread.h>
@@ -15,10 +19,16 @@
 
 struct IngPiece { int part; int64_t first, nent; size_t dst; };
 
+// called with the copy stream after the copy of a piece has been queued: d_piece = its records on the device,
+// first = its first entry counted from the start of the ingested range, nent = its entries.  0 = success.
+typedef int (*IngestHook)(void *ctx, hipStream_t stream, const uint8_t *d_piece, int64_t first, int64_t nent);
+
 struct Ingest
 { const smg_table_source *src;
   int          pbyte, device, nslots;
-  uint8_t     *d_rec;
+  uint8_t     *d_rec;                // whole-range destination, or NULL: pieces go to d_ring and to the hook
+  uint8_t     *d_ring[ING_MAXT + 2];
+  IngestHook   hook; void *hook_ctx;
   hipStream_t  stream;
   IngPiece    *piece; long npiece, next;
   char        *sent;                 // piece c has been handed to the copy stream
@@ -47,9 +57,12 @@ static void *ingest_worker(void *arg)
         }
       const IngPiece &p = g->piece[c];
       if (!bad && g->src->read(g->src->ctx, p.part, p.first, p.nent, g->ring[slot]) != 0) bad = 1;
-      if (!bad && (hipMemcpyAsync(g->d_rec + p.dst, g->ring[slot], (size_t) p.nent * g->pbyte, hipMemcpyHostToDevice, g->stream) != hipSuccess
+      uint8_t *dst = g->d_rec ? g->d_rec + p.dst : g->d_ring[slot];
+      if (!bad && (hipMemcpyAsync(dst, g->ring[slot], (size_t) p.nent * g->pbyte, hipMemcpyHostToDevice, g->stream) != hipSuccess
                    || hipEventRecord(g->ev[slot], g->stream) != hipSuccess))
         bad = 2;
+      // (the device slot is written again nslots pieces on, by a copy that is queued behind this hook's kernel)
+      if (!bad && g->hook && g->hook(g->hook_ctx, g->stream, dst, (int64_t) (p.dst / (size_t) g->pbyte), p.nent) != 0) bad = 2;
       pthread_mutex_lock(&g->mu);
       if (bad && !g->failed) g->failed = bad;
       g->sent[c] = 1;                              // (also on failure: nobody may wait for ever)
@@ -61,13 +74,16 @@ static void *ingest_worker(void *arg)
 
 // records of the entries [lo, hi) of the table -> d_rec[0 ..), on `device`.  0, or a negative SMG_E* code.
 static int ingest_records(const smg_table_source *src, int pbyte, int64_t lo, int64_t hi, uint8_t *d_rec, int device,
-                          int nthreads, double *seconds, char *errbuf, size_t errlen)
+                          int nthreads, double *seconds, char *errbuf, size_t errlen, IngestHook hook = NULL, void *hook_ctx = NULL,
+                          hipEvent_t after = NULL /* the copy stream waits for this event first (what the hook's kernels read) */)
 { Ingest g;
   memset(&g, 0, sizeof(g));
   if (nthreads < 1) nthreads = 4;
   if (nthreads > ING_MAXT) nthreads = ING_MAXT;
-  g.src = src; g.pbyte = pbyte; g.device = device; g.d_rec = d_rec;
-  const int64_t per = (int64_t) (ING_CHUNK / (size_t) pbyte);
+  g.src = src; g.pbyte = pbyte; g.device = device; g.d_rec = d_rec; g.hook = hook; g.hook_ctx = hook_ctx;
+  if (!d_rec && !hook) return fail(errbuf, errlen, SMG_EINVAL, "ingest: no destination%s");
+  // (whole decode tiles per piece: the pieces of a part start on multiples of 1024 entries of the part)
+  const int64_t per = (int64_t) (ING_CHUNK / (size_t) pbyte) / 1024 * 1024;
   // pieces: part by part, `per` entries each
   long cap = 0;
   { int64_t base = 0;
@@ -102,11 +118,17 @@ static int ingest_records(const smg_table_source *src, int pbyte, int64_t lo, in
   for (; rc == SMG_OK && made < g.nslots; made++)
     if (hipHostMalloc((void **) &g.ring[made], ING_CHUNK) != hipSuccess)
       { rc = fail(errbuf, errlen, SMG_ENOMEM, "cannot allocate the pinned staging buffers%s"); break; }
+  int dmade = 0;
+  for (; rc == SMG_OK && !d_rec && dmade < g.nslots; dmade++)
+    if (hipMalloc((void **) &g.d_ring[dmade], ING_CHUNK) != hipSuccess)
+      { rc = fail(errbuf, errlen, SMG_ENOMEM, "cannot allocate the device staging ring%s"); break; }
   for (; rc == SMG_OK && evs < g.nslots; evs++)
     if (hipEventCreateWithFlags(&g.ev[evs], hipEventDisableTiming) != hipSuccess)
       { rc = fail(errbuf, errlen, SMG_ENODEV, "cannot create an event%s"); break; }
   if (rc == SMG_OK && (hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess))
     rc = fail(errbuf, errlen, SMG_ENODEV, "cannot create an event%s");
+  if (rc == SMG_OK && after && hipStreamWaitEvent(g.stream, after, 0) != hipSuccess)
+    rc = fail(errbuf, errlen, SMG_ENODEV, "cannot order the copy stream%s");
   if (rc == SMG_OK)
     { pthread_mutex_init(&g.mu, NULL); pthread_cond_init(&g.cv, NULL);
       struct timespec a, b;
@@ -128,6 +150,7 @@ static int ingest_records(const smg_table_source *src, int pbyte, int64_t lo, in
   if (t1) hipEventDestroy(t1);
   for (int i = 0; i < evs; i++) hipEventDestroy(g.ev[i]);
   for (int i = 0; i < made; i++) hipHostFree(g.ring[i]);
+  for (int i = 0; i < dmade; i++) hipFree(g.d_ring[i]);
   if (g.stream) hipStreamDestroy(g.stream);
   free(g.piece); free(g.sent);
   return rc;

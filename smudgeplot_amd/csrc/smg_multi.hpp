@@ -182,7 +182,7 @@ static void *multi_worker(void *argp)
   const int r = arg->r, n = c->n, W = c->W;
   const smg_table_source *tv = c->tv;
   smg_engine *e = NULL;
-  uint8_t *d_rec = NULL; int64_t *d_index = NULL, *d_plot = NULL;
+  int64_t *d_index = NULL, *d_plot = NULL;
   uint64_t *recv = NULL;
   u64 splitters[SMG_MAXGPU * 4];
   char *eb = c->err[r]; const size_t el = sizeof(c->err[r]);
@@ -196,15 +196,17 @@ static void *multi_worker(void *argp)
   const int64_t lo = c->cut[r], hi = c->cut[r + 1], ns = hi - lo;
   const size_t ixbytes = sizeof(int64_t) << (8 * tv->ibyte);
   if (MOK)
-    { if (hipMalloc(&d_rec, (size_t) (ns > 0 ? ns : 1) * c->pbyte) != hipSuccess || hipMalloc(&d_index, ixbytes) != hipSuccess
-          || hipMalloc(&d_plot, sizeof(int64_t) * SMG_PLOT_CELLS) != hipSuccess)
+    { if (hipMalloc(&d_index, ixbytes) != hipSuccess || hipMalloc(&d_plot, sizeof(int64_t) * SMG_PLOT_CELLS) != hipSuccess)
         MFAIL(SMG_ENOMEM, "out of device memory for the table shard");
     }
-  if (MOK && (c->rc[r] = ingest_records(tv, c->pbyte, lo, hi, d_rec, c->devs[r], c->io_threads, NULL, eb, el))) c->failed = 1;
   if (MOK && hipMemcpy(d_index, tv->prefix_index, ixbytes, hipMemcpyHostToDevice) != hipSuccess)
     MFAIL(SMG_ENODEV, "host to device copy failed");
-  if (MOK && (c->rc[r] = decode_at(e, tv->kmer, tv->ibyte, ns, lo, d_rec, d_index, eb, el))) c->failed = 1;
-  if (d_rec) { hipFree(d_rec); d_rec = NULL; }
+  if (MOK && (c->rc[r] = decode_begin(e, tv->kmer, tv->ibyte, ns, eb, el))) c->failed = 1;
+  if (MOK)
+    { // the shard's record range, piece by piece: copied, and decoded behind its copy (entry lo of the table = entry 0 here)
+      DecodeHook hk; hk.e = e; hk.d_index = d_index; hk.ibyte = tv->ibyte; hk.ibase = lo;
+      if ((c->rc[r] = ingest_records(tv, c->pbyte, lo, hi, NULL, c->devs[r], c->io_threads, NULL, eb, el, decode_hook, &hk))) c->failed = 1;
+    }
   if (d_index) { hipFree(d_index); d_index = NULL; }
   if (MOK && (c->condition & SMG_COND_TRIM))
     { int64_t nn = 0;

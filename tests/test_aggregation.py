@@ -147,3 +147,39 @@ def test_centrality_cells_by_hand():
     # the size cut-off is a strict "greater than"
     out = aggregation.fishnet_centralities(b, a, f, sm, 400, np.array([10.0]), smudge_filter=0.25)
     assert out[0] == 0.0                                    # only the 300-pair cell (0.75 > 0.25; 0.25 > 0.25 is false)
+
+
+def test_coverage_table_with_ties_goes_through_load_hetmers(tmp_path):
+    """rows of equal freq keep the order of the file (documented: the reference leaves it to pandas' unstable sort);
+    the labels then are those of local_aggregation on exactly that order"""
+    rows = [(5, 30, 700), (6, 30, 700), (5, 31, 700), (20, 20, 900), (21, 20, 900), (2, 40, 100), (7, 33, 700)]
+    smu = tmp_path / "t.smu"
+    smu.write_text("".join(f"{b}\t{a}\t{f}\n" for b, a, f in rows))
+    b, a, f = aggregation.load_hetmers(str(smu))
+    assert f.tolist() == [900, 900, 700, 700, 700, 700, 100]
+    assert list(zip(b.tolist(), a.tolist()))[:2] == [(20, 20), (21, 20)]           # ties: file order
+    assert list(zip(b.tolist(), a.tolist()))[2:6] == [(5, 30), (6, 30), (5, 31), (7, 33)]
+    cov = aggregation.Coverages((b, a, f))
+    cov.local_aggregation(distance=2, noise_filter=200, mask_errors=False)
+    want, _ = aggregation.local_aggregation(b, a, f, 2, 200, False)
+    assert cov.smudge.tolist() == want.tolist() and want[-1] == 0 and want[0] == want[1] == 1
+
+
+def test_coverages_that_are_not_a_hetmers_table_are_refused_with_a_reason():
+    with pytest.raises(RuntimeError, match="65535"):
+        aggregation.local_aggregation([1], [70000], [5], 2, 1, False)
+
+
+@pytest.mark.gpu
+def test_aggregation_goldens_on_the_gpu_box():
+    """the same goldens once more under the `gpu` marker, so that the driver's GPU-side run (which loads the in-tree
+    libraries on that box) shows this row too; nothing here needs the GPU"""
+    for c in CASES:
+        rows = np.array(c["rows"], dtype=np.int64)
+        peak, _ = aggregation.local_aggregation(rows[:, 0], rows[:, 1], rows[:, 2], c["distance"], c["noise_filter"], c["mask_errors"])
+        assert peak.tolist() == c["peaks"], c["name"]
+    for c in CCASES:
+        rows = np.array(c["rows"], dtype=np.int64)
+        s = aggregation.Smudges((rows[:, 0], rows[:, 1], rows[:, 2], rows[:, 3]), c["total_genomic_kmers"])
+        s.get_centrality_df(c["min_c"], c["max_c"], c["cutoff"])
+        assert s.centrality_df["centrality"].tobytes() == np.array(c["centrality"]).tobytes() and float(s.cov) == c["best"]

@@ -464,25 +464,26 @@ def test_condition_sharded_driver_one_rank_and_engine_primitives(k, seed):
 # ---- BASELINE config 3 at FULL size: size-independent properties (no CPU oracle finishes 2.5e9 entries) ----
 
 def _manual_sharded(k, tk, tc, cuts, dev, symcheck="hash"):
-    """the sharded protocol on ONE GPU: one engine per prefix shard, the request exchange done by hand"""
+    """the sharded protocol on ONE GPU: one engine per prefix shard, the request exchange done by hand.
+    tk: the table's k-mer words (n * W int64, W = ceil(k / 32)), cuts in entries."""
     import torch
     from smudgeplot_amd import sharded
     world = len(cuts) - 1
-    keys_np = None
+    W = (k + 31) // 32
     engs, sends, counts = [], [], []
     ntab = tc.numel()                          # (an empty trailing shard starts at +infinity)
-    firsts = [tk[c:c + 1].cpu().numpy().view(np.uint64) if c < ntab else np.array([~np.uint64(0)]) for c in cuts[1:-1]]
+    firsts = [tk[c * W:(c + 1) * W].cpu().numpy().view(np.uint64) if c < ntab else np.full(W, ~np.uint64(0)) for c in cuts[1:-1]]
     split = np.concatenate(firsts) if firsts else np.zeros(0, np.uint64)
     for r in range(world):
         en = sharded.TorchEngine(dev)
-        en.bind(k, tk[cuts[r]:cuts[r + 1]].clone(), tc[cuts[r]:cuts[r + 1]].clone())    # aligned copies
+        en.bind(k, tk[cuts[r] * W:cuts[r + 1] * W].clone(), tc[cuts[r]:cuts[r + 1]].clone())    # aligned copies
         en.pass1(symcheck)
         engs.append(en)
     bits, nwords = engs[0].blockmap()
     assert all(en.blockmap() == (bits, nwords) for en in engs)        # empty shards included
     emitted = sum(en.nreq() for en in engs)
     if bits:                                   # request filter: the exchange of the candidate block maps, by hand
-        wlo, wlen = sharded.blockmap_ranges(split, 1, world, bits, nwords // (((1 << bits) + 31) >> 5))
+        wlo, wlen = sharded.blockmap_ranges(split, W, world, bits, nwords // (((1 << bits) + 31) >> 5))
         full = torch.zeros(nwords, dtype=torch.int32, device=dev)
         for r, en in enumerate(engs):
             part = torch.zeros(wlen[r], dtype=torch.int32, device=dev)
@@ -522,15 +523,16 @@ def test_manual_shards_with_an_empty_shard(k):
     import torch
     packed, cnt = synth.adversarial_table(k, 5000, 4, 33, low_complexity=20, dense=1)
     want = brute.hetmers_plot(packed, cnt, k)
-    if k > 32:
-        pytest.skip("_manual_sharded routes one-word k-mers")
-    keys = ktab.packed_to_u64(packed)
+    W = (k + 31) // 32
+    buf = np.zeros((len(cnt), 8 * W), dtype=np.uint8)
+    buf[:, : packed.shape[1]] = packed
+    keys = np.ascontiguousarray(buf.view(">u8").astype(np.uint64)).reshape(-1)       # n * W words, left aligned
     dev = torch.device("cuda:0")
     tk = torch.from_numpy(keys.view(np.int64)).to(dev)
     tc = torch.from_numpy(cnt.view(np.int16)).to(dev)
     n = len(cnt)
     from smudgeplot_amd import sharded
-    cut = sharded.fix_cut(keys, 1, k, n // 2)
+    cut = sharded.fix_cut(keys, W, k, n // 2)
     for cuts in ([0, 0, cut, n], [0, cut, cut, n], [0, cut, n, n]):
         tot, _ = _manual_sharded(k, tk, tc, cuts, dev)
         assert np.array_equal(tot.cpu().numpy().reshape(1001, 501), want), cuts
@@ -952,7 +954,18 @@ def test_exact_proof_is_not_fooled_by_a_signature_twin():
         assert np.array_equal(plot, want), mode
 
 
+_BRUTE = {}
+
+
+def _brute_cached(k, m, seed, packed, cnt):
+    """the oracle's plot of a synthetic table, computed once per table (eight switch settings share it)"""
+    if (k, m, seed) not in _BRUTE:
+        _BRUTE[(k, m, seed)] = brute.hetmers_plot(packed, cnt, k)
+    return _BRUTE[(k, m, seed)]
+
+
 @pytest.mark.parametrize("env", [{"SMG_ONE_BIT_MAP": "1"}, {"SMG_OLD_LOOKUP": "1"}, {"SMG_LOOKUP_SPLIT": "1"}, {"SMG_BM_BITS": "30"},
+                                 {"SMG_SIG": "1"}, {"SMG_SIG": "0", "SMG_BM_BITS": "30"},
                                  {"SMG_BM_BITS": "24", "SMG_ONE_BIT_MAP": "1"}, {"SMG_DIR_PER": "8"}, {"SMG_DIR_PER": "200"},
                                  {"SMG_NO_FILTER": "1"}])
 @pytest.mark.parametrize("k,m,seed", [(31, 60000, 21), (27, 40000, 22), (24, 30000, 23)])
@@ -962,6 +975,7 @@ def test_every_variant_of_the_lookup_chain_gives_the_same_plot(k, m, seed, env, 
     packed, cnt = synth.adversarial_table(k, m, 4, seed, low_complexity=60, dense=1)
     tab = table_from(packed, cnt, k)
     base, st0 = engine.hetmers_run(tab, symcheck="hash")
+    assert np.array_equal(base, _brute_cached(k, m, seed, packed, cnt)), "the default chain against the numpy oracle"
     for name, val in env.items():
         monkeypatch.setenv(name, val)
     plot, st = engine.hetmers_run(tab, symcheck="hash")
