@@ -175,7 +175,7 @@ def main():
     if args.k <= 32:
         p1 = "kf_pass1_d<1, %d, %s, %s>" % (1 if args.symcheck == "hash" else 2, tf(args.k & 1), tf(17 <= args.k))
     elif args.k <= 64:
-        p1 = "kf_pass1_d<2, 3, %s, false>" % tf(args.k & 1)
+        p1 = "kf_pass1_d<2, %d, %s, false>" % (2 if args.symcheck == "hash" else 3, tf(args.k & 1))
     else:
         p1 = "kf_pass1<3>"
     single = {"ms_pass1": p1, "ms_pass2": "kf_pass2<%d>" % ((args.k + 31) // 32)}
@@ -215,10 +215,12 @@ def main():
                                               "ms_bigfix": float(np.mean([s.get("ms_bigfix", 0.0) for s in eng_stats]))},
                          "lookup_phase_GBps": alg["ms_rclookup"] / (ms["ms_rclookup"] * 1e-3) / 1e9
                          if ms["ms_rclookup"] > 0 else 0.0,
-                         "whole_job_frac_of_22B_roofline":
+                         # whole job against B_alg(k) = 2 x (ceil(k/4) + 2) + 2 bytes per k-mer (22 at k = 31, 32 at k = 51)
+                         "whole_job_frac_of_the_B_alg_roofline":
                              (n_total * 2.0 * alg_bytes_per_kmer_pass(args.k) / (dt / args.steps)) / 1e9 / (HBM_PEAK_GBS * world)},
             "cpu_baseline": cpu,
             "pairs_in_plot": int(plot.sum().item()),
+            "hbm_peak_allocated_by_torch_GB": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),     # (the generator's peak)
         }
         print(json.dumps(out))
     if dist.is_initialized():

@@ -156,11 +156,6 @@ int smg_condition_table(const smg_table_view *table, const smg_opts *opts, uint6
 /* number of usable HIP devices (0 when there is none or the runtime is missing)             */
 int smg_device_count(void);
 
-/* Start the HIP runtime on `device` and load the engine's code object there (what the first call into the engine would
-   otherwise do: ~80 ms).  Thread safe and optional: the `hetmers` executable calls it from a helper thread while the
-   main thread opens and probes the table (the reference has nothing to hide here: its start-up is the page cache).
-   Returns SMG_OK or SMG_ENODEV.                                                                                    */
-int smg_device_warmup(int device);
 
 /* ---- engine object: device-resident table, phase-level calls ---------------------------
    Used by the one-shot entry, by bench.py and by the one-process-per-GPU sharded driver

@@ -350,9 +350,11 @@ template <int W> SMG_DEV int64_t sig_find(const FastArgs &A, const Key<W> &y, bo
 // chunk_fill != NULL : one workgroup per chunk of the local request list
 // chunk_fill == NULL : flat list of nflat records (received from other ranks), grid-stride
 
+// rw = words per record: W (the k-mer; its sender owns a pair at p > k-1-p, or it would not have sent) or W + 1
+// (+ count | has-such-a-pair << 16; only these can have their count checked)
 template <int W> __global__ void __launch_bounds__(F_TPB)
 kf_apply(FastArgs A, const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill,
-         int64_t nflat, int check_count, FastCtl *__restrict__ ctl)
+         int64_t nflat, int check_count, FastCtl *__restrict__ ctl, int rw)
 { int64_t first, count, stride;
   if (chunk_fill)
     { first = (int64_t) blockIdx.x * F_CH + threadIdx.x; count = (int64_t) blockIdx.x * F_CH + chunk_fill[blockIdx.x];
@@ -361,14 +363,15 @@ kf_apply(FastArgs A, const u64 *__restrict__ req, const uint32_t *__restrict__ c
   else
     { first = (int64_t) blockIdx.x * F_TPB + threadIdx.x; count = nflat; stride = (int64_t) gridDim.x * F_TPB; }
   for (int64_t r = first; r < count; r += stride)
-    { const u64 *q = req + r * (W + 1);
+    { const u64 *q = req + r * rw;
       Key<W> y;
 #pragma unroll
       for (int w = 0; w < W; w++) y.w[w] = q[w];
-      const u64 meta = q[W];
-      const int64_t j = sig_find<W>(A, y, check_count != 0);
+      const u64 meta = rw > W ? q[W] : 1ull << 16;
+      const bool cc = check_count && rw > W;
+      const int64_t j = sig_find<W>(A, y, cc);
       bool bad = j < 0;
-      if (!bad && check_count) bad = A.cnt[j] != (unsigned) (meta & 0xFFFF);
+      if (!bad && cc) bad = A.cnt[j] != (unsigned) (meta & 0xFFFF);
       if (bad) { if (ctl->missing == 0) ctl->missing = 1; continue; }
       if (meta >> 16 & 1) SET_P(A, j);
     }
@@ -545,17 +548,18 @@ kf_sortkey(const u64 *__restrict__ rec, int rw, int64_t n, uint32_t *__restrict_
 
 template <int W> __global__ void __launch_bounds__(F_TPB)
 kf_apply_indexed(FastArgs A, const u64 *__restrict__ rec, const uint32_t *__restrict__ perm, int64_t n,
-                 int check_count, FastCtl *__restrict__ ctl)
+                 int check_count, FastCtl *__restrict__ ctl, int rw)
 { const int64_t stride = (int64_t) gridDim.x * F_TPB;
   for (int64_t r = (int64_t) blockIdx.x * F_TPB + threadIdx.x; r < n; r += stride)
-    { const u64 *q = rec + (size_t) perm[r] * (W + 1);
+    { const u64 *q = rec + (size_t) perm[r] * rw;
       Key<W> y;
 #pragma unroll
       for (int w = 0; w < W; w++) y.w[w] = q[w];
-      const u64 meta = q[W];
-      const int64_t j = sig_find<W>(A, y, check_count != 0);
+      const u64 meta = rw > W ? q[W] : 1ull << 16;
+      const bool cc = check_count && rw > W;
+      const int64_t j = sig_find<W>(A, y, cc);
       bool bad = j < 0;
-      if (!bad && check_count) bad = A.cnt[j] != (unsigned) (meta & 0xFFFF);
+      if (!bad && cc) bad = A.cnt[j] != (unsigned) (meta & 0xFFFF);
       if (bad) { if (ctl->missing == 0) ctl->missing = 1; continue; }
       if (meta >> 16 & 1) SET_P(A, j);
     }
@@ -850,15 +854,16 @@ kf_route_scatter(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk
 
 // Deferred entries of kf_pass1_d: entries with a pair at distance 4..30 in the sorted table (0.8 % of the pairs of a
 // diploid table) and entries whose window block is longer than the +-30 entry window (repeats, low-complexity k-mers).
-// Pass 1 sets their bits in `dbits` (one bit per table entry); this kernel redoes every marked entry exactly -- final code
-// byte, map bit of a candidate, a request for an owner of a pair at p > k-1-p -- and clears the map for the next run.
-// Short blocks are walked entry by entry (all pairs inside the block), long ones by bisection (~800 dependent steps).
-// Marked entries are rare and scattered on ordinary tables (a bit in 1 of 25 words), so they are compacted through an LDS
-// queue and redone BF_TPB at a time with every lane busy; where a batch of words holds more bits than the queue (repeat
-// regions) every thread works through its own word.
+// Pass 1 sets their bits in `dbits` (one bit per table entry).  Two kernels redo them exactly:
+//   kf_collect  scans the bit map, clears it for the next run and compacts the marked entries into a list (one global
+//               atomic per workgroup and round: marked entries come in clusters -- whole repeat regions -- so the list,
+//               not the map, is what deals them out evenly);
+//   kf_bigfix   one entry per thread and round from that list: final code byte, map bit of a candidate, a request for an
+//               owner of a pair at p > k-1-p.  Short blocks are walked in batches of eight independent loads, blocks
+//               that reach past +-BF_LIN entries by bisection (~800 dependent steps).
+// (The first version of this round let every thread work through the bits of its own map words: 63 ms on the table
+//  with 5 % repeats, where a few workgroups owned all the work; the list takes 9.4e6 entries through in ~7 ms.)
 #define BF_TPB   1024
-#define BF_QCAP  6144                   // queued entries: a round adds at most BF_QADD to < BF_TPB left over
-#define BF_QADD  (BF_QCAP - BF_TPB)
 #define BF_LIN   48                     // blocks of up to ~2 * BF_LIN entries are walked linearly
 
 template <int W> SMG_DEV void
@@ -868,16 +873,20 @@ block_scan(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, int64
   // neighbours are therefore fetched eight at a time, independent loads in flight together -- a walk of one
   // dependent load per step took 0.19 us per entry with every lane of the chip busy.
   const Key<W> x = load_key<W>(keys, i);
+  // a block that reaches past the linear range on either side goes straight to the bisection
+  { const int64_t lo = i - BF_LIN - 1, hi = i + BF_LIN + 1;
+    const bool far_lo = lo >= 0 && same_block<W>(x, load_key<W>(keys, lo >= 0 ? lo : i), g);
+    const bool far_hi = hi < n && same_block<W>(x, load_key<W>(keys, hi < n ? hi : i), g);
+    if (far_lo || far_hi) { big_block_scan<W>(keys, cnt, n, g, i, s_all, s_hi, partner, w2); return; }
+  }
   const unsigned c = cnt[i];
   s_all = 0; s_hi = 0; partner = -1; w2 = 0;
-  bool over = false;
 #pragma unroll 1
   for (int dir = -1; dir <= 1; dir += 2)
     { bool open = true;
 #pragma unroll 1
-      for (int base = 1; open; base += 8)
-        { if (base > BF_LIN) { over = true; break; }
-          Key<W> y[8]; unsigned cy[8]; bool in[8];
+      for (int base = 1; open && base <= BF_LIN; base += 8)
+        { Key<W> y[8]; unsigned cy[8]; bool in[8];
 #pragma unroll
           for (int j = 0; j < 8; j++)
             { const int64_t q = i + (int64_t) dir * (base + j);
@@ -898,128 +907,109 @@ block_scan(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, int64
                 }
             }
         }
-      if (over) break;
     }
-  if (over) big_block_scan<W>(keys, cnt, n, g, i, s_all, s_hi, partner, w2);      // (a long block: bisection)
+}
+
+// marked entries of the bit map -> list[0 .. *count) (entries beyond `cap` are counted, not stored, and keep their
+// bits: the host grows the list and runs another round); a thread takes four map words (128 table entries) per round
+__global__ void __launch_bounds__(BF_TPB)
+kf_collect(uint32_t *__restrict__ dbits, int64_t nwords, uint32_t *__restrict__ list, unsigned cap, unsigned *__restrict__ count)
+{ __shared__ unsigned s_n[2], s_base[2];
+  const int t = threadIdx.x;
+  if (t < 2) s_n[t] = 0;
+  __syncthreads();
+  const int64_t nquads = nwords >> 2;
+  const int64_t rounds = (nquads + (int64_t) gridDim.x * BF_TPB - 1) / ((int64_t) gridDim.x * BF_TPB);
+  for (int64_t rd = 0; rd < rounds; rd++)
+    { const int par = (int) (rd & 1);
+      const int64_t wi = (rd * gridDim.x + blockIdx.x) * (int64_t) BF_TPB + t;
+      uint4 w4 = make_uint4(0, 0, 0, 0);
+      if (wi < nquads) w4 = reinterpret_cast<const uint4 *>(dbits)[wi];
+      const uint32_t w[4] = { w4.x, w4.y, w4.z, w4.w };
+      const unsigned c = (unsigned) (__popc(w[0]) + __popc(w[1]) + __popc(w[2]) + __popc(w[3]));
+      unsigned pos = 0;
+      if (c) pos = atomicAdd(&s_n[par], c);
+      __syncthreads();
+      const unsigned tot = s_n[par];
+      if (tot == 0) continue;                           // (nothing marked in these 131072 entries)
+      if (t == 0) s_base[par] = atomicAdd(count, tot);
+      __syncthreads();
+      const unsigned base = s_base[par];
+      if (t == 0) s_n[par] = 0;                         // (used again two rounds on, behind the barriers of the next round)
+      if (c && base + pos + c <= cap)
+        { unsigned o = base + pos;
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            for (uint32_t m = w[j]; m; m &= m - 1) list[o++] = (uint32_t) ((wi * 4 + j) * 32 + __ffs(m) - 1);
+          reinterpret_cast<uint4 *>(dbits)[wi] = make_uint4(0, 0, 0, 0);
+        }
+    }
 }
 
 template <int W, int RW> __global__ void __launch_bounds__(BF_TPB)
-kf_bigfix(FastArgs A, uint32_t *__restrict__ dbits, int64_t nwords, u64 *__restrict__ req,
+kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, const unsigned *__restrict__ pcount, unsigned cap, u64 *__restrict__ req,
           uint32_t *__restrict__ chunk_fill, unsigned max_chunks, FastCtl *__restrict__ ctl,
           unsigned *__restrict__ whist /* this kernel's rows */, unsigned owner0, unsigned owners, int hbits)
 { constexpr int rw = RW;
   __shared__ u64      sq[BF_TPB * RW];
   __shared__ unsigned hist[1024];       // requests of this workgroup per look-up bucket (a row of whist, like pass 1's)
-  __shared__ uint32_t q[BF_QCAP];
-  __shared__ unsigned s_qn, s_chunk, s_used, s_en, s_add[2], s_max[2], s_fixed;     // (s_add / s_max: one pair per round parity)
+  __shared__ unsigned s_qn, s_chunk, s_used;
   __shared__ u64      s_base, s_total;
   const int t = threadIdx.x;
-  if (t == 0) { s_qn = 0; s_chunk = F_NOCHUNK; s_used = 0; s_total = 0; s_en = 0; s_add[0] = s_add[1] = 0; s_max[0] = s_max[1] = 0; s_fixed = 0; }
+  if (t == 0) { s_qn = 0; s_chunk = F_NOCHUNK; s_used = 0; s_total = 0; }
   for (int b = t; b < 1024; b += BF_TPB) hist[b] = 0;
   __syncthreads();
-
-  // one entry: exact walk, final code byte, map bit, request (staged in sq)
-  auto fix = [&](int64_t i)
-  { unsigned s_all, s_hi, w2;
-    int64_t partner;
-    block_scan<W>(A.keys, A.cnt, A.n, A.g, i, s_all, s_hi, partner, w2);
-    A.code[i] = (uint8_t) make_code(s_all, partner - i, w2);
-    if (W <= 2 && A.bmap && s_all == 1)             // a candidate: mark its block for the request filter
-      { const uint32_t id = (uint32_t) (A.keys[i * W] >> 32) >> A.bmsh;
-        if (A.bm2) atomicOr(reinterpret_cast<u64 *>(A.bmap) + (id >> 5), bm2_bits(id, (uint32_t) A.keys[i * W]));
-        else atomicOr(&A.bmap[id >> 5], 1u << (id & 31));
-      }
-    if (s_hi > 0)
-      { const Key<W> kx = load_key<W>(A.keys, i);
-        const Key<W> rc = revcomp<W>(kx, A.g.k);
-        const unsigned qq = atomicAdd(&s_qn, 1u);
+  const unsigned nbig = *pcount;
+  if (nbig > cap) return;                // the list overflowed (it has holes at its end): the host grows it and redoes the run
+  for (unsigned r0 = blockIdx.x * BF_TPB; r0 < nbig; r0 += gridDim.x * BF_TPB)
+    { const unsigned r = r0 + t;
+      if (r < nbig)
+        { const int64_t i = biglist[r];
+          unsigned s_all, s_hi, w2;
+          int64_t partner;
+          block_scan<W>(A.keys, A.cnt, A.n, A.g, i, s_all, s_hi, partner, w2);
+          A.code[i] = (uint8_t) make_code(s_all, partner - i, w2);
+          if (W <= 2 && A.bmap && s_all == 1)             // a candidate: mark its block for the request filter
+            { const uint32_t id = (uint32_t) (A.keys[i * W] >> 32) >> A.bmsh;
+              if (A.bm2) atomicOr(reinterpret_cast<u64 *>(A.bmap) + (id >> 5), bm2_bits(id, (uint32_t) A.keys[i * W]));
+              else atomicOr(&A.bmap[id >> 5], 1u << (id & 31));
+            }
+          if (s_hi > 0)
+            { const Key<W> kx = load_key<W>(A.keys, i);
+              const Key<W> rc = revcomp<W>(kx, A.g.k);
+              const unsigned q = atomicAdd(&s_qn, 1u);
 #pragma unroll
-        for (int w = 0; w < W; w++) sq[qq * rw + w] = rc.w[w];
-        if (rw > W) sq[qq * rw + W] = (u64) A.cnt[i] | (1ull << 16);
-        if (whist && hbits) atomicAdd(&hist[(unsigned) (rc.w[0] >> 32) >> (32 - hbits)], 1u);
-      }
-  };
-  // the staged requests (<= BF_TPB) -> this workgroup's chunk; called by every thread
-  auto flush = [&]()
-  { __syncthreads();
-    const unsigned qn = s_qn;
-    if (qn > 0)
-      { if (t == 0)
-          { if (s_chunk == F_NOCHUNK || s_used + qn > F_CH)
-              { if (s_chunk != F_NOCHUNK && s_chunk < max_chunks) chunk_fill[s_chunk] = s_used;
-                // (look-up chain: chunk slots owner, owner + owners, .. as in pass 1; this kernel's owners follow pass 1's)
-                if (whist && hbits) s_chunk = s_chunk == F_NOCHUNK ? owner0 + blockIdx.x : s_chunk + owners;
-                else s_chunk = atomicAdd(&ctl->n_chunks, 1u);
-                s_used = 0;
-              }
-            s_base = (u64) s_chunk * F_CH + s_used;
-            s_used += qn; s_total += qn; s_qn = 0;
-          }
-        __syncthreads();
-        if (s_chunk < max_chunks)
-          { u64 *o = req + s_base * rw;
-            for (unsigned e = t; e < qn * rw; e += BF_TPB) o[e] = sq[e];
-          }
-      }
-    __syncthreads();
-  };
-
-  // a thread takes four map words (128 table entries) per round; nwords is a multiple of 4
-  const int64_t nquads = nwords >> 2;
-  const int64_t rounds = (nquads + (int64_t) gridDim.x * BF_TPB - 1) / ((int64_t) gridDim.x * BF_TPB);
-  for (int64_t rd = 0; rd < rounds; rd++)
-    { const int64_t wi = (rd * gridDim.x + blockIdx.x) * (int64_t) BF_TPB + t;
-      uint4 w4 = make_uint4(0, 0, 0, 0);
-      if (wi < nquads)
-        { w4 = reinterpret_cast<const uint4 *>(dbits)[wi];
-          if (w4.x | w4.y | w4.z | w4.w) reinterpret_cast<uint4 *>(dbits)[wi] = make_uint4(0, 0, 0, 0);
+              for (int w = 0; w < W; w++) sq[q * rw + w] = rc.w[w];
+              if (rw > W) sq[q * rw + W] = (u64) A.cnt[i] | (1ull << 16);
+              if (whist && hbits) atomicAdd(&hist[(unsigned) (rc.w[0] >> 32) >> (32 - hbits)], 1u);
+            }
         }
-      uint32_t w[4] = { w4.x, w4.y, w4.z, w4.w };
-      const unsigned c = (unsigned) (__popc(w[0]) + __popc(w[1]) + __popc(w[2]) + __popc(w[3]));
-      const int par = (int) (rd & 1);
-      unsigned pos = 0;
-      if (c) { pos = atomicAdd(&s_add[par], c); atomicMax(&s_max[par], c); }
       __syncthreads();
-      const unsigned add = s_add[par], en = s_en, mx = s_max[par];
-      if (add == 0) continue;                            // (nothing marked in this round: the counters are still zero)
-      __syncthreads();
-      if (t == 0) { s_add[par] = 0; s_max[par] = 0; }     // (next used two rounds on, behind the barriers of the next round)
-      if (add <= BF_QADD)
-        { // sparse: queue the marked entries, redo them BF_TPB at a time
-#pragma unroll
-          for (int j = 0; j < 4; j++)
-            for (uint32_t m = w[j]; m; m &= m - 1) q[en + pos++] = (uint32_t) ((wi * 4 + j) * 32 + __ffs(m) - 1);
-          unsigned have = en + add;
+      const unsigned qn = s_qn;
+      if (qn > 0)
+        { if (t == 0)
+            { if (s_chunk == F_NOCHUNK || s_used + qn > F_CH)
+                { if (s_chunk != F_NOCHUNK && s_chunk < max_chunks) chunk_fill[s_chunk] = s_used;
+                  // (look-up chain: chunk slots owner, owner + owners, .. as in pass 1; this kernel's owners follow pass 1's)
+                  if (whist && hbits) s_chunk = s_chunk == F_NOCHUNK ? owner0 + blockIdx.x : s_chunk + owners;
+                  else s_chunk = atomicAdd(&ctl->n_chunks, 1u);
+                  s_used = 0;
+                }
+              s_base = (u64) s_chunk * F_CH + s_used;
+              s_used += qn; s_total += qn; s_qn = 0;
+            }
           __syncthreads();
-          while (have >= BF_TPB)
-            { fix((int64_t) q[have - BF_TPB + t]);
-              have -= BF_TPB;
-              flush();
+          if (s_chunk < max_chunks)
+            { u64 *o = req + s_base * rw;
+              for (unsigned e = t; e < qn * rw; e += BF_TPB) o[e] = sq[e];
             }
-          if (t == 0) { s_en = have; s_fixed += en + add - have; }
-        }
-      else
-        { // dense (repeat region): every thread works through its own words, one entry per step
-          int j = 0;
-          for (unsigned step = 0; step < mx; step++)
-            { while (j < 4 && w[j] == 0) j++;
-              if (j < 4) { fix((wi * 4 + j) * 32 + __ffs(w[j]) - 1); w[j] &= w[j] - 1; }
-              flush();
-            }
-          if (t == 0) s_fixed += add;
         }
       __syncthreads();
     }
-  { const unsigned have = s_en;                     // what is left in the queue
-    if ((unsigned) t < have) fix((int64_t) q[t]);
-    flush();
-    if (t == 0) s_fixed += have;
-  }
   if (t == 0)
     { if (s_chunk != F_NOCHUNK && s_chunk < max_chunks) chunk_fill[s_chunk] = s_used;
       if (whist && hbits && s_chunk != F_NOCHUNK) atomicMax(&ctl->n_chunks, s_chunk + 1u);
       if (s_total) atomicAdd(&ctl->nreq, s_total);
-      if (s_fixed) atomicAdd(&ctl->nbig, s_fixed);
     }
   if (whist && hbits)
     for (int b = t; b < 1024; b += BF_TPB) whist[(size_t) blockIdx.x * 1024 + b] = hist[b];

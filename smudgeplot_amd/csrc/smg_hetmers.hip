@@ -230,6 +230,30 @@ k_directory(Tab t, uint32_t *__restrict__ bstart, Ctrl *__restrict__ ctrl)
   else bstart[t.dir.nb] = (uint32_t) t.n;
 }
 
+// ---- the general path over a table that is cut into prefix shards ON ONE DEVICE (more than 2^32 entries) -----------
+// The prefix-side partner of an entry (the k-mer with one of its first p0 bases replaced) may live in another shard:
+// the look-up first picks the shard whose k-mer range holds it (<= 16 comparisons with the shards' first k-mers), then
+// searches that shard's directory.  Window blocks never straddle a cut, so everything else stays shard local.
+#define SET_MAX 16
+struct TabSet
+{ int ns;
+  Tab shard[SET_MAX];
+  u64 first[SET_MAX][4];       // first k-mer of shard s (all ones for an empty shard behind the last one)
+};
+
+template <int W> SMG_DEV int set_find(const TabSet *set, const Key<W> &y, int64_t &j)
+{ int s = 0;
+  for (int q = 1; q < set->ns; q++)
+    { Key<W> f;
+#pragma unroll
+      for (int w = 0; w < W; w++) f.w[w] = set->first[q][w];
+      if (!key_lt<W>(y, f)) s = q;
+    }
+  const Tab &t = set->shard[s];
+  j = t.n > 0 ? find_key<W>(t.keys, t.dir, y) : -1;
+  return s;
+}
+
 // ---- pass 1 -------------------------------------------------------------------------------
 // One thread per entry.  SYM: scan positions >= p0 inside the window block, write
 // deg = S_all, emit a request (rc(x), cnt, S_hi) when S_hi > 0 (or for every entry when
@@ -238,7 +262,7 @@ k_directory(Tab t, uint32_t *__restrict__ bstart, Ctrl *__restrict__ ctrl)
 
 template <int W, bool SYM> __global__ void __launch_bounds__(TPB)
 k_pass1(Tab t, int64_t lo, int64_t hi, int emit_all, int want_fp, u64 *__restrict__ req,
-        int64_t req_cap, Ctrl *__restrict__ ctrl)
+        int64_t req_cap, Ctrl *__restrict__ ctrl, const TabSet *__restrict__ set = NULL)
 { const int64_t i = lo + (int64_t) blockIdx.x * TPB + threadIdx.x;
   const bool live = i < hi;
   const Geo g = t.g;
@@ -296,8 +320,16 @@ k_pass1(Tab t, int64_t lo, int64_t hi, int emit_all, int want_fp, u64 *__restric
       if (!SYM)
         { for (int p = 0; p < g.p0; p++)
             for (int d = 1; d <= 3; d++)
-              { const int64_t j = find_key<W>(t.keys, t.dir, flip_base<W>(x, p, d));
-                if (j >= 0 && c + (unsigned) t.cnt[j] <= SMG_SMAX) s_all++;
+              { const Key<W> y = flip_base<W>(x, p, d);
+                if (set)                      // (the partner may live in another shard of the same device)
+                  { int64_t j;
+                    const int sh = set_find<W>(set, y, j);
+                    if (j >= 0 && c + (unsigned) set->shard[sh].cnt[j] <= SMG_SMAX) s_all++;
+                  }
+                else
+                  { const int64_t j = find_key<W>(t.keys, t.dir, y);
+                    if (j >= 0 && c + (unsigned) t.cnt[j] <= SMG_SMAX) s_all++;
+                  }
               }
         }
       t.deg[i] = (uint8_t) s_all;
@@ -378,7 +410,7 @@ SMG_DEV void plot_add(u64 *__restrict__ plot, unsigned ci, unsigned cj, unsigned
 }
 
 template <int W, bool SYM> __global__ void __launch_bounds__(TPB)
-k_pass2(Tab t, int64_t lo, int64_t hi, u64 *__restrict__ plot)
+k_pass2(Tab t, int64_t lo, int64_t hi, u64 *__restrict__ plot, const TabSet *__restrict__ set = NULL)
 { const int64_t i = lo + (int64_t) blockIdx.x * TPB + threadIdx.x;
   if (i >= hi) return;
   const Geo g = t.g;
@@ -430,10 +462,20 @@ k_pass2(Tab t, int64_t lo, int64_t hi, u64 *__restrict__ plot)
         for (int d = 1; d <= 3; d++)
           { const Key<W> y = flip_base<W>(x, p, d);
             if (!key_lt<W>(x, y)) continue;
-            const int64_t j = find_key<W>(t.keys, t.dir, y);
-            if (j >= 0)
-              { const unsigned cj = t.cnt[j];
-                if (c + cj <= SMG_SMAX && t.deg[j] <= 1) plot_add(plot, c, cj, 1);
+            if (set)
+              { int64_t j;
+                const int sh = set_find<W>(set, y, j);
+                if (j >= 0)
+                  { const unsigned cj = set->shard[sh].cnt[j];
+                    if (c + cj <= SMG_SMAX && set->shard[sh].deg[j] <= 1) plot_add(plot, c, cj, 1);
+                  }
+              }
+            else
+              { const int64_t j = find_key<W>(t.keys, t.dir, y);
+                if (j >= 0)
+                  { const unsigned cj = t.cnt[j];
+                    if (c + cj <= SMG_SMAX && t.deg[j] <= 1) plot_add(plot, c, cj, 1);
+                  }
               }
           }
     }
@@ -539,6 +581,7 @@ struct smg_engine
   uint32_t    *sidx[2]; int64_t sidx_cap[2];   //                                  record numbers (in, out)
   uint32_t    *dbits;  int64_t dbits_cap;      // deferred entries of kf_pass1_d: one bit per table entry (bytes); all zero between runs
   bool         dbits_dirty;                     //   ... unless a run was abandoned between pass 1 and kf_bigfix
+  uint32_t    *biglist; int64_t biglist_cap;    // the marked entries, compacted (kf_collect), bytes
   int          rw;                           // 64-bit words per request record
   uint32_t    *chunk_fill; int64_t chunk_cap; // bytes
   unsigned     max_chunks;
@@ -604,20 +647,6 @@ extern "C" int smg_device_count(void)
   return n;
 }
 
-__global__ void k_warm(unsigned *p) { if (p && threadIdx.x == 0) *p = 1u; }
-
-extern "C" int smg_device_warmup(int device)
-{ int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return SMG_ENODEV;
-  if (hipSetDevice(device) != hipSuccess) return SMG_ENODEV;
-  unsigned *p = NULL;
-  if (hipMalloc(&p, 256) != hipSuccess) return SMG_ENODEV;
-  hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, 0, p);       // (the first launch loads the code object)
-  const hipError_t he = hipDeviceSynchronize();
-  hipFree(p);
-  return he == hipSuccess ? SMG_OK : SMG_ENODEV;
-}
-
 extern "C" smg_engine *smg_engine_create(int device, void *stream, char *errbuf, size_t errlen)
 { int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
@@ -656,7 +685,7 @@ extern "C" void smg_engine_destroy(smg_engine *e)
   hipSetDevice(e->device);
   hipStreamSynchronize(e->stream);
   hipFree(e->own_keys); hipFree(e->own_cnt); hipFree(e->deg); hipFree(e->sig); hipFree(e->bstart);
-  hipFree(e->req); hipFree(e->req2); hipFree(e->sort_tmp); hipFree(e->dense); hipFree(e->chunk_off); hipFree(e->skey[0]); hipFree(e->skey[1]); hipFree(e->sidx[0]); hipFree(e->sidx[1]); hipFree(e->dbits); hipFree(e->chunk_fill); hipFree(e->bmap); hipFree(e->reqf); hipFree(e->chunk_fillf); hipFree(e->route_cnt); hipFree(e->route_off);
+  hipFree(e->req); hipFree(e->req2); hipFree(e->sort_tmp); hipFree(e->dense); hipFree(e->chunk_off); hipFree(e->skey[0]); hipFree(e->skey[1]); hipFree(e->sidx[0]); hipFree(e->sidx[1]); hipFree(e->dbits); hipFree(e->biglist); hipFree(e->chunk_fill); hipFree(e->bmap); hipFree(e->reqf); hipFree(e->chunk_fillf); hipFree(e->route_cnt); hipFree(e->route_off);
   hipFree(e->partials); hipFree(e->ctrl); hipFree(e->d_split); hipFree(e->p1cold); hipFree(e->ghist); hipFree(e->boff);
   hipFree(e->whist);
   hipHostFree(e->h_ctrl); hipHostFree(e->h_partials); hipHostFree(e->h_p1cold);
@@ -950,6 +979,53 @@ static int run_general(smg_engine *e, int64_t *d_plot, char *errbuf, size_t errl
   return SMG_OK;
 }
 
+// the general path of ONE shard of a table whose shards all live on this device (smg_multi.hpp: virtual shards): step 1
+// builds the directory and the degree array (then the caller collects the Tabs of all shards into a TabSet on the
+// device), step 2 = pass 1 (degrees, over all positions), step 3 = pass 2 -- a barrier between the steps is the caller's.
+static int general_shard_prepare(smg_engine *e, Tab *out, char *errbuf, size_t errlen)
+{ int rc = counted_prepare(e, errbuf, errlen);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  *out = make_tab(e);
+  return SMG_OK;
+}
+
+static int general_shard_pass(smg_engine *e, const TabSet *d_set, int pass, int64_t *d_plot, char *errbuf, size_t errlen)
+{ const unsigned nblk = (unsigned) ((e->n + TPB - 1) / TPB);
+  Tab t = make_tab(e);
+  if (pass == 1)
+    { hipEventRecord(e->ev[2], e->stream);
+      if (e->n > 0)
+        {
+#define CALL(WW) hipLaunchKernelGGL((k_pass1<WW, false>), dim3(nblk), dim3(TPB), 0, e->stream, t, \
+                   (int64_t) 0, e->n, 0, 0, (u64 *) NULL, (int64_t) 0, e->ctrl, d_set)
+          DISPATCH_W(e, CALL)
+#undef CALL
+        }
+      hipEventRecord(e->ev[3], e->stream);
+    }
+  else
+    { HIPCHK(hipMemsetAsync(d_plot, 0, sizeof(int64_t) * SMG_PLOT_CELLS, e->stream));
+      hipEventRecord(e->ev[6], e->stream);
+      if (e->n > 0)
+        {
+#define CALL(WW) hipLaunchKernelGGL((k_pass2<WW, false>), dim3(nblk), dim3(TPB), 0, e->stream, t, \
+                   (int64_t) 0, e->n, (u64 *) d_plot, d_set)
+          DISPATCH_W(e, CALL)
+#undef CALL
+        }
+      hipEventRecord(e->ev[7], e->stream);
+    }
+  HIPCHK(hipGetLastError());
+  int rc = read_ctrl(e, errbuf, errlen);
+  if (rc) return rc;
+  if (e->h_ctrl->unsorted) return fail(errbuf, errlen, SMG_EFORMAT, "table entries are not strictly increasing%s");
+  float ms = 0;
+  if (pass == 1) { hipEventElapsedTime(&ms, e->ev[2], e->ev[3]); e->st.ms_pass1 += ms; }
+  else { hipEventElapsedTime(&ms, e->ev[6], e->ev[7]); e->st.ms_pass2 = ms; e->st.path = 2; }
+  return SMG_OK;
+}
+
 // ---- fast path (k <= 85) --------------------------------------------------------------------------
 
 static FastArgs make_fast(smg_engine *e)
@@ -967,12 +1043,14 @@ static FastArgs make_fast(smg_engine *e)
 static int bm_id_bits(int kmer, int cap);
 // (k = 1 has no prefix bases to name a block by)
 static bool filter_ok(const smg_engine *e)
-{ return e->kmer >= 2 && ((e->W == 1 && e->rw == 1) || (e->W == 2 && e->rw == 3) || (e->W == 3 && e->rw == 4)); }
+{ return e->kmer >= 2 && ((e->W == 1 && e->rw == 1) || (e->W == 2 && e->rw != 1) || (e->W == 3 && e->rw == 4)); }
 
 static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, char *errbuf, size_t errlen)
 { int rc;
   // record = the complement k-mer (W words) [+ one word: count | has-hi-pair << 16]
-  e->rw = e->W + ((with_meta || e->W > 1) ? 1 : 0);
+  // (two-word k-mers send key-only records for the hash proof as one-word ones do: 16 instead of 24 bytes for 21.6 % of
+  //  the entries at k = 51; three-word k-mers go through the generic kernel, whose records always carry the count word)
+  e->rw = e->W + ((with_meta || e->W > 2) ? 1 : 0);
   HIPCHK(hipMemsetAsync(e->ctrl, 0, sizeof(Ctrl), e->stream));
   set_geo(e);
   e->fast = true; e->counted_done = false;
@@ -1040,6 +1118,7 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
           // (the ODD / KF variants of one (W, RW) class use the same registers and LDS: ask for one of them)
           if (e->W == 1 && e->rw == 1) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kf_pass1_d<1, 1, true, true>, D_TPB, 0);
           else if (e->W == 1)          he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kf_pass1_d<1, 2, true, true>, D_TPB, 0);
+          else if (e->rw == 2)         he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kf_pass1_d<2, 2, true, false>, D_TPB, 0);
           else                         he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kf_pass1_d<2, 3, true, false>, D_TPB, 0);
           if (he != hipSuccess || nb < 1) nb = 3;
           if (nb > 8) nb = 8;
@@ -1061,8 +1140,9 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
     { if (e->dbits_cap < dwords * 4) e->dbits_dirty = true;                 // (fresh memory)
       if ((rc = grow(&e->dbits, &e->dbits_cap, dwords * 4, errbuf, errlen))) return rc;
     }
+  int64_t want_big = e->n / 16 + 4096;      // deferred entries: 0.13 % of the diploid table, 0.4 % with 5 % repeats
   bool done = false;
-  for (int attempt = 0; attempt < 4 && !done; attempt++)
+  for (int attempt = 0; attempt < 5 && !done; attempt++)
     { unsigned maxc = (unsigned) ((want_rec + F_CH - 1) / F_CH);
       if (e->lg.nb)
         { // look-up chain: owner w fills the slots w, w + G, w + 2G, .. (G = workgroups of this launch + those of kf_bigfix),
@@ -1105,7 +1185,8 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
                               (const P1Cold *) e->p1cold)
 #define LAUNCH_R2(RW_, ODD_) { if (kf) LAUNCH_R(1, RW_, ODD_, true); else LAUNCH_R(1, RW_, ODD_, false); }
           const bool kf = gr.pshift < 32 && gr.kshift < 32;          // 17 <= k <= 32
-          if (e->W == 2)       { if (odd) LAUNCH_R(2, 3, true, false); else LAUNCH_R(2, 3, false, false); }
+          if (e->W == 2 && e->rw == 2) { if (odd) LAUNCH_R(2, 2, true, false); else LAUNCH_R(2, 2, false, false); }
+          else if (e->W == 2)  { if (odd) LAUNCH_R(2, 3, true, false); else LAUNCH_R(2, 3, false, false); }
           else if (e->rw == 1) { if (odd) LAUNCH_R2(1, true) else LAUNCH_R2(1, false) }
           else                 { if (odd) LAUNCH_R2(2, true) else LAUNCH_R2(2, false) }
 #undef LAUNCH_R2
@@ -1122,17 +1203,24 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
       HIPCHK(hipGetLastError());
       if (want_fp)
         HIPCHK(hipMemcpyAsync(e->h_partials, e->partials, sizeof(u64) * 4 * grid, hipMemcpyDeviceToHost, e->stream));
+      unsigned bigcap = 0;
       if (narrow)
-        { // exact redo of the deferred entries (a pair at distance 4..30, or a window block longer than the window): the
-          // kernel scans the bit map pass 1 marked them in and leaves it cleared.  Launched without waiting for pass 1's
-          // control words (a request list that overflowed is guarded on the device; the run is redone below either way).
-          unsigned fb = (unsigned) ((dwords / 4 + BF_TPB - 1) / BF_TPB);
-          if (fb > BF_MAXGRID) fb = BF_MAXGRID;
-#define BIGFIX(W_, RW_) hipLaunchKernelGGL((kf_bigfix<W_, RW_>), dim3(fb), dim3(BF_TPB), 0, e->stream, a, e->dbits, dwords, e->req, \
+        { // exact redo of the deferred entries (a pair at distance 4..30, or a window block longer than the window):
+          // kf_collect compacts the bit map pass 1 marked them in into a list (and clears it), kf_bigfix redoes the list.
+          // Launched without waiting for pass 1's control words (a request list that overflowed is guarded on the
+          // device; the run is redone below either way, and so it is when the list of deferred entries was too short).
+          if (want_big < e->biglist_cap / 4) want_big = e->biglist_cap / 4;
+          if (want_big > 0xFFFFFFF0ll) want_big = 0xFFFFFFF0ll;
+          if ((rc = grow(&e->biglist, &e->biglist_cap, want_big * 4, errbuf, errlen))) return rc;
+          bigcap = (unsigned) (e->biglist_cap / 4 > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : e->biglist_cap / 4);
+          unsigned cb = (unsigned) ((dwords / 4 + BF_TPB - 1) / BF_TPB);
+          if (cb > BF_MAXGRID) cb = BF_MAXGRID;
+          hipEventRecord(e->ev[0], e->stream);
+          hipLaunchKernelGGL(kf_collect, dim3(cb), dim3(BF_TPB), 0, e->stream, e->dbits, dwords, e->biglist, bigcap, &e->ctrl->fast.nbig);
+#define BIGFIX(W_, RW_) hipLaunchKernelGGL((kf_bigfix<W_, RW_>), dim3(BF_MAXGRID), dim3(BF_TPB), 0, e->stream, a, e->biglist, &e->ctrl->fast.nbig, bigcap, e->req, \
                               e->chunk_fill, maxc, &e->ctrl->fast, e->lg.nb ? e->whist + (size_t) grid * L_BK : (unsigned *) NULL, \
                               grid, grid + BF_MAXGRID, e->lg.nb)
-          hipEventRecord(e->ev[0], e->stream);
-          if (e->W == 2) BIGFIX(2, 3); else if (e->rw == 1) BIGFIX(1, 1); else BIGFIX(1, 2);
+          if (e->W == 2 && e->rw == 2) BIGFIX(2, 2); else if (e->W == 2) BIGFIX(2, 3); else if (e->rw == 1) BIGFIX(1, 1); else BIGFIX(1, 2);
 #undef BIGFIX
           hipEventRecord(e->ev[3], e->stream);
           HIPCHK(hipGetLastError());
@@ -1141,6 +1229,13 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
       e->dbits_dirty = false;
       if (e->h_ctrl->fast.unsorted)
         return fail(errbuf, errlen, SMG_EFORMAT, "table entries are not strictly increasing%s");
+      if (narrow && e->h_ctrl->fast.nbig > bigcap)
+        { // more deferred entries than the list holds (a repeat-dominated table): size it from the count and redo
+          want_big = (int64_t) e->h_ctrl->fast.nbig + (int64_t) e->h_ctrl->fast.nbig / 8 + 4096;
+          e->dbits_dirty = true;                  // (the bits of the entries that did not fit are still set)
+          HIPCHK(hipMemsetAsync(&e->ctrl->fast, 0, sizeof(FastCtl), e->stream));
+          continue;
+        }
       if (e->h_ctrl->fast.n_chunks > maxc)
         { // the request list outgrew its first-guess capacity: size it from the count and redo
           want_rec = (int64_t) (e->h_ctrl->fast.n_chunks + 16 + 256) * F_CH;
@@ -1224,7 +1319,7 @@ static int apply_indexed(smg_engine *e, const u64 *rec, int64_t n, int check_cou
   if (n < SORT_MIN || n >= 0xFFFFFFF0ll)
     {
 #define CALL(WW) hipLaunchKernelGGL(kf_apply<WW>, dim3((unsigned) (nb > 8192 ? 8192 : nb)), dim3(F_TPB), 0, e->stream, a, rec, \
-                   (const uint32_t *) NULL, n, check_count, &e->ctrl->fast)
+                   (const uint32_t *) NULL, n, check_count, &e->ctrl->fast, e->rw)
       DISPATCH_W3(e, CALL)
 #undef CALL
       return SMG_OK;
@@ -1233,7 +1328,7 @@ static int apply_indexed(smg_engine *e, const u64 *rec, int64_t n, int check_cou
     { if ((rc = grow(&e->skey[q], &e->skey_cap[q], n * 4 + 16, errbuf, errlen))) return rc;
       if ((rc = grow(&e->sidx[q], &e->sidx_cap[q], n * 4 + 16, errbuf, errlen))) return rc;
     }
-  hipLaunchKernelGGL(kf_sortkey, dim3((unsigned) nb), dim3(F_TPB), 0, e->stream, rec, e->W + 1, n, e->skey[0], e->sidx[0]);
+  hipLaunchKernelGGL(kf_sortkey, dim3((unsigned) nb), dim3(F_TPB), 0, e->stream, rec, e->rw, n, e->skey[0], e->sidx[0]);
   size_t tmp = 0;
   HIPCHK(rocprim::radix_sort_pairs<smg_sort_config>(nullptr, tmp, e->skey[0], e->skey[1], e->sidx[0], e->sidx[1], (size_t) n,
                                                     8u, 32u, e->stream));
@@ -1241,7 +1336,7 @@ static int apply_indexed(smg_engine *e, const u64 *rec, int64_t n, int check_cou
   HIPCHK(rocprim::radix_sort_pairs<smg_sort_config>(e->sort_tmp, tmp, e->skey[0], e->skey[1], e->sidx[0], e->sidx[1], (size_t) n,
                                                     8u, 32u, e->stream));
 #define CALL(WW) hipLaunchKernelGGL(kf_apply_indexed<WW>, dim3((unsigned) nb), dim3(F_TPB), 0, e->stream, a, rec, e->sidx[1], n, \
-                   check_count, &e->ctrl->fast)
+                   check_count, &e->ctrl->fast, e->rw)
   DISPATCH_W3(e, CALL)
 #undef CALL
   return SMG_OK;
@@ -1357,6 +1452,9 @@ static int fast_filter(smg_engine *e, const uint32_t *map, char *errbuf, size_t 
                        map, 64 - nbits, e->reqf, e->chunk_fillf, maxout, &e->ctrl->fast);
   else if (e->rw == 1)
     hipLaunchKernelGGL(kf_filter<1>, dim3(grid), dim3(F_TPB), 0, e->stream, e->req, e->chunk_fill, e->n_chunks, (int64_t) 0,
+                       map, 64 - nbits, e->reqf, e->chunk_fillf, maxout, &e->ctrl->fast);
+  else if (e->rw == 2)
+    hipLaunchKernelGGL(kf_filter<2>, dim3(grid), dim3(F_TPB), 0, e->stream, e->req, e->chunk_fill, e->n_chunks, (int64_t) 0,
                        map, 64 - nbits, e->reqf, e->chunk_fillf, maxout, &e->ctrl->fast);
   else if (e->rw == 3)
     hipLaunchKernelGGL(kf_filter<3>, dim3(grid), dim3(F_TPB), 0, e->stream, e->req, e->chunk_fill, e->n_chunks, (int64_t) 0,
@@ -2185,8 +2283,12 @@ static int host_run(const smg_table_source *tv, const smg_opts *opts, int64_t *p
           { smg_opts o; memset(&o, 0, sizeof(o));
             if (opts) o = *opts; else o.symcheck = SMG_SYM_HASH;
             const int mrc = host_run_multi(tv, &o, ng == -1 ? 1 : ng, virt, plot, stats, errbuf, errlen);
-            // a table that fails the symmetry proof: the shards cannot help each other, one GPU takes the general path
-            if (mrc != SMG_ENOTSYM || tv->nels >= 0xFFFFFFF0ll - 16) return mrc;
+            // a table that fails the symmetry proof: shards on ONE device run the general path together (smg_multi.hpp,
+            // TabSet); several real GPUs hand the table to one of them, which can hold it as long as it has < 2^32 entries
+            if (mrc != SMG_ENOTSYM) return mrc;
+            if (tv->nels >= 0xFFFFFFF0ll - 16)
+              return fail(errbuf, errlen, SMG_ENOTSYM, "the table is not closed under reverse complement and has more than 2^32 entries: "
+                          "the general path for such a table runs on one device (unset SMUDGEPLOT_GPUS), or condition the table%s");
             if (verbose) fprintf(stderr, "  [smg] the table is not closed under reverse complement: general path on one GPU\n");
           }
       }

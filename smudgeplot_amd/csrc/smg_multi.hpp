@@ -79,6 +79,9 @@ struct MultiCtx
   RcclApi  api;
   ncclComm_t comm[SMG_MAXGPU];
   int64_t *plot;                            // result (host), written by rank 0
+  Tab      gtab[SMG_MAXGPU];                // general path over virtual shards: the shards' tables ...
+  TabSet  *d_set;                           // ... collected on the device by rank 0
+  int      general;                         // 1: the table failed the proof and the shards run the general path together
 };
 
 struct MultiArg { MultiCtx *c; int r; };
@@ -317,11 +320,38 @@ static void *multi_worker(void *argp)
       for (int s = 0; s < n; s++) { miss += c->missing[s]; for (int q = 0; q < 4; q++) f[q] ^= c->fp[s][q]; }
       bool symmetric = miss == 0;
       if (c->symcheck == SMG_SYM_HASH) symmetric = symmetric && f[0] == f[2] && f[1] == f[3];
-      if (!symmetric)
+      if (!symmetric && c->virt)
+        c->general = 1;                       // (every rank computes the same verdict from the same published words)
+      else if (!symmetric)
         MFAIL(SMG_ENOTSYM, "the table is not closed under reverse complement with equal counts: "
                            "a multi-GPU run needs a conditioned table (use one GPU for this one)");
     }
-  if (MOK && (c->rc[r] = smg_engine_pass2(e, d_plot, eb, el))) c->failed = 1;
+  const bool go_pass2 = multi_agree(c);                                                  // C1: verdict known to all
+  if (go_pass2 && c->general)
+    { // The reference answers for ANY sorted table (it only spot-checks the symmetry, PloidyPlot.c:1199-1229): so do
+      // the shards of one device, together -- both passes over all k positions, a prefix-side partner looked up in
+      // whichever shard holds it (TabSet).  Several real GPUs hand such a table to one GPU instead (host_run).
+      if (MOK && (c->rc[r] = general_shard_prepare(e, &c->gtab[r], eb, el))) c->failed = 1;
+      pthread_barrier_wait(&c->bar);                                                     // G1: directories built
+      if (MOK && r == 0)
+        { TabSet hs; memset(&hs, 0, sizeof(hs));
+          hs.ns = n;
+          for (int s = 0; s < n; s++)
+            { hs.shard[s] = c->gtab[s];
+              for (int w = 0; w < 4; w++) hs.first[s][w] = w < W ? c->first[s][w] : 0;
+            }
+          if (hipMalloc(&c->d_set, sizeof(TabSet)) != hipSuccess
+              || hipMemcpy(c->d_set, &hs, sizeof(TabSet), hipMemcpyHostToDevice) != hipSuccess)
+            MFAIL(SMG_ENOMEM, "out of device memory for the shard set");
+        }
+      pthread_barrier_wait(&c->bar);                                                     // G2: shard set published
+      if (MOK && (c->rc[r] = general_shard_pass(e, c->d_set, 1, d_plot, eb, el))) c->failed = 1;
+      pthread_barrier_wait(&c->bar);                                                     // G3: all degrees final
+      if (MOK && (c->rc[r] = general_shard_pass(e, c->d_set, 2, d_plot, eb, el))) c->failed = 1;
+      pthread_barrier_wait(&c->bar);                                                     // G4: nobody reads the set any more
+      if (r == 0 && c->d_set) { hipFree(c->d_set); c->d_set = NULL; }
+    }
+  else if (go_pass2 && MOK && (c->rc[r] = smg_engine_pass2(e, d_plot, eb, el))) c->failed = 1;
   const bool go_reduce = multi_agree(c);                                                 // C2: all in, or all out
   if (go_reduce && c->virt)
     { c->h_plot[r] = (int64_t *) malloc(sizeof(int64_t) * SMG_PLOT_CELLS);
@@ -441,7 +471,7 @@ static int host_run_multi(const smg_table_source *tv, const smg_opts *opts, int 
   hipEventDestroy(t0); hipEventDestroy(t1);
   if (rc == SMG_OK)
     { smg_stats st; memset(&st, 0, sizeof(st));
-      st.path = 1; st.key_words = c->W;
+      st.path = c->general ? 2 : 1; st.key_words = c->W;
       for (int r = 0; r < ngpus; r++)
         { st.nels += c->st[r].nels; st.nrequests += c->st[r].nrequests; st.nemitted += c->st[r].nemitted;
 #define MX(f) if (c->st[r].f > st.f) st.f = c->st[r].f

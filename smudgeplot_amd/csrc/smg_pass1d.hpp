@@ -274,7 +274,7 @@ SMG_DEV bool d_code_uq(unsigned c) { return ((c & 63u) - 1u) < 62u && c < 128u; 
 template <int W, int RW, bool ODD, bool KF, bool INNER> SMG_DEV void
 d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64 &fa, u64 &fb, DPrefetch<W> &pf)
 { typedef typename DWord<W>::type WT;
-  constexpr bool D_BM = (W == 1 && RW == 1) || (W == 2 && RW == 3);     // variants that feed the request filter
+  constexpr bool D_BM = (W == 1 && RW == 1) || (W == 2 && RW != 1);     // variants that feed the request filter
   const GeoR &G = A.G;
   const int lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);       // the wave number is uniform: keep it scalar
   const int slot0 = (wv * D_WL + lane) * 4;
@@ -661,21 +661,25 @@ d_detect(const P1Hot &A, const u64 *ent, const uint16_t *lcn, int64_t g0, int sa
 }
 
 #ifndef D_WAVES_W2
-#define D_WAVES_W2 3                       // two-word k-mers: waves per SIMD (4 cannot be met: the compiler stays at 3; 2: 35 % slower)
+#define D_WAVES_W2 3                       // two-word k-mers with a count word in the request (exact proof): waves per SIMD
+#endif                                     //   (the 23 KB request queue of that variant allows three workgroups per CU)
+#ifndef D_WAVES_W2K
+#define D_WAVES_W2K 4                      // ... with key-only requests (hash proof): 15 KB less LDS, 108 vector registers
 #endif
 #ifndef D_WAVES_PER_EU
 #define D_WAVES_PER_EU 5
 #endif
+#define D_WAVES(W_, RW_) ((W_) == 2 ? ((RW_) == 2 ? D_WAVES_W2K : D_WAVES_W2) : ((RW_) == 1 ? D_WAVES_PER_EU : 5))
 
 template <int W, int RW, bool ODD, bool KF> __global__ void __launch_bounds__(D_TPB)
-__attribute__((amdgpu_waves_per_eu(W == 2 ? D_WAVES_W2 : (RW == 1 ? D_WAVES_PER_EU : 5), W == 2 ? D_WAVES_W2 : (RW == 1 ? D_WAVES_PER_EU : 5))))
+__attribute__((amdgpu_waves_per_eu(D_WAVES(W, RW), D_WAVES(W, RW))))
 kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
 { __shared__ uint16_t tailq[D_OWN + 8];   // deferred tail: slots of this tile's queued entries
   __shared__ u64      ent[D_SLOTS * W];  // the staged k-mers
   __shared__ uint16_t lcn[D_SLOTS];
   __shared__ u64      sq[(RW == 1 ? D_QCAP : D_OWN) * RW];
   __shared__ u64      sfp[D_TPB / 64][2];
-  constexpr bool D_BM = (W == 1 && RW == 1) || (W == 2 && RW == 3);
+  constexpr bool D_BM = (W == 1 && RW == 1) || (W == 2 && RW != 1);
   __shared__ __attribute__((aligned(16))) unsigned bm[D_BM ? 2 * D_BMW : 1];
   __shared__ unsigned hist[(D_BM && W == 1) ? D_HB : 1];
   __shared__ unsigned s_tn[2], s_qn, s_unsorted, s_chunk, s_used;      // (s_tn: one counter per tile parity)

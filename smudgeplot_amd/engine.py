@@ -58,7 +58,7 @@ class Stats(C.Structure):
 
 
 EXPORTS = [
-    "smg_hetmers_run", "smg_hetmers_run_source", "smg_device_count", "smg_device_warmup", "smg_engine_create", "smg_engine_destroy",
+    "smg_hetmers_run", "smg_hetmers_run_source", "smg_device_count", "smg_engine_create", "smg_engine_destroy",
     "smg_engine_decode", "smg_engine_bind", "smg_engine_condition", "smg_engine_run", "smg_engine_pass1",
     "smg_engine_nreq", "smg_engine_record_words", "smg_engine_route", "smg_engine_apply",
     "smg_engine_apply_own", "smg_engine_blockmap", "smg_engine_blockmap_copy", "smg_engine_filter",

@@ -795,6 +795,25 @@ def test_tables_beyond_the_shard_limit_are_cut_into_shards_on_one_device(name, n
     assert (tmp_path / "out.smu").read_text() == g["smu"]
 
 
+@pytest.mark.parametrize("k,nshards", [(31, 3), (40, 4), (21, 2), (70, 3)])
+def test_unsymmetric_table_beyond_the_shard_limit_takes_the_general_path_across_the_shards(k, nshards, monkeypatch):
+    """the reference answers for ANY sorted table (it only probes entry #1 for symmetry, PloidyPlot.c:1199-1229).  A
+    table of more than 2^32 entries lives in several shards of one device; when it fails the proof the shards run the
+    general path TOGETHER -- a prefix-side partner is looked up in whichever shard holds it (the threshold is
+    lowered here so that small tables take that road)."""
+    packed, cnt = synth.adversarial_table(k, 3000, 4, seed=60 + k, low_complexity=80, dense=2)
+    rng = np.random.default_rng(k)
+    keep = rng.random(len(cnt)) > 0.07                     # holes: the table is no longer closed
+    pa, ca = packed[keep], cnt[keep]
+    want = brute.hetmers_plot(pa, ca, k)
+    assert want.sum() > 0
+    monkeypatch.setenv("SMG_SHARD_LIMIT", str(len(ca) // nshards + 1))
+    for mode in ("hash", "exact"):
+        plot, st = engine.hetmers_run(table_from(pa, ca, k), symcheck=mode)
+        assert st["path"] == 2 and st["nels"] == len(ca), (k, mode)
+        assert np.array_equal(plot, want), (k, mode)
+
+
 def _records_on_device(tk, tc, k):
     """format F records (ibyte = 3) + prefix index of a device-resident one-word table, built with torch"""
     import torch

@@ -40,9 +40,15 @@ with tempfile.TemporaryDirectory(prefix="smg_e2e") as d:
             os.remove(p)
         t = time.time()
         r = subprocess.run(cmd, cwd=d, capture_output=True, text=True, env=env)
-        dt = time.time() - t
+        t1 = time.time()
+        dt = t1 - t
         assert r.returncode == 0, r.stderr
-        return dt, r.stderr
+        err = r.stderr
+        import re
+        m = re.search(r"main\(\) entered at ([0-9.]+), left at ([0-9.]+)", err)
+        if m:       # what lies outside main(): exec + dynamic loader in front, exit() (HIP runtime shutdown) behind
+            err += f"  [smg] outside main(): {1e3 * (float(m.group(1)) - t):.1f} ms before (exec, loader), {1e3 * (t1 - float(m.group(2))):.1f} ms after (exit)\n"
+        return dt, err
 
     cores = min(64, os.cpu_count() or 1)
     if not OURS_ONLY:
