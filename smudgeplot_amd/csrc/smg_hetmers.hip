@@ -1066,7 +1066,7 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
   if (filter_ok(e) && !emit_all && !getenv("SMG_NO_FILTER"))
     { const int nbits = bm_id_bits(e->kmer, e->bm_cap);
       // the look-up chain of smg_lookup.hpp: one-word k-mers, key-only records, a map of >= 12 id bits
-      const bool chain = nbits >= 12 && e->W == 1 && e->rw == 1 && !getenv("SMG_OLD_LOOKUP");
+      const bool chain = nbits >= 12 && e->W <= 2 && e->rw == e->W && !getenv("SMG_OLD_LOOKUP");
       // ... with the two-bit map (smg_fast.hpp) when the k-mer has bits below the id to hash (a function of k and the
       // environment alone: every shard of a table decides the same)
       e->bm2 = (chain && e->kmer >= 24 && !getenv("SMG_ONE_BIT_MAP")) ? 1 : 0;
@@ -1364,14 +1364,17 @@ static int filter_presort(smg_engine *e, char *errbuf, size_t errlen)
   if (e->lg.nb)
     { // smg_lookup.hpp: bucket offsets from pass 1's histogram, one-pass partition into the dense array req2
       const int64_t nreq = e->st.nrequests;
-      if ((rc = grow(&e->req2, &e->req2_cap, (nreq > 0 ? nreq : 1) * (int64_t) sizeof(u64), errbuf, errlen))) return rc;
+      if ((rc = grow(&e->req2, &e->req2_cap, (nreq > 0 ? nreq : 1) * (int64_t) sizeof(u64) * e->rw, errbuf, errlen))) return rc;
       const int nbk = 1 << e->lg.nb;
       // bucket sizes = column sums of the owners' histogram rows -> bucket offsets -> first slot of every owner in every bucket
       hipLaunchKernelGGL(kl_tot, dim3(L_BK / LW_BPW), dim3(64 * LW_BPW), 0, e->stream, (const unsigned *) e->whist, e->nown, e->ghist);
       hipLaunchKernelGGL(kl_scan, dim3(1), dim3(L_BK), 0, e->stream, e->ghist, nbk, e->boff, e->boff + L_BK + 2, e->ghist + L_BK);
       hipLaunchKernelGGL(kl_woff, dim3(L_BK / LW_BPW), dim3(64 * LW_BPW), 0, e->stream, e->whist, e->nown, (const u64 *) e->boff);
-      if (e->n_chunks)
-        hipLaunchKernelGGL(kl_part, dim3(e->nown), dim3(PT_TPB), 0, e->stream, e->req, e->chunk_fill, e->nown,
+      if (e->n_chunks && e->rw == 1)
+        hipLaunchKernelGGL(kl_part<1>, dim3(e->nown), dim3(PT_TPB), 0, e->stream, e->req, e->chunk_fill, e->nown,
+                           (const unsigned *) e->whist, e->max_chunks, e->lg.nb, e->req2);
+      else if (e->n_chunks)
+        hipLaunchKernelGGL(kl_part<2>, dim3(e->nown), dim3(PT_TPB), 0, e->stream, e->req, e->chunk_fill, e->nown,
                            (const unsigned *) e->whist, e->max_chunks, e->lg.nb, e->req2);
       HIPCHK(hipGetLastError());
       e->presorted = 3;
@@ -1402,10 +1405,12 @@ static int lookup_probe(smg_engine *e, const uint32_t *map, bool list, unsigned 
   const unsigned nbk = 1u << e->lg.nb;
   if (grid > nbk) grid = nbk;
   FastArgs a = make_fast(e);
-#define PROBE(LIST_, TWO_, OUT_, FILL_, MAX_) hipLaunchKernelGGL((kl_probe<LIST_, TWO_>), dim3(grid), dim3(PB_TPB), 0, e->stream, a, \
+#define PROBE(LIST_, TWO_, RW_, OUT_, FILL_, MAX_) hipLaunchKernelGGL((kl_probe<LIST_, TWO_, RW_>), dim3(grid), dim3(PB_TPB), 0, e->stream, a, \
                        (const u64 *) e->req2, (const u64 *) e->boff, map, e->lg, e->ghist + L_BK, OUT_, FILL_, MAX_, &e->ctrl->fast)
-  if (list) { if (two) PROBE(true, true, e->reqf, e->chunk_fillf, maxout); else PROBE(true, false, e->reqf, e->chunk_fillf, maxout); }
-  else      { if (two) PROBE(false, true, (u64 *) NULL, (uint32_t *) NULL, 0u); else PROBE(false, false, (u64 *) NULL, (uint32_t *) NULL, 0u); }
+#define PROBE_RW(LIST_, TWO_, OUT_, FILL_, MAX_) { if (e->rw == 1) PROBE(LIST_, TWO_, 1, OUT_, FILL_, MAX_); else PROBE(LIST_, TWO_, 2, OUT_, FILL_, MAX_); }
+  if (list) { if (two) PROBE_RW(true, true, e->reqf, e->chunk_fillf, maxout) else PROBE_RW(true, false, e->reqf, e->chunk_fillf, maxout) }
+  else      { if (two) PROBE_RW(false, true, (u64 *) NULL, (uint32_t *) NULL, 0u) else PROBE_RW(false, false, (u64 *) NULL, (uint32_t *) NULL, 0u) }
+#undef PROBE_RW
 #undef PROBE
   HIPCHK(hipGetLastError());
   return SMG_OK;
@@ -2259,7 +2264,7 @@ static int host_run(const smg_table_source *tv, const smg_opts *opts, int64_t *p
       // (a table that still has to be symmetrised closes to at most twice its entries: shard it for that size)
       const bool want_symm = opts && (opts->condition & SMG_COND_SYMM);
       const int64_t closed = want_symm ? 2 * tv->nels : tv->nels;
-      if (ng <= 1 && closed >= limit && !labels)
+      if (ng <= 1 && closed >= limit)
         { int64_t per = limit > 3000000000ll ? 3000000000ll : limit;     // ~3e9 entries per shard
           if (per < 1) per = 1;
           ng = (int) ((closed + per - 1) / per);
@@ -2276,13 +2281,13 @@ static int host_run(const smg_table_source *tv, const smg_opts *opts, int64_t *p
     // SMG_FORCE_MULTI=1 (tests): take the multi-GPU code path even with one GPU -- a one-rank RCCL
     // communicator, send/recv to self, all-reduce: checks the dlopen'ed RCCL entry points on a 1-GPU box
     if (ng <= 1 && getenv("SMG_FORCE_MULTI") && !v) ng = -1;
-    if ((ng > 1 || ng == -1) && !labels)
+    if (ng > 1 || ng == -1)
       { if (tv->kmer > FAST_MAX_K)
           { if (verbose) fprintf(stderr, "  [smg] k > 85: using one GPU\n"); }
         else
           { smg_opts o; memset(&o, 0, sizeof(o));
             if (opts) o = *opts; else o.symcheck = SMG_SYM_HASH;
-            const int mrc = host_run_multi(tv, &o, ng == -1 ? 1 : ng, virt, plot, stats, errbuf, errlen);
+            const int mrc = host_run_multi(tv, &o, ng == -1 ? 1 : ng, virt, plot, stats, errbuf, errlen, labels, records, nrec, rec_words);
             // a table that fails the symmetry proof: shards on ONE device run the general path together (smg_multi.hpp,
             // TabSet); several real GPUs hand the table to one of them, which can hold it as long as it has < 2^32 entries
             if (mrc != SMG_ENOTSYM) return mrc;

@@ -1,4 +1,4 @@
-// smg_lookup.hpp -- the look-up chain of the hash proof for one-word k-mers (k <= 32): requests -> P flags.
+// smg_lookup.hpp -- the look-up chain of the hash proof for k <= 64 (key-only request records of one or two words): requests -> P flags.
 //
 // Round 1: sentinel fill, rocPRIM Onesweep histogram + scatter on the leading 8 bits (3.5 ms on the 1 Gbp table),
 // kf_filter probing the block map through the L2s (3.0), Onesweep on 24 bits of the survivors (1.1), in-order look-ups
@@ -132,17 +132,19 @@ kl_woff(unsigned *__restrict__ whist /* in: counts, out: first slots */, unsigne
 #ifndef PT_TPB
 #define PT_TPB    1024
 #endif
-#ifndef PT_CH
-#define PT_CH     4                        // chunks per batch (2 with 512 threads: 3.0 instead of 2.6 ms -- shorter runs)
-#endif
-#define PT_BATCH  (PT_CH * F_CH)           // 16384 records = 128 KB of LDS: one workgroup per CU
-#define PT_PER    (PT_BATCH / PT_TPB)      // 16 records per thread, held in registers between the phases
+#define PT_LDSREC 16384                    // records of one word per batch = 128 KB of LDS: one workgroup per CU
 #define PT_BPT    (L_BK / PT_TPB)          // buckets per thread in the scan
 
-__global__ void __launch_bounds__(PT_TPB)
+// RW = 64-bit words per record (1: k <= 32, 2: 33 <= k <= 64; the bucket is taken from the first word).  A batch holds
+// PT_LDSREC / RW records: four chunks of one-word records (two with 512 threads took 3.0 instead of 2.6 ms -- shorter
+// runs), two chunks of two-word ones.
+template <int RW> __global__ void __launch_bounds__(PT_TPB)
 kl_part(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill, unsigned owners,
         const unsigned *__restrict__ woff, unsigned max_chunks, int nb, u64 *__restrict__ out)
-{ __shared__ u64      sorted[PT_BATCH];
+{ constexpr int PT_BATCH = PT_LDSREC / RW;           // records per batch
+  constexpr int PT_CH = PT_BATCH / F_CH;             // chunks per batch
+  constexpr int PT_PER = PT_BATCH / PT_TPB;          // records per thread, held in registers between the phases
+  __shared__ u64      sorted[PT_BATCH * RW];
   __shared__ unsigned cur[L_BK];           // phase A: counts; phase C: cursors
   __shared__ unsigned lbase[L_BK];         // first slot of the bucket in `sorted`
   __shared__ unsigned gbase[L_BK];         // first output slot of this batch's run
@@ -154,7 +156,7 @@ kl_part(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill, un
 
   // batch q = the chunks blockIdx.x + (q * PT_CH + j) * owners, j < PT_CH, of this owner (fill 0: not used).
   // The PT_PER records of a thread; `ok` = which of them exist, bit 31 = the batch's first chunk is in use.
-  auto load = [&](unsigned q, u64 (&y)[PT_PER]) -> unsigned
+  auto load = [&](unsigned q, u64 (&y)[PT_PER][RW]) -> unsigned
   { unsigned ok = 0;
 #pragma unroll
     for (int j = 0; j < PT_PER; j++)
@@ -164,21 +166,26 @@ kl_part(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill, un
         const bool k = r < fill;
         ok |= (unsigned) k << j;
         if (j == 0 && fill) ok |= 1u << 31;
-        y[j] = k ? req[(size_t) ch * F_CH + r] : 0ull;
+        if constexpr (RW == 2)
+          { ulonglong2 v = make_ulonglong2(0ull, 0ull);
+            if (k) v = *reinterpret_cast<const ulonglong2 *>(req + ((size_t) ch * F_CH + r) * 2);
+            y[j][0] = v.x; y[j][1] = v.y;
+          }
+        else y[j][0] = k ? req[(size_t) ch * F_CH + r] : 0ull;
       }
     return ok;
   };
 
   // The barriers order LDS traffic only (lds_barrier): a __syncthreads() also drains the wave's outstanding stores,
   // which made every batch wait for its own copy-out.  The NEXT batch is loaded while this one is sorted.
-  u64 y[PT_PER], yn[PT_PER];
+  u64 y[PT_PER][RW], yn[PT_PER][RW];
   unsigned ok = load(0u, y), okn = 0;
   lds_barrier();
   for (unsigned q = 0; ok >> 31; q++)
     { // A: count per bucket
 #pragma unroll
       for (int j = 0; j < PT_PER; j++)
-        if (ok >> j & 1u) atomicAdd(&cur[(unsigned) (y[j] >> 32) >> hsh], 1u);
+        if (ok >> j & 1u) atomicAdd(&cur[(unsigned) (y[j][0] >> 32) >> hsh], 1u);
       okn = load(q + 1, yn);                                     // (in flight until the end of this batch)
       lds_barrier();
       // B: exclusive scan of the counts (PT_BPT buckets per thread); the owner's cursors move on
@@ -212,18 +219,26 @@ kl_part(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill, un
       // C: sort inside LDS (the order inside a bucket is arbitrary)
 #pragma unroll
       for (int j = 0; j < PT_PER; j++)
-        if (ok >> j & 1u) sorted[atomicAdd(&cur[(unsigned) (y[j] >> 32) >> hsh], 1u)] = y[j];
+        if (ok >> j & 1u)
+          { const unsigned slot = atomicAdd(&cur[(unsigned) (y[j][0] >> 32) >> hsh], 1u);
+#pragma unroll
+            for (int w = 0; w < RW; w++) sorted[slot * RW + w] = y[j][w];
+          }
       lds_barrier();
 #pragma unroll
       for (int j = 0; j < PT_BPT; j++) cur[PT_BPT * t + j] = 0;   // (for the next batch; D does not read them)
       // D: copy out in order
       for (unsigned i = t; i < total; i += PT_TPB)
-        { const u64 v = sorted[i];
-          const unsigned b = (unsigned) (v >> 32) >> hsh;
-          out[(size_t) gbase[b] + (i - lbase[b])] = v;
+        { const unsigned b = (unsigned) (sorted[i * RW] >> 32) >> hsh;
+          const size_t o = (size_t) gbase[b] + (i - lbase[b]);
+          if constexpr (RW == 2)
+            *reinterpret_cast<ulonglong2 *>(out + o * 2) = make_ulonglong2(sorted[i * 2], sorted[i * 2 + 1]);
+          else out[o] = sorted[i];
         }
 #pragma unroll
-      for (int j = 0; j < PT_PER; j++) y[j] = yn[j];
+      for (int j = 0; j < PT_PER; j++)
+#pragma unroll
+        for (int w = 0; w < RW; w++) y[j][w] = yn[j][w];
       ok = okn;
       lds_barrier();
     }
@@ -251,7 +266,9 @@ SMG_DEV unsigned pb_fold(unsigned f)
 
 // LIST = false: look the survivors up and set their P flags.  LIST = true: append them to the chunk list `out`
 // (every wave fills chunks of its own).
-template <bool LIST, bool TWO> __global__ void __launch_bounds__(PB_TPB)
+// RW = words per record: the filter reads the first one; the survivors' queue holds the k-mer itself (RW = 1) or the
+// number of the record (RW = 2: two more queue words per slot would not fit next to the 128 KB map slice)
+template <bool LIST, bool TWO, int RW> __global__ void __launch_bounds__(PB_TPB)
 kl_probe(FastArgs A, const u64 *__restrict__ recs, const u64 *__restrict__ boff, const uint32_t *__restrict__ fmap,
          LookupGeo g, unsigned *__restrict__ bnext, u64 *__restrict__ out, uint32_t *__restrict__ out_fill,
          unsigned max_out, FastCtl *__restrict__ ctl)
@@ -272,10 +289,15 @@ kl_probe(FastArgs A, const u64 *__restrict__ recs, const u64 *__restrict__ boff,
   // the last `take` (<= 64) survivors of this wave's queue
   auto drain = [&](unsigned take)
   { const u64 yv = q[qn - take + ((unsigned) lane < take ? lane : 0)];
+    Key<RW> y;
+    if constexpr (RW == 1) y.w[0] = yv;
+    else
+      { const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(recs + (size_t) yv * 2);     // (read a moment ago: a cache hit)
+        y.w[0] = v.x; y.w[1] = v.y;
+      }
     if (!LIST)
       { if ((unsigned) lane < take)
-          { Key<1> y; y.w[0] = yv;
-            const int64_t j = sig_find<1>(A, y, false);
+          { const int64_t j = sig_find<RW>(A, y, false);
             if (j < 0) { if (ctl->missing == 0) ctl->missing = 1; }
             else SET_P(A, j);
           }
@@ -288,7 +310,11 @@ kl_probe(FastArgs A, const u64 *__restrict__ recs, const u64 *__restrict__ boff,
             chunk = (unsigned) __builtin_amdgcn_readfirstlane((int) c);
             used = 0;
           }
-        if ((unsigned) lane < take && chunk < max_out) out[(size_t) chunk * F_CH + used + lane] = yv;
+        if ((unsigned) lane < take && chunk < max_out)
+          {
+#pragma unroll
+            for (int w = 0; w < RW; w++) out[((size_t) chunk * F_CH + used + lane) * RW + w] = y.w[w];
+          }
         used += take;
       }
     qn -= take; kept += take;
@@ -322,7 +348,7 @@ kl_probe(FastArgs A, const u64 *__restrict__ recs, const u64 *__restrict__ boff,
           for (int j = 0; j < PB_PER; j++)
             { const u64 i = i0 + (u64) j * 64 + lane;
               keep[j] = i < r1;
-              y[j] = keep[j] ? recs[i] : 0ull;
+              y[j] = keep[j] ? recs[i * RW] : 0ull;
             }
 #pragma unroll
           for (int j = 0; j < PB_PER; j++)
@@ -348,8 +374,9 @@ kl_probe(FastArgs A, const u64 *__restrict__ recs, const u64 *__restrict__ boff,
           for (int j = 0; j < PB_PER; j += 2)                  // queue two wave-instructions' worth, drain to below 64
             { const u64 m0 = __ballot(keep[j]), m1 = __ballot(keep[j + 1]);
               const unsigned n0 = (unsigned) __popcll(m0), n1 = (unsigned) __popcll(m1);
-              if (keep[j]) q[qn + __builtin_amdgcn_mbcnt_hi((unsigned) (m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m0, 0u))] = y[j];
-              if (keep[j + 1]) q[qn + n0 + __builtin_amdgcn_mbcnt_hi((unsigned) (m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m1, 0u))] = y[j + 1];
+              const u64 v0 = RW == 1 ? y[j] : i0 + (u64) j * 64 + lane, v1 = RW == 1 ? y[j + 1] : i0 + (u64) (j + 1) * 64 + lane;
+              if (keep[j]) q[qn + __builtin_amdgcn_mbcnt_hi((unsigned) (m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m0, 0u))] = v0;
+              if (keep[j + 1]) q[qn + n0 + __builtin_amdgcn_mbcnt_hi((unsigned) (m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m1, 0u))] = v1;
               qn += n0 + n1;
               while (qn >= 64) drain(64);
             }

@@ -79,6 +79,9 @@ struct MultiCtx
   RcclApi  api;
   ncclComm_t comm[SMG_MAXGPU];
   int64_t *plot;                            // result (host), written by rank 0
+  const uint16_t *labels;                   // extract leg (or NULL): labels of the annotated pixels (host, SMG_PLOT_CELLS)
+  uint64_t *h_rec[SMG_MAXGPU];              //   records of shard r (malloc'ed), nrec[r] of them
+  int64_t   nrec[SMG_MAXGPU];
   Tab      gtab[SMG_MAXGPU];                // general path over virtual shards: the shards' tables ...
   TabSet  *d_set;                           // ... collected on the device by rank 0
   int      general;                         // 1: the table failed the proof and the shards run the general path together
@@ -377,6 +380,31 @@ static void *multi_worker(void *argp)
           c->plot[cell] = v;
         }
     }
+  // ---- extract leg (PloidyList.c:1207-1583 has no size limit either): every shard lists the pairs behind the labelled
+  // pixels among ITS entries -- the two members of a pair share a window block, hence a shard -- the host concatenates
+  c->h_rec[r] = NULL; c->nrec[r] = 0;
+  if (MOK && c->labels)
+    { uint16_t *d_labels = NULL; uint64_t *d_out = NULL;
+      int64_t cnt = 0, got = 0;
+      const int rw = W + 1;
+      if (c->general) MFAIL(SMG_EINVAL, "extract needs a trimmed, reverse-complement closed table");
+      if (MOK && (hipMalloc(&d_labels, sizeof(uint16_t) * SMG_PLOT_CELLS) != hipSuccess
+                  || hipMemcpy(d_labels, c->labels, sizeof(uint16_t) * SMG_PLOT_CELLS, hipMemcpyHostToDevice) != hipSuccess))
+        MFAIL(SMG_ENOMEM, "out of device memory for the pair list");
+      if (MOK && (c->rc[r] = smg_engine_extract(e, d_labels, NULL, 0, &cnt, eb, el))) c->failed = 1;       // count first
+      if (MOK && cnt > 0)
+        { c->h_rec[r] = (uint64_t *) malloc(sizeof(uint64_t) * (size_t) cnt * rw);
+          if (!c->h_rec[r] || hipMalloc(&d_out, sizeof(uint64_t) * (size_t) cnt * rw) != hipSuccess)
+            MFAIL(SMG_ENOMEM, "out of memory for the pair list");
+          if (MOK && (c->rc[r] = smg_engine_extract(e, d_labels, d_out, cnt, &got, eb, el))) c->failed = 1;
+          if (MOK && got != cnt) MFAIL(SMG_ENODEV, "internal error: the pair list changed between two passes");
+          if (MOK && hipMemcpy(c->h_rec[r], d_out, sizeof(uint64_t) * (size_t) cnt * rw, hipMemcpyDeviceToHost) != hipSuccess)
+            MFAIL(SMG_ENODEV, "device to host copy failed");
+          if (MOK) c->nrec[r] = cnt;
+        }
+      if (d_labels) hipFree(d_labels);
+      if (d_out) hipFree(d_out);
+    }
   pthread_barrier_wait(&c->bar);                                                         // E: done with h_plot
   free(c->h_plot[r]); c->h_plot[r] = NULL;
   if (d_plot) hipFree(d_plot);
@@ -408,7 +436,8 @@ static void multi_cuts(const smg_table_source *tv, int n, int64_t *cut)
 }
 
 static int host_run_multi(const smg_table_source *tv, const smg_opts *opts, int ngpus, bool force_virtual, int64_t *plot,
-                          smg_stats *stats, char *errbuf, size_t errlen)
+                          smg_stats *stats, char *errbuf, size_t errlen, const uint16_t *labels = NULL,
+                          uint64_t **records = NULL, int64_t *nrec = NULL, int *rec_words = NULL)
 { if (ngpus > SMG_MAXGPU) ngpus = SMG_MAXGPU;
   if (tv->kmer > FAST_MAX_K)
     return fail(errbuf, errlen, SMG_EINVAL, "multi-GPU runs support k <= 85%s");
@@ -420,6 +449,7 @@ static int host_run_multi(const smg_table_source *tv, const smg_opts *opts, int 
   c->W = (tv->kmer + 31) / 32;
   c->pbyte = ((tv->kmer + 3) >> 2) + 2 - tv->ibyte;
   c->plot = plot;
+  c->labels = labels;
   { const char *v = getenv("SMG_VIRTUAL_SHARDS"); c->virt = force_virtual || (v && atoi(v) > 0); }
   c->io_threads = (tv->host_threads > 0 ? tv->host_threads : 4) / ngpus;
   if (c->io_threads < 2) c->io_threads = 2;
@@ -486,6 +516,26 @@ static int host_run_multi(const smg_table_source *tv, const smg_opts *opts, int 
                 "(slowest shard each), wall incl. H2D %.2f ms\n", (long long) st.nels, tv->kmer, ngpus,
                 c->virt ? " (virtual shards on one device)" : "", st.ms_decode, st.ms_pass1, st.ms_rclookup, st.ms_pass2, wall);
     }
+  if (rc == SMG_OK && labels)
+    { // the shards' records, one after the other; their number must be the plot's weight on the labelled pixels
+      int64_t want = 0, have = 0;
+      for (int cell = 0; cell < SMG_PLOT_CELLS; cell++) if (labels[cell]) want += plot[cell];
+      for (int r = 0; r < ngpus; r++) have += c->nrec[r];
+      const int rw = c->W + 1;
+      uint64_t *all = (uint64_t *) malloc(sizeof(uint64_t) * (size_t) (have > 0 ? have : 1) * rw);
+      if (have != want) rc = fail(errbuf, errlen, SMG_ENODEV, "internal error: pair list and plot disagree%s");
+      else if (!all) rc = fail(errbuf, errlen, SMG_ENOMEM, "out of host memory for the pair list%s");
+      else
+        { int64_t o = 0;
+          for (int r = 0; r < ngpus; r++)
+            { if (c->nrec[r]) memcpy(all + o * rw, c->h_rec[r], sizeof(uint64_t) * (size_t) c->nrec[r] * rw);
+              o += c->nrec[r];
+            }
+          *records = all; *nrec = have; *rec_words = rw; all = NULL;
+        }
+      free(all);
+    }
+  for (int r = 0; r < ngpus; r++) free(c->h_rec[r]);
   if (!c->virt) for (int r = 0; r < ngpus; r++) c->api.CommDestroy(c->comm[r]);
   pthread_barrier_destroy(&c->bar);
   pthread_mutex_destroy(&c->big_mu);

@@ -681,7 +681,7 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
   __shared__ u64      sfp[D_TPB / 64][2];
   constexpr bool D_BM = (W == 1 && RW == 1) || (W == 2 && RW != 1);
   __shared__ __attribute__((aligned(16))) unsigned bm[D_BM ? 2 * D_BMW : 1];
-  __shared__ unsigned hist[(D_BM && W == 1) ? D_HB : 1];
+  __shared__ unsigned hist[(D_BM && RW == W) ? D_HB : 1];
   __shared__ unsigned s_tn[2], s_qn, s_unsorted, s_chunk, s_used;      // (s_tn: one counter per tile parity)
   __shared__ u64      s_base, s_total;
 
@@ -695,7 +695,7 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
   S.s_tn = &s_tn[0]; S.s_qn = &s_qn; S.s_unsorted = &s_unsorted;
   S.bm = bm; S.hist = hist;
   if (D_BM) for (int w = t; w < 2 * D_BMW; w += D_TPB) bm[w] = 0;
-  if (D_BM && W == 1) for (int w = t; w < D_HB; w += D_TPB) hist[w] = 0;
+  if (D_BM && RW == W) for (int w = t; w < D_HB; w += D_TPB) hist[w] = 0;
   if (t == 0) { s_chunk = F_NOCHUNK; s_used = 0; s_total = 0; s_tn[0] = 0; s_tn[1] = 0; s_qn = 0; s_unsorted = 0; }
   lds_barrier();
   (void) lane; (void) slot0; (void) n;
@@ -767,7 +767,7 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
               if (qn > head)
                 { if (old_chunk != F_NOCHUNK && old_chunk < max_chunks) cold->chunk_fill[old_chunk] = F_CH;
                   // (look-up chain: the partition kernel finds the chunks of owner w at w + j * owners, no list needed)
-                  if (D_BM && W == 1 && A.hbits()) s_chunk = old_chunk == F_NOCHUNK ? blockIdx.x : old_chunk + cold->owners;
+                  if (D_BM && RW == W && A.hbits()) s_chunk = old_chunk == F_NOCHUNK ? blockIdx.x : old_chunk + cold->owners;
                   else s_chunk = atomicAdd(&cold->ctl->n_chunks, 1u);
                   s_used = qn - head;
                 }
@@ -776,9 +776,9 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
               s_qn = 0;
             }
           lds_barrier();
-          if (D_BM && W == 1 && A.hbits())            // requests per bucket, for the partition of the look-up chain
+          if (D_BM && RW == W && A.hbits())            // requests per bucket, for the partition of the look-up chain
             { const int hsh = 32 - A.hbits();
-              for (unsigned e = t; e < qn; e += D_TPB) atomicAdd(&hist[(unsigned) (sq[e] >> 32) >> hsh], 1u);
+              for (unsigned e = t; e < qn; e += D_TPB) atomicAdd(&hist[(unsigned) (sq[e * RW] >> 32) >> hsh], 1u);
             }
           if (head && old_chunk < max_chunks)
             { u64 *o = req + s_base * RW;
@@ -793,11 +793,11 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
       if (t == 0) s_tn[par] = 0;
     }
 
-  if (D_BM && W == 1 && A.hbits())                   // this workgroup's row of the request histogram (kl_tot / kl_woff)
+  if (D_BM && RW == W && A.hbits())                   // this workgroup's row of the request histogram (kl_tot / kl_woff)
     for (int w = t; w < D_HB; w += D_TPB) cold->whist[(size_t) blockIdx.x * D_HB + w] = hist[w];
   if (t == 0)
     { if (s_chunk != F_NOCHUNK && s_chunk < cold->max_chunks) cold->chunk_fill[s_chunk] = s_used;
-      if (D_BM && W == 1 && A.hbits() && s_chunk != F_NOCHUNK) atomicMax(&cold->ctl->n_chunks, s_chunk + 1u);   // slots in use
+      if (D_BM && RW == W && A.hbits() && s_chunk != F_NOCHUNK) atomicMax(&cold->ctl->n_chunks, s_chunk + 1u);   // slots in use
       if (s_total) atomicAdd(&cold->ctl->nreq, s_total);
       if (s_unsorted) cold->ctl->unsorted = 1;
     }

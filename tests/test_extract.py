@@ -166,3 +166,21 @@ def test_extract_on_raw_table_conditions_first(tmp_path):
         assert q.returncode == 0, q.stderr
         for lab in want:
             assert sorted(open(tmp_path / f"ref.{lab}.txt").readlines()) == sorted(open(tmp_path / f"gpu.{lab}.txt").readlines())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shards", [3, 6])
+@pytest.mark.parametrize("name", ["k31_i1", "k51_i1_p3", "k65_i1"])
+def test_extract_over_prefix_shards_matches_reference_golden(name, shards, monkeypatch):
+    """PloidyList.c:1207-1583 has no size or device limit: the extract leg over a table that is cut into prefix shards
+    (several GPUs, or more than 2^32 entries on one) -- every shard lists the pairs among its own entries, the host
+    puts the lists together; same lines as the reference, whatever the cut"""
+    g, labels, lines, _ = load_extract(name)
+    monkeypatch.setenv("SMG_VIRTUAL_SHARDS", str(shards))
+    plot, got = engine.hetmers_extract(make_table(g), labels)
+    assert engine.smu_text(plot) == g["smu"]
+    assert {lab: sorted(v) for lab, v in got.items()} == lines
+    monkeypatch.delenv("SMG_VIRTUAL_SHARDS")
+    monkeypatch.setenv("SMG_SHARD_LIMIT", str(len(g["counts"]) // shards + 1))          # the automatic shards of a big table
+    plot, got = engine.hetmers_extract(make_table(g), labels)
+    assert {lab: sorted(v) for lab, v in got.items()} == lines
