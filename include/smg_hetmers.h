@@ -240,9 +240,18 @@ int64_t smg_engine_nreq(smg_engine *e);
 int     smg_engine_record_words(smg_engine *e);
 int     smg_engine_route(smg_engine *e, const uint64_t *splitters, int nranks, uint64_t *d_send,
                          int64_t capacity, int64_t *counts, char *errbuf, size_t errlen);
+/* the same with the per-rank counts left on the device (d_counts[nranks], int64, written in stream order): a driver that
+   exchanges the counts with a collective hands them over without a host round trip and reads both sides' counts once */
+int     smg_engine_route_device(smg_engine *e, const uint64_t *splitters, int nranks, uint64_t *d_send,
+                                int64_t capacity, int64_t *d_counts, char *errbuf, size_t errlen);
 int     smg_engine_apply(smg_engine *e, const uint64_t *d_recv, int64_t nrecv, int64_t *missing,
                          char *errbuf, size_t errlen);
 int     smg_engine_apply_own(smg_engine *e, int64_t *missing, char *errbuf, size_t errlen);
+/* (smg_engine_apply with missing == NULL does not wait for the device: the count stays there.)
+   proof: d_dst[0..2] (device) = { complements that were missing or carried another count, fingerprint residue words 0, 1 }
+   of this shard, written in stream order -- a sharded run appends them to the histogram buffer of its final all_reduce
+   without a host round trip (the residues of the ranks combine by XOR: give each rank its own two words).            */
+int     smg_engine_proof(smg_engine *e, uint64_t *d_dst, char *errbuf, size_t errlen);
 /* Request filter (hash proof, k <= 85).  A request only matters when its target is a candidate of
    pass 2 (exactly one suffix-side pair).  Pass 1 records in a bit map which block ids -- the leading
    id_bits = min(30, 2*(k/2)) bits of a k-mer -- hold a candidate; smg_engine_filter drops every request

@@ -100,36 +100,136 @@ template <int W> SMG_DEV Key<W> lds_key(const u64 *sk, int idx)
   return x;
 }
 
-// slow exact walk of a window block that outgrows the halo: binary searches in global memory
+// first base at which x and y differ (32 * W when they are equal)
+template <int W> SMG_DEV int first_diff(const Key<W> &x, const Key<W> &y)
+{ int r = 32 * W;
+#pragma unroll
+  for (int w = W - 1; w >= 0; w--)
+    { const u64 d = x.w[w] ^ y.w[w];
+      if (d) r = 32 * w + (__clzll((long long) d) >> 1);
+    }
+  return r;
+}
+
+// Exact walk of a window block that outgrows the linear ranges (repeats, low-complexity sequence): hundreds to
+// thousands of entries that share their first p0 bases with entry i.
+//   1. block bounds: gallop outwards from i in doubling steps, then bisect the last step;
+//   2. NARROW by prefix: [lo, hi) holds the entries that share the first p bases with x.  The entries that also share
+//      base p are a sub-range around i; a partner at position p lies outside it (same first p bases, another base at p,
+//      the same bases behind).  The two bounds of the sub-range and the three flips of base p are FIVE binary searches
+//      over the same range: they run in lockstep, five independent loads per step, so a level costs log2(hi - lo)
+//      memory round trips; then p + 1 with the sub-range, which is typically a quarter of the range;
+//   3. once at most BB_LIN entries are left they are read eight at a time: a single-base difference among entries that
+//      share p bases is a pair at a position >= p.
+// (The first version bisected the bounds over the whole table and then looked up all 3 (k - p0) flips in the whole
+//  block one after the other: ~550 dependent loads per entry; this one needs ~40 for a block of 500 entries.)
+#define BB_LIN  24
+
 template <int W> __device__ __noinline__ void
 big_block_scan(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, int64_t n,
                const Geo g, int64_t i, unsigned &s_all, unsigned &s_hi, int64_t &partner,
                unsigned &w2)
 { const Key<W> x = load_key<W>(keys, i);
   const unsigned c = cnt[i];
-  int64_t a = 0, b = i;
-  while (a < b)
-    { const int64_t m = (a + b) >> 1;
-      if (same_block<W>(x, load_key<W>(keys, m), g)) b = m; else a = m + 1;
-    }
-  const int64_t blo = a;
-  a = i + 1; b = n;
-  while (a < b)
-    { const int64_t m = (a + b) >> 1;
-      if (!same_block<W>(x, load_key<W>(keys, m), g)) b = m; else a = m + 1;
-    }
-  const int64_t bhi = a;
-  s_all = 0; s_hi = 0; partner = -1; w2 = 0;
-  for (int p = g.p0; p < g.k; p++)
-    for (int d = 1; d <= 3; d++)
-      { const Key<W> y = flip_base<W>(x, p, d);
-        const int64_t j = lower_bound_key<W>(keys, blo, bhi, y);
-        if (j < bhi && key_eq<W>(load_key<W>(keys, j), y) && c + (unsigned) cnt[j] <= SMG_SMAX)
-          { const unsigned hi = (p != g.k - 1 - p);
-            if (s_all == 0) { partner = j; w2 = hi; }
-            s_all++; s_hi += hi;
-          }
+  int64_t lo, hi;
+  { int64_t in = i, out, step = 64;
+    for (;;)
+      { out = in - step;
+        if (out < 0) { out = -1; break; }
+        if (!same_block<W>(x, load_key<W>(keys, out), g)) break;
+        in = out; step <<= 1;
       }
+    int64_t a = out + 1, b = in;                            // first entry of the block in (out, in]
+    while (a < b)
+      { const int64_t m = (a + b) >> 1;
+        if (same_block<W>(x, load_key<W>(keys, m), g)) b = m; else a = m + 1;
+      }
+    lo = a;
+    in = i; step = 64;
+    for (;;)
+      { out = in + step;
+        if (out >= n) { out = n; break; }
+        if (!same_block<W>(x, load_key<W>(keys, out), g)) break;
+        in = out; step <<= 1;
+      }
+    a = in + 1; b = out;                                    // first entry behind the block in (in, out]
+    while (a < b)
+      { const int64_t m = (a + b) >> 1;
+        if (!same_block<W>(x, load_key<W>(keys, m), g)) b = m; else a = m + 1;
+      }
+    hi = a;
+  }
+  s_all = 0; s_hi = 0; partner = -1; w2 = 0;
+  int p = g.p0;
+#pragma unroll 1
+  for (; hi - lo > BB_LIN && p < g.k; p++)
+    { Key<W> y[3];
+#pragma unroll
+      for (int d = 0; d < 3; d++) y[d] = flip_base<W>(x, p, d + 1);
+      // search 0: first entry of [lo, i) that shares base p too; 1: first entry of (i, hi) that does not;
+      // 2..4: lower bound of the flips in [lo, hi)
+      int64_t sa[5] = { lo, i + 1, lo, lo, lo }, sb[5] = { i, hi, hi, hi, hi };
+      for (;;)
+        { bool any = false;
+#pragma unroll
+          for (int q = 0; q < 5; q++) any |= sa[q] < sb[q];
+          if (!any) break;
+          Key<W> z[5]; int64_t m[5];
+#pragma unroll
+          for (int q = 0; q < 5; q++)
+            { m[q] = (sa[q] + sb[q]) >> 1;
+              z[q] = load_key<W>(keys, sa[q] < sb[q] ? m[q] : i);
+            }
+#pragma unroll
+          for (int q = 0; q < 5; q++)
+            if (sa[q] < sb[q])
+              { bool right;                                  // the answer is at m or in front of it
+                if (q == 0)      right = first_diff<W>(x, z[q]) > p;
+                else if (q == 1) right = first_diff<W>(x, z[q]) <= p;
+                else             right = !key_lt<W>(z[q], y[q - 2]);
+                if (right) sb[q] = m[q]; else sa[q] = m[q] + 1;
+              }
+        }
+      { Key<W> z[3]; unsigned cz[3]; bool in[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++)
+          { in[d] = sa[2 + d] < hi;
+            z[d] = load_key<W>(keys, in[d] ? sa[2 + d] : i);
+            cz[d] = cnt[in[d] ? sa[2 + d] : i];
+          }
+#pragma unroll
+        for (int d = 0; d < 3; d++)
+          if (in[d] && key_eq<W>(z[d], y[d]) && c + cz[d] <= SMG_SMAX)
+            { const unsigned h = (p != g.k - 1 - p);
+              if (s_all == 0) { partner = sa[2 + d]; w2 = h; }
+              s_all++; s_hi += h;
+            }
+      }
+      lo = sa[0]; hi = sa[1];
+    }
+  if (p >= g.k) return;
+  // what is left shares the first p bases with x
+#pragma unroll 1
+  for (int64_t base = lo; base < hi; base += 8)
+    { Key<W> z[8]; unsigned cz[8]; bool in[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        { const int64_t q = base + j;
+          in[j] = q < hi && q != i;
+          z[j] = load_key<W>(keys, in[j] ? q : i);
+          cz[j] = cnt[in[j] ? q : i];
+        }
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        if (in[j])
+          { const int pp = pair_pos<W>(x, z[j]);
+            if (pp >= 0 && c + cz[j] <= SMG_SMAX)
+              { const unsigned h = (pp != g.k - 1 - pp);
+                if (s_all == 0) { partner = base + j; w2 = h; }
+                s_all++; s_hi += h;
+              }
+          }
+    }
 }
 
 SMG_DEV unsigned make_code(unsigned s_all, int64_t delta, unsigned w2)
@@ -573,10 +673,21 @@ SMG_DEV unsigned tri_index(unsigned s, unsigned m)       // cell of (sum, min) i
 }
 
 
-SMG_DEV void plot_bump(unsigned *tile, u64 *__restrict__ plot, unsigned ci, unsigned cj, unsigned wgt)
+// Cells beyond the LDS tile (sum >= P2_SMAX: repeats, organelles, high-coverage tables) go through a small
+// direct-mapped cache of (cell, weight) pairs in LDS: the pairs of a repeat family hit a handful of cells, and a global
+// atomic per pair on those few addresses cost 3.4 of the 5.1 ms pass 2 took on the table with 5 % repeats.  A slot
+// that is taken by another cell sends the pair to the global plot directly, as before.
+#define P2_FAR    512                   // slots (4 KB: tile + queue + cache = 80.5 KB, two workgroups per CU)
+#define P2_EMPTY  0xFFFFFFFFu
+
+SMG_DEV void plot_bump(unsigned *tile, unsigned *fkey, unsigned *fval, u64 *__restrict__ plot, unsigned ci, unsigned cj, unsigned wgt)
 { const unsigned s = ci + cj, m = ci < cj ? ci : cj;
-  if (s < P2_SMAX) atomicAdd(tile + tri_index(s, m), wgt);
-  else atomicAdd(plot + (size_t) s * SMG_PLOT_COLS + m, (u64) wgt);
+  if (s < P2_SMAX) { atomicAdd(tile + tri_index(s, m), wgt); return; }
+  const unsigned cell = s * SMG_PLOT_COLS + m;
+  const unsigned h = (cell * 0x9E3779B1u) >> 23;                  // 9 bits
+  const unsigned old = atomicCAS(&fkey[h], P2_EMPTY, cell);
+  if (old == P2_EMPTY || old == cell) atomicAdd(&fval[h], wgt);
+  else atomicAdd(plot + cell, (u64) wgt);
 }
 
 // rare: the unique partner is more than 30 entries away -- search it again
@@ -595,23 +706,22 @@ far_partner(const FastArgs &A, int64_t i, int64_t &partner, unsigned &w2)
 // Phase B: the queue is drained densely, one candidate per lane: the five dependent-free loads
 //          (partner code, two P flags, two counts) are issued together -- walking the candidates
 //          inside the 16-entry loop serialised one memory round trip per entry (r01_v2 profile).
+// An entry whose unique partner is more than 30 entries away (CODE_FAR) is skipped here and finished by kf_pass2_far:
+// from the list of deferred entries that kf_bigfix worked through (every such entry is on it), or -- three-word
+// k-mers, whose pass 1 keeps no list -- from a scan of the code bytes.  (The search for a far partner needs ~120 VGPRs;
+// called from this kernel it halved the occupancy of all the other entries and put 160 bytes of scratch on each.)
 template <int W> SMG_DEV void
-p2_candidate(const FastArgs &A, unsigned *tile, u64 *__restrict__ plot, int64_t i, unsigned ci)
+p2_candidate(const FastArgs &A, unsigned *tile, unsigned *fkey, unsigned *fval, u64 *__restrict__ plot, int64_t i, unsigned ci)
 { const unsigned lo6 = ci & 63;
-  int64_t j;
-  unsigned w2 = (ci & CODE_W2) != 0;
-  if (lo6 == CODE_FAR)
-    { far_partner<W>(A, i, j, w2);
-      if (j <= i) return;
-    }
-  else
-    j = i + (int) lo6 - 31;
+  if (lo6 == CODE_FAR) return;
+  const unsigned w2 = (ci & CODE_W2) != 0;
+  const int64_t j = i + (int) lo6 - 31;
   const unsigned cj = A.code[j], pi = ci & CODE_P, pj = cj & CODE_P;
   const unsigned ni = A.cnt[i], nj = A.cnt[j];
   const unsigned lj = cj & 63;
   if (lj == CODE_NONE || lj == CODE_MULTI) return;    // partner has several pairs
   if (pi | pj) return;                                // a prefix-side pair exists too
-  plot_bump(tile, plot, ni, nj, w2 ? 2u : 1u);
+  plot_bump(tile, fkey, fval, plot, ni, nj, w2 ? 2u : 1u);
 }
 
 // (1024 threads = 4 waves per SIMD and workgroup: two workgroups per CU need <= 64 VGPRs)
@@ -619,9 +729,11 @@ template <int W> __global__ void __launch_bounds__(P2_TPB) __attribute__((amdgpu
 kf_pass2(FastArgs A, u64 *__restrict__ plot)
 { __shared__ unsigned tile[P2_CELLS];
   __shared__ unsigned queue[P2_QCAP];     // local index (14 bits) | code << 16
+  __shared__ unsigned fkey[P2_FAR], fval[P2_FAR];      // cells beyond the tile: cell number, weight
   __shared__ unsigned s_qn[2];            // queue fill of the even / odd tiles of this workgroup
   const int t = threadIdx.x;
   for (int c = t; c < P2_CELLS; c += P2_TPB) tile[c] = 0;
+  for (int c = t; c < P2_FAR; c += P2_TPB) { fkey[c] = P2_EMPTY; fval[c] = 0; }
   if (t == 0) { s_qn[0] = 0; s_qn[1] = 0; }
   lds_barrier();
 
@@ -664,7 +776,7 @@ kf_pass2(FastArgs A, u64 *__restrict__ plot)
               const unsigned ci = (unsigned) ((j < 8 ? lo : hi) >> (8 * (j & 7))) & 0xFFu;
               const int li = t * P2_VEC + j;
               if (slot < P2_QCAP) queue[slot] = (unsigned) li | (ci << 16);
-              else p2_candidate<W>(A, tile, plot, c0 + li, ci);                    // queue full: rare, done in place
+              else p2_candidate<W>(A, tile, fkey, fval, plot, c0 + li, ci);       // queue full: rare, done in place
             }
         }
       // prefetch the next tile's codes while the queue is drained
@@ -677,11 +789,13 @@ kf_pass2(FastArgs A, u64 *__restrict__ plot)
       if (t == 0) s_qn[it ^ 1u] = 0;             // the other counter is idle until the next tile's phase A
       for (unsigned q = t; q < qn; q += P2_TPB)
         { const unsigned e = queue[q];
-          p2_candidate<W>(A, tile, plot, c0 + (e & 0xFFFF), e >> 16);
+          p2_candidate<W>(A, tile, fkey, fval, plot, c0 + (e & 0xFFFF), e >> 16);
         }
       lds_barrier();
     }
 
+  for (int c = t; c < P2_FAR; c += P2_TPB)
+    if (fval[c]) atomicAdd(plot + fkey[c], (u64) fval[c]);
   // flush the LDS tile: (sum,min) rows are laid out triangularly
   for (int c = t; c < P2_CELLS; c += P2_TPB)
     { const unsigned v = tile[c];
@@ -693,6 +807,49 @@ kf_pass2(FastArgs A, u64 *__restrict__ plot)
       if ((unsigned) c >= (a + 1) * (a + 1)) { s = 2 * a + 1; m = c - (a + 1) * (a + 1); }
       else { s = 2 * a; m = c - a * (a + 1); }
       atomicAdd(plot + (size_t) s * SMG_PLOT_COLS + m, (u64) v);
+    }
+}
+
+// the far partners of pass 2: the deferred entries of pass 1 (list[0 .. nlist)) whose code says "one pair, partner out of
+// the code's reach" -- found again by the block walk, then the same tests as p2_candidate, straight into the plot
+template <int W> SMG_DEV void p2_far_entry(const FastArgs &A, int64_t i, u64 *__restrict__ plot)
+{ int64_t j; unsigned w2;
+  far_partner<W>(A, i, j, w2);
+  if (j <= i) return;
+  const unsigned cj = A.code[j], lj = cj & 63;
+  if (lj == CODE_NONE || lj == CODE_MULTI || (cj & CODE_P)) return;
+  const unsigned ni = A.cnt[i], nj = A.cnt[j];
+  const unsigned sm = ni + nj, mn = ni < nj ? ni : nj;
+  atomicAdd(plot + (size_t) sm * SMG_PLOT_COLS + mn, (u64) (w2 ? 2u : 1u));
+}
+
+template <int W> __global__ void __launch_bounds__(256)
+kf_pass2_far(FastArgs A, const uint32_t *__restrict__ list, unsigned nlist, u64 *__restrict__ plot)
+{ for (unsigned q = blockIdx.x * blockDim.x + threadIdx.x; q < nlist; q += gridDim.x * blockDim.x)
+    { const int64_t i = list[q];
+      const unsigned ci = A.code[i];
+      if ((ci & 63) == CODE_FAR && !(ci & CODE_P)) p2_far_entry<W>(A, i, plot);
+    }
+}
+
+// the same without a list: 16 code bytes per thread and step
+template <int W> __global__ void __launch_bounds__(256)
+kf_pass2_farscan(FastArgs A, u64 *__restrict__ plot)
+{ const int64_t nv = (A.n + 15) >> 4;
+  for (int64_t v = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (int64_t) gridDim.x * blockDim.x)
+    { const uint4 cv = *reinterpret_cast<const uint4 *>(A.code + (v << 4));      // (the code array is padded to 16 bytes)
+      const unsigned wv[4] = { cv.x, cv.y, cv.z, cv.w };
+#pragma unroll 1
+      for (int q = 0; q < 4; q++)
+        { // bytes whose low six bits are 62 and whose bit 7 is clear
+          const unsigned w = wv[q];
+          const unsigned x6 = (w & 0x3F3F3F3Fu) ^ 0x3E3E3E3Eu;                    // zero in the low six bits <=> 62
+          unsigned hit = ~(((x6 & 0x3F3F3F3Fu) + 0x3F3F3F3Fu) >> 6) & ~(w >> 7) & 0x01010101u;
+          for (; hit; hit &= hit - 1)
+            { const int64_t i = (v << 4) + 4 * q + ((__ffs(hit) - 1) >> 3);
+              if (i < A.n) p2_far_entry<W>(A, i, plot);
+            }
+        }
     }
 }
 
@@ -834,19 +991,57 @@ kf_route_count(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_f
   if ((int) threadIdx.x < nranks) counts[(size_t) blockIdx.x * nranks + threadIdx.x] = cnt[threadIdx.x];
 }
 
-// offsets[chunk][rank] = first record slot of that (chunk, rank) group in the send buffer
+// offsets[chunk][rank] = records of that rank in the chunks in front (exclusive scan down column `rank`); totals[rank].
+// One workgroup per rank; the send buffer is destination-major, so group (chunk, rank) starts at
+// sum(totals[< rank]) + offsets[chunk][rank].  (Round 2 brought the counts to the host, scanned them there and sent the
+// offsets back: two host round trips per step of a sharded run.)
+__global__ void __launch_bounds__(1024)
+kf_route_offsets(const uint32_t *__restrict__ counts, unsigned nc, int nranks, u64 *__restrict__ offsets, u64 *__restrict__ totals)
+{ __shared__ u64 wsum[16];
+  __shared__ u64 s_carry;
+  const int r = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  if (t == 0) s_carry = 0;
+  __syncthreads();
+  for (unsigned c0 = 0; c0 < nc; c0 += 1024)
+    { const unsigned c = c0 + t;
+      const u64 v = c < nc ? (u64) counts[(size_t) c * nranks + r] : 0ull;
+      u64 incl = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1)
+        { const u64 u = __shfl_up(incl, o, 64);
+          if (lane >= o) incl += u;
+        }
+      if (lane == 63) wsum[wv] = incl;
+      __syncthreads();
+      u64 before = s_carry;
+      for (int w = 0; w < wv; w++) before += wsum[w];
+      if (c < nc) offsets[(size_t) c * nranks + r] = before + incl - v;
+      __syncthreads();
+      if (t == 1023) s_carry = before + incl;
+      __syncthreads();
+    }
+  if (t == 0) totals[r] = s_carry;
+}
+
+// the records of every chunk -> their groups in the send buffer
 template <int W> __global__ void __launch_bounds__(F_TPB)
 kf_route_scatter(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill, int rw,
-                 const u64 *__restrict__ split, int nranks, const u64 *__restrict__ offsets,
+                 const u64 *__restrict__ split, int nranks, const u64 *__restrict__ offsets, const u64 *__restrict__ totals,
                  u64 *__restrict__ out)
 { __shared__ unsigned cur[16];
-  if (threadIdx.x < 16) cur[threadIdx.x] = 0;
+  __shared__ u64 rbase[16];
+  if (threadIdx.x < 16)
+    { cur[threadIdx.x] = 0;
+      u64 b = 0;
+      for (int r = 0; r < (int) threadIdx.x && r < nranks; r++) b += totals[r];
+      rbase[threadIdx.x] = b;
+    }
   __syncthreads();
   const unsigned fill = chunk_fill[blockIdx.x];
   for (unsigned r = threadIdx.x; r < fill; r += F_TPB)
     { const u64 *q = req + ((size_t) blockIdx.x * F_CH + r) * rw;
       const int d = rank_of<W>(q, split, nranks);
-      const u64 slot = offsets[(size_t) blockIdx.x * nranks + d] + atomicAdd(&cur[d], 1u);
+      const u64 slot = rbase[d] + offsets[(size_t) blockIdx.x * nranks + d] + atomicAdd(&cur[d], 1u);
       u64 *o = out + slot * rw;
       for (int w = 0; w < rw; w++) o[w] = q[w];
     }

@@ -364,11 +364,12 @@ k_pass1(Tab t, int64_t lo, int64_t hi, int emit_all, int want_fp, u64 *__restric
               f2 = hash_entry<W>(r, c, 0x243f6a8885a308d3ull);
               f3 = hash_entry<W>(r, c, 0x13198a2e03707344ull);
             }
-          f0 = wave_sum_u64(f0); f1 = wave_sum_u64(f1);
-          f2 = wave_sum_u64(f2); f3 = wave_sum_u64(f3);
+          // (XOR, as on the fast path: the entries are strictly increasing, nothing can cancel; shards XOR their residues)
+          f0 = wave_xor_u64(f0); f1 = wave_xor_u64(f1);
+          f2 = wave_xor_u64(f2); f3 = wave_xor_u64(f3);
           if ((threadIdx.x & 63) == 0)
-            { atomicAdd(&ctrl->fp[0], f0); atomicAdd(&ctrl->fp[1], f1);
-              atomicAdd(&ctrl->fp[2], f2); atomicAdd(&ctrl->fp[3], f3);
+            { atomicXor((unsigned long long *) &ctrl->fp[0], (unsigned long long) f0); atomicXor((unsigned long long *) &ctrl->fp[1], (unsigned long long) f1);
+              atomicXor((unsigned long long *) &ctrl->fp[2], (unsigned long long) f2); atomicXor((unsigned long long *) &ctrl->fp[3], (unsigned long long) f3);
             }
         }
     }
@@ -600,7 +601,9 @@ struct smg_engine
                            //   owner w fills the chunk slots w, w + nown, w + 2 nown, ..
   u64         *boff;       //   bucket offsets [L_BK + 1] and scatter cursors [L_BK] behind them
   LookupGeo    lg;         //   geometry of the current run (lg.nb = 0: the round-1 chain is used)
+  bool         far_listed;   // pass 1 left the list of its deferred entries in biglist[0 .. st.nbig): pass 2 finishes the far partners from it
   bool         counted_done; // the counted path (k > 85) has run on a closed table: deg[] holds the wrapped degrees
+  bool         lookup_pending; // look-ups of received requests were queued without a host wait (their time is read later)
   bool         use_sig;    // pass 1 writes the 2-byte look-up signatures (not worth their 5 GB when the filter leaves 1 request in 115)
   int          bm2;        //   the map is a two-bit map (smg_fast.hpp): 64-bit words, private to this engine
   int          bm_cap;     //   id bits of the block map: 32 on one GPU, 30 when the maps of several shards are exchanged
@@ -701,7 +704,7 @@ static int set_table(smg_engine *e, int kmer, int64_t nels, char *errbuf, size_t
   e->kmer = kmer;
   e->W = (kmer + 31) / 32;
   e->n = nels;
-  e->prepared = false; e->counted_done = false;
+  e->prepared = false; e->counted_done = false; e->lookup_pending = false;
   memset(&e->st, 0, sizeof(e->st));
   e->st.nels = nels;
   e->st.key_words = e->W;
@@ -1259,6 +1262,7 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
   e->st.nemitted = e->st.nrequests;
   e->st.ms_filter = 0;
   e->st.nbig = narrow ? (int64_t) e->h_ctrl->fast.nbig : 0;
+  e->far_listed = narrow;
   e->st.ms_bigfix = 0;
   if (narrow) { float mb = 0; hipEventElapsedTime(&mb, e->ev[0], e->ev[3]); e->st.ms_bigfix = mb; }
   e->prepared = true;
@@ -1546,6 +1550,8 @@ static int fast_apply(smg_engine *e, const u64 *flat, int64_t nflat, int check_c
   if (rc) return rc;
   hipEventRecord(e->ev[5], e->stream);
   HIPCHK(hipGetLastError());
+  if (!missing && flat)                   // (sharded run: the count of missing complements stays on the device -- smg_engine_proof)
+    { e->lookup_pending = true; return SMG_OK; }
   rc = read_ctrl(e, errbuf, errlen);
   if (rc) return rc;
   float ms = 0; hipEventElapsedTime(&ms, e->ev[4], e->ev[5]);
@@ -1564,30 +1570,55 @@ static int fast_pass2(smg_engine *e, int64_t *d_plot, bool with_sum, char *errbu
 #define CALL(WW) hipLaunchKernelGGL(kf_pass2<WW>, dim3((unsigned) nb), dim3(P2_TPB), 0, e->stream, a, (u64 *) d_plot)
       DISPATCH_W3(e, CALL)
 #undef CALL
+      // entries whose unique partner is out of the code's reach: from the list of deferred entries that pass 1 of one-
+      // and two-word k-mers leaves, else (three words: the generic pass 1) from a scan of the code bytes
+      if (e->far_listed && e->W <= 2)
+        { const unsigned nl = (unsigned) e->st.nbig;
+          unsigned fb = (nl + 255) / 256;
+          if (fb > 4096) fb = 4096;
+          if (nl && e->W == 1) hipLaunchKernelGGL(kf_pass2_far<1>, dim3(fb), dim3(256), 0, e->stream, a, (const uint32_t *) e->biglist, nl, (u64 *) d_plot);
+          else if (nl)         hipLaunchKernelGGL(kf_pass2_far<2>, dim3(fb), dim3(256), 0, e->stream, a, (const uint32_t *) e->biglist, nl, (u64 *) d_plot);
+        }
+      else
+        { int64_t fb = ((e->n + 15) / 16 + 255) / 256;
+          if (fb > 4096) fb = 4096;
+#define CALL(WW) hipLaunchKernelGGL(kf_pass2_farscan<WW>, dim3((unsigned) fb), dim3(256), 0, e->stream, a, (u64 *) d_plot)
+          DISPATCH_W3(e, CALL)
+#undef CALL
+        }
     }
   hipEventRecord(e->ev[7], e->stream);
   HIPCHK(hipGetLastError());
   int rc = SMG_OK;
-  if (with_sum) rc = plot_sum(e, d_plot, errbuf, errlen);           // (one more kernel and a host round trip)
-  else { e->st.npairs = 0; HIPCHK(hipEventSynchronize(e->ev[7])); }
+  e->st.path = 1;
+  if (!with_sum)                         // (phase API: no host wait here; smg_engine_stats reads the events once they have fired)
+    { e->st.npairs = 0; e->st.ms_pass2 = -1.0; return SMG_OK; }
+  rc = plot_sum(e, d_plot, errbuf, errlen);                         // (one more kernel and a host round trip)
   if (rc) return rc;
   float ms = 0; hipEventElapsedTime(&ms, e->ev[6], e->ev[7]);
   e->st.ms_pass2 = ms;
-  e->st.path = 1;
   return SMG_OK;
 }
 
-// ---- public phase API (sharded runs; fast path only) ---------------------------------------------
+// ---- public phase API (sharded runs) ------------------------------------------------------------
+// k <= 85: the fast path.  k > 85: the counted path in the same steps (counted_phase_* below) -- pass 1 leaves ONE flat
+// list of (rc(x), count | S_hi << 16) records, presented to the router as full chunks; no block map, nothing is filtered.
 
 #define NEED_FAST(e)                                                                          \
   if (!(e)) return fail(errbuf, errlen, SMG_EINVAL, "null engine%s");                          \
   if ((e)->kmer > FAST_MAX_K)                                                                 \
-    return fail(errbuf, errlen, SMG_EINVAL, "the phase API supports k <= 85 (use smg_engine_run)%s");
+    return fail(errbuf, errlen, SMG_EINVAL, "no block map and no request filter above k = 85%s");
+#define NEED_ENGINE(e)  if (!(e)) return fail(errbuf, errlen, SMG_EINVAL, "null engine%s");
+
+static int counted_phase_pass1(smg_engine *e, int symcheck, char *errbuf, size_t errlen);
+static int counted_phase_apply(smg_engine *e, const u64 *rec, int64_t nrec, int64_t *missing, char *errbuf, size_t errlen);
+static int counted_phase_pass2(smg_engine *e, int64_t *d_plot, char *errbuf, size_t errlen);
 
 extern "C" int smg_engine_pass1(smg_engine *e, int symcheck, char *errbuf, size_t errlen)
-{ NEED_FAST(e)
+{ NEED_ENGINE(e)
   HIPCHK(hipSetDevice(e->device));
-  e->st.ms_rclookup = 0;
+  e->st.ms_rclookup = 0; e->lookup_pending = false;
+  if (e->kmer > FAST_MAX_K) return counted_phase_pass1(e, symcheck, errbuf, errlen);
   e->bm_cap = e->bm_want ? e->bm_want : 30;  // default: the maps of the shards are exchanged, 128 MB in total
   return fast_pass1(e, symcheck == SMG_SYM_EXACT, symcheck == SMG_SYM_EXACT, symcheck == SMG_SYM_HASH, errbuf, errlen);
 }
@@ -1597,16 +1628,32 @@ extern "C" int smg_engine_record_words(smg_engine *e) { return e ? e->rw : 0; }
 
 extern "C" int smg_engine_apply(smg_engine *e, const uint64_t *d_recv, int64_t nrecv,
                                 int64_t *missing, char *errbuf, size_t errlen)
-{ NEED_FAST(e)
+{ NEED_ENGINE(e)
   if (!e->prepared) return fail(errbuf, errlen, SMG_EINVAL, "apply before pass1%s");
   HIPCHK(hipSetDevice(e->device));
+  if (!e->fast) return counted_phase_apply(e, (const u64 *) d_recv, nrecv, missing, errbuf, errlen);
   return fast_apply(e, (const u64 *) d_recv, nrecv, 1, missing, errbuf, errlen);
 }
 
+__global__ void k_proof_words(const Ctrl *__restrict__ ctrl, int fast, u64 f0, u64 f1, u64 *__restrict__ dst)
+{ if (threadIdx.x == 0) { dst[0] = fast ? (u64) ctrl->fast.missing : ctrl->missing; dst[1] = f0; dst[2] = f1; } }
+
+extern "C" int smg_engine_proof(smg_engine *e, uint64_t *d_dst, char *errbuf, size_t errlen)
+{ NEED_ENGINE(e)
+  if (!e->prepared || !d_dst) return fail(errbuf, errlen, SMG_EINVAL, "proof before pass1%s");
+  HIPCHK(hipSetDevice(e->device));
+  hipLaunchKernelGGL(k_proof_words, dim3(1), dim3(64), 0, e->stream,
+                     (const Ctrl *) e->ctrl, e->fast ? 1 : 0, e->fp[0] ^ e->fp[2], e->fp[1] ^ e->fp[3],
+                     (u64 *) d_dst);
+  HIPCHK(hipGetLastError());
+  return SMG_OK;
+}
+
 extern "C" int smg_engine_apply_own(smg_engine *e, int64_t *missing, char *errbuf, size_t errlen)
-{ NEED_FAST(e)
+{ NEED_ENGINE(e)
   if (!e->prepared) return fail(errbuf, errlen, SMG_EINVAL, "apply before pass1%s");
   HIPCHK(hipSetDevice(e->device));
+  if (!e->fast) return counted_phase_apply(e, e->req, e->st.nrequests, missing, errbuf, errlen);
   return fast_apply(e, NULL, 0, 1, missing, errbuf, errlen);
 }
 
@@ -1672,9 +1719,9 @@ extern "C" int smg_engine_merge_maps(smg_engine *e, const uint32_t *d_parts, int
 }
 
 extern "C" int smg_engine_presort(smg_engine *e, char *errbuf, size_t errlen)
-{ NEED_FAST(e)
+{ NEED_ENGINE(e)
   if (!e->prepared) return fail(errbuf, errlen, SMG_EINVAL, "presort before pass1%s");
-  if (!filter_ok(e) || !e->bm_bits || e->filtered || e->presorted || e->n_chunks == 0) return SMG_OK;
+  if (!e->fast || !filter_ok(e) || !e->bm_bits || e->filtered || e->presorted || e->n_chunks == 0) return SMG_OK;
   HIPCHK(hipSetDevice(e->device));
   return filter_presort(e, errbuf, errlen);
 }
@@ -1700,50 +1747,45 @@ extern "C" int smg_engine_symhash(smg_engine *e, uint64_t out[4], char *errbuf, 
 // range holds the k-mer (splitters = first k-mer of ranks 1..nranks-1); counts[nranks] on the host
 static int route_records(smg_engine *e, const u64 *req, const uint32_t *chunk_fill, unsigned nc, int rw,
                          const uint64_t *splitters, int nranks, uint64_t *d_send, int64_t *counts,
-                         char *errbuf, size_t errlen)
-{ for (int r = 0; r < nranks; r++) counts[r] = 0;
-  if (nc == 0) return SMG_OK;
+                         char *errbuf, size_t errlen, int64_t *d_counts = NULL /* device: the totals stay there, no host wait */)
+{ if (counts) for (int r = 0; r < nranks; r++) counts[r] = 0;
+  if (nc == 0)
+    { if (d_counts) HIPCHK(hipMemsetAsync(d_counts, 0, sizeof(int64_t) * nranks, e->stream));
+      return SMG_OK;
+    }
   int rc;
   if (nranks > 1)
     HIPCHK(hipMemcpyAsync(e->d_split, splitters, sizeof(u64) * (nranks - 1) * e->W,
                           hipMemcpyHostToDevice, e->stream));
   if ((rc = grow(&e->route_cnt, &e->route_cnt_cap, (int64_t) nc * nranks * 4, errbuf, errlen))) return rc;
-  if ((rc = grow(&e->route_off, &e->route_off_cap, (int64_t) nc * nranks * 8, errbuf, errlen))) return rc;
+  if ((rc = grow(&e->route_off, &e->route_off_cap, ((int64_t) nc * nranks + 16) * 8, errbuf, errlen))) return rc;
+  u64 *totals = e->route_off + (size_t) nc * nranks;           // [nranks], behind the offsets
 #define CALL(WW) hipLaunchKernelGGL(kf_route_count<WW>, dim3(nc), dim3(F_TPB), 0, e->stream, req, \
                    chunk_fill, rw, e->d_split, nranks, e->route_cnt)
   DISPATCH_W(e, CALL)
 #undef CALL
-  uint32_t *hc = (uint32_t *) malloc(sizeof(uint32_t) * (size_t) nc * nranks);
-  u64 *ho = (u64 *) malloc(sizeof(u64) * (size_t) nc * nranks);
-  if (!hc || !ho) { free(hc); free(ho); return fail(errbuf, errlen, SMG_ENOMEM, "out of host memory%s"); }
-  if (hipMemcpyAsync(hc, e->route_cnt, sizeof(uint32_t) * (size_t) nc * nranks, hipMemcpyDeviceToHost, e->stream) != hipSuccess
-      || hipStreamSynchronize(e->stream) != hipSuccess)
-    { free(hc); free(ho); return fail(errbuf, errlen, SMG_ENODEV, "route: device to host copy failed%s"); }
-  u64 acc = 0;
-  for (int r = 0; r < nranks; r++)          // destination-major, chunk order inside a destination
-    for (unsigned c = 0; c < nc; c++)
-      { ho[(size_t) c * nranks + r] = acc;
-        acc += hc[(size_t) c * nranks + r];
-        counts[r] += hc[(size_t) c * nranks + r];
-      }
-  hipError_t he = hipMemcpyAsync(e->route_off, ho, sizeof(u64) * (size_t) nc * nranks, hipMemcpyHostToDevice, e->stream);
-  if (he == hipSuccess)
-    {
+  // offsets and scatter follow on the device; the host only learns the totals (what the exchange needs): ONE round trip
+  hipLaunchKernelGGL(kf_route_offsets, dim3(nranks), dim3(1024), 0, e->stream, (const uint32_t *) e->route_cnt, nc, nranks, e->route_off, totals);
 #define CALL(WW) hipLaunchKernelGGL(kf_route_scatter<WW>, dim3(nc), dim3(F_TPB), 0, e->stream, req, \
-                   chunk_fill, rw, e->d_split, nranks, e->route_off, (u64 *) d_send)
-      DISPATCH_W(e, CALL)
+                   chunk_fill, rw, e->d_split, nranks, (const u64 *) e->route_off, (const u64 *) totals, (u64 *) d_send)
+  DISPATCH_W(e, CALL)
 #undef CALL
-      he = hipStreamSynchronize(e->stream);
+  HIPCHK(hipGetLastError());
+  if (d_counts)
+    { HIPCHK(hipMemcpyAsync(d_counts, totals, sizeof(u64) * nranks, hipMemcpyDeviceToDevice, e->stream));
+      return SMG_OK;
     }
-  free(hc); free(ho);
-  if (he != hipSuccess) return fail(errbuf, errlen, SMG_ENODEV, "route: %s", hipGetErrorString(he));
+  u64 ht[16];
+  HIPCHK(hipMemcpyAsync(ht, totals, sizeof(u64) * nranks, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  for (int r = 0; r < nranks; r++) counts[r] = (int64_t) ht[r];
   return SMG_OK;
 }
 
 extern "C" int smg_engine_route(smg_engine *e, const uint64_t *splitters, int nranks,
                                 uint64_t *d_send, int64_t capacity, int64_t *counts,
                                 char *errbuf, size_t errlen)
-{ NEED_FAST(e)
+{ NEED_ENGINE(e)
   if (!counts || nranks < 1 || nranks > 16)
     return fail(errbuf, errlen, SMG_EINVAL, "bad route arguments (1..16 ranks)%s");
   if (!e->prepared) return fail(errbuf, errlen, SMG_EINVAL, "route before pass1%s");
@@ -1752,15 +1794,39 @@ extern "C" int smg_engine_route(smg_engine *e, const uint64_t *splitters, int nr
   return route_records(e, e->req, e->chunk_fill, e->n_chunks, e->rw, splitters, nranks, d_send, counts, errbuf, errlen);
 }
 
+extern "C" int smg_engine_route_device(smg_engine *e, const uint64_t *splitters, int nranks, uint64_t *d_send, int64_t capacity,
+                                       int64_t *d_counts, char *errbuf, size_t errlen)
+{ NEED_ENGINE(e)
+  if (!d_counts || nranks < 1 || nranks > 16)
+    return fail(errbuf, errlen, SMG_EINVAL, "bad route arguments (1..16 ranks)%s");
+  if (!e->prepared) return fail(errbuf, errlen, SMG_EINVAL, "route before pass1%s");
+  HIPCHK(hipSetDevice(e->device));
+  if (e->st.nrequests > capacity) return fail(errbuf, errlen, SMG_EINVAL, "send buffer too small%s");
+  return route_records(e, e->req, e->chunk_fill, e->n_chunks, e->rw, splitters, nranks, d_send, NULL, errbuf, errlen, d_counts);
+}
+
 extern "C" int smg_engine_pass2(smg_engine *e, int64_t *d_plot, char *errbuf, size_t errlen)
-{ NEED_FAST(e)
+{ NEED_ENGINE(e)
   if (!e->prepared || !d_plot) return fail(errbuf, errlen, SMG_EINVAL, "pass2 before pass1%s");
   HIPCHK(hipSetDevice(e->device));
+  if (!e->fast) return counted_phase_pass2(e, d_plot, errbuf, errlen);
   return fast_pass2(e, d_plot, false, errbuf, errlen);
 }
 
 extern "C" int smg_engine_stats(smg_engine *e, smg_stats *stats)
 { if (!e || !stats) return SMG_EINVAL;
+  if (e->lookup_pending)                 // look-ups of received requests were queued without a wait
+    { float ms = 0;
+      hipSetDevice(e->device);
+      if (hipEventSynchronize(e->ev[5]) == hipSuccess && hipEventElapsedTime(&ms, e->ev[4], e->ev[5]) == hipSuccess) e->st.ms_rclookup += ms;
+      e->lookup_pending = false;
+    }
+  if (e->st.ms_pass2 < 0)                // pass 2 of the phase API was queued without a wait
+    { float ms = 0;
+      hipSetDevice(e->device);
+      if (hipEventSynchronize(e->ev[7]) == hipSuccess && hipEventElapsedTime(&ms, e->ev[6], e->ev[7]) == hipSuccess) e->st.ms_pass2 = ms;
+      else e->st.ms_pass2 = 0;
+    }
   *stats = e->st;
   return SMG_OK;
 }
@@ -2004,6 +2070,94 @@ kc_symm_records(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, 
 __global__ void __launch_bounds__(TPB) kc_fill_u32(uint32_t *__restrict__ p, int64_t n, uint32_t v, uint32_t last)
 { const int64_t i = (int64_t) blockIdx.x * TPB + threadIdx.x;
   if (i < n) p[i] = i == n - 1 ? last : v;
+}
+
+// ---- the counted path (k > 85) in the steps of the phase API ---------------------------------------------------
+// Pass 1 = k_pass1<W, true>: S_all into deg[], records (rc(x), count | S_hi << 16) from the owners of a hi-side pair (from
+// every entry for the exact proof) into one flat list, which the router reads as full chunks of F_CH records; a received
+// record adds S_hi to the degree of its k-mer (the uint8 wrap of PloidyPlot.c:163 emulated by deg_add) and proves that
+// the k-mer is there with the same count; pass 2 = k_pass2<W, true>.
+static int counted_phase_pass1(smg_engine *e, int symcheck, char *errbuf, size_t errlen)
+{ int rc;
+  if ((rc = counted_prepare(e, errbuf, errlen))) return rc;
+  const int emit_all = symcheck == SMG_SYM_EXACT;
+  const unsigned nblk = (unsigned) ((e->n + TPB - 1) / TPB);
+  int64_t cap = (emit_all ? e->n : e->n / 4) + 1024;
+  e->rw = e->W + 1;
+  for (int attempt = 0; attempt < 2; attempt++)
+    { if ((rc = grow(&e->req, &e->req_cap, cap * (int64_t) sizeof(u64) * e->rw, errbuf, errlen))) return rc;
+      Tab t = make_tab(e);
+      hipEventRecord(e->ev[2], e->stream);
+      if (e->n > 0)
+        {
+#define CALL(WW) hipLaunchKernelGGL((k_pass1<WW, true>), dim3(nblk), dim3(TPB), 0, e->stream, t, \
+                   (int64_t) 0, e->n, emit_all, symcheck == SMG_SYM_HASH, e->req, cap, e->ctrl)
+          DISPATCH_W(e, CALL)
+#undef CALL
+        }
+      hipEventRecord(e->ev[3], e->stream);
+      if ((rc = read_ctrl(e, errbuf, errlen))) return rc;
+      if (e->h_ctrl->unsorted)
+        return fail(errbuf, errlen, SMG_EFORMAT, "table entries are not strictly increasing%s");
+      if ((int64_t) e->h_ctrl->nreq <= cap) break;
+      cap = (int64_t) e->h_ctrl->nreq;
+      HIPCHK(hipMemsetAsync(&e->ctrl->nreq, 0, sizeof(u64), e->stream));
+      HIPCHK(hipMemsetAsync(e->ctrl->fp, 0, sizeof(u64) * 4, e->stream));
+    }
+  float ms = 0; hipEventElapsedTime(&ms, e->ev[2], e->ev[3]);
+  e->st.ms_pass1 = ms;
+  const int64_t nreq = (int64_t) e->h_ctrl->nreq;
+  e->st.nrequests = nreq;
+  for (int i = 0; i < 4; i++) e->fp[i] = e->h_ctrl->fp[i];
+  const int64_t nc = (nreq + F_CH - 1) / F_CH;
+  if (nc >= 0x7FFFFFFFll) return fail(errbuf, errlen, SMG_EINVAL, "shard too large%s");
+  if ((rc = grow(&e->chunk_fill, &e->chunk_cap, nc * 4 + 4, errbuf, errlen))) return rc;
+  if (nc > 0)
+    hipLaunchKernelGGL(kc_fill_u32, dim3((unsigned) ((nc + TPB - 1) / TPB)), dim3(TPB), 0, e->stream, e->chunk_fill, nc, (uint32_t) F_CH,
+                       (uint32_t) (nreq - (nc - 1) * F_CH));
+  HIPCHK(hipGetLastError());
+  e->n_chunks = (unsigned) nc; e->bm_bits = 0; e->filtered = false; e->presorted = false;
+  e->st.path = 1; e->st.ms_filter = 0;
+  e->prepared = true;                     // (with e->fast == false: the counted steps)
+  return SMG_OK;
+}
+
+static int counted_phase_apply(smg_engine *e, const u64 *rec, int64_t nrec, int64_t *missing, char *errbuf, size_t errlen)
+{ hipEventRecord(e->ev[4], e->stream);
+  if (nrec > 0)
+    { Tab t = make_tab(e);
+      const unsigned rb = (unsigned) ((nrec + TPB - 1) / TPB);
+#define CALL(WW) hipLaunchKernelGGL(k_apply<WW>, dim3(rb), dim3(TPB), 0, e->stream, t, rec, nrec, e->ctrl)
+      DISPATCH_W(e, CALL)
+#undef CALL
+    }
+  hipEventRecord(e->ev[5], e->stream);
+  HIPCHK(hipGetLastError());
+  if (!missing) { e->lookup_pending = true; return SMG_OK; }
+  const int rc = read_ctrl(e, errbuf, errlen);
+  if (rc) return rc;
+  float ms = 0; hipEventElapsedTime(&ms, e->ev[4], e->ev[5]);
+  e->st.ms_rclookup += ms;
+  *missing = (int64_t) e->h_ctrl->missing;
+  return SMG_OK;
+}
+
+static int counted_phase_pass2(smg_engine *e, int64_t *d_plot, char *errbuf, size_t errlen)
+{ HIPCHK(hipMemsetAsync(d_plot, 0, sizeof(int64_t) * SMG_PLOT_CELLS, e->stream));
+  hipEventRecord(e->ev[6], e->stream);
+  if (e->n > 0)
+    { Tab t = make_tab(e);
+      const unsigned nblk = (unsigned) ((e->n + TPB - 1) / TPB);
+#define CALL(WW) hipLaunchKernelGGL((k_pass2<WW, true>), dim3(nblk), dim3(TPB), 0, e->stream, t, \
+                   (int64_t) 0, e->n, (u64 *) d_plot)
+      DISPATCH_W(e, CALL)
+#undef CALL
+    }
+  hipEventRecord(e->ev[7], e->stream);
+  HIPCHK(hipGetLastError());
+  e->st.path = 1; e->st.npairs = 0; e->st.ms_pass2 = -1.0;      // (no host wait: smg_engine_stats resolves the events)
+  e->counted_done = true;
+  return SMG_OK;
 }
 
 // records -> separate k-mer / count / is-a-complement arrays
@@ -2274,18 +2428,13 @@ static int host_run(const smg_table_source *tv, const smg_opts *opts, int64_t *p
           virt = true;
           if (verbose) fprintf(stderr, "  [smg] %lld entries%s: %d prefix shards on one device\n", (long long) tv->nels,
                                want_symm ? " before the table is symmetrised" : "", ng);
-          if (tv->kmer > FAST_MAX_K)
-            return fail(errbuf, errlen, SMG_EINVAL, "a table of more than 2^32 entries needs k <= 85%s");
         }
     }
     // SMG_FORCE_MULTI=1 (tests): take the multi-GPU code path even with one GPU -- a one-rank RCCL
     // communicator, send/recv to self, all-reduce: checks the dlopen'ed RCCL entry points on a 1-GPU box
     if (ng <= 1 && getenv("SMG_FORCE_MULTI") && !v) ng = -1;
     if (ng > 1 || ng == -1)
-      { if (tv->kmer > FAST_MAX_K)
-          { if (verbose) fprintf(stderr, "  [smg] k > 85: using one GPU\n"); }
-        else
-          { smg_opts o; memset(&o, 0, sizeof(o));
+      { { smg_opts o; memset(&o, 0, sizeof(o));
             if (opts) o = *opts; else o.symcheck = SMG_SYM_HASH;
             const int mrc = host_run_multi(tv, &o, ng == -1 ? 1 : ng, virt, plot, stats, errbuf, errlen, labels, records, nrec, rec_words);
             // a table that fails the symmetry proof: shards on ONE device run the general path together (smg_multi.hpp,

@@ -439,8 +439,6 @@ static int host_run_multi(const smg_table_source *tv, const smg_opts *opts, int 
                           smg_stats *stats, char *errbuf, size_t errlen, const uint16_t *labels = NULL,
                           uint64_t **records = NULL, int64_t *nrec = NULL, int *rec_words = NULL)
 { if (ngpus > SMG_MAXGPU) ngpus = SMG_MAXGPU;
-  if (tv->kmer > FAST_MAX_K)
-    return fail(errbuf, errlen, SMG_EINVAL, "multi-GPU runs support k <= 85%s");
   MultiCtx *c = new (std::nothrow) MultiCtx();
   if (!c) return fail(errbuf, errlen, SMG_ENOMEM, "out of host memory%s");
   memset(c, 0, sizeof(*c));

@@ -54,7 +54,8 @@
 #define D_BMW    (D_BMF / 32)
 #define D_HB     1024                      // bins of the request histogram (smg_lookup.hpp: L_BK)
 #ifndef D_QCAP
-#define D_QCAP   1280                      // LDS request queue (records); flushed when the next tile might not fit
+#define D_QCAP   1792                      // LDS request queue (records); flushed when the next tile might not fit (every ~5th tile;
+                                           //   1280 records: every 2nd or 3rd, +0.3 ms)
 #endif
 // Scheduling fences (nothing is scheduled across them).  They were put between the tests and between the phases when
 // the machine scheduler hoisted every compare to the front and the kernel spilled lane masks (SGPR pairs) by the dozen;

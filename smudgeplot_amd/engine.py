@@ -60,10 +60,10 @@ class Stats(C.Structure):
 EXPORTS = [
     "smg_hetmers_run", "smg_hetmers_run_source", "smg_device_count", "smg_engine_create", "smg_engine_destroy",
     "smg_engine_decode", "smg_engine_bind", "smg_engine_condition", "smg_engine_run", "smg_engine_pass1",
-    "smg_engine_nreq", "smg_engine_record_words", "smg_engine_route", "smg_engine_apply",
+    "smg_engine_nreq", "smg_engine_record_words", "smg_engine_route", "smg_engine_route_device", "smg_engine_apply",
     "smg_engine_apply_own", "smg_engine_blockmap", "smg_engine_blockmap_copy", "smg_engine_filter",
     "smg_engine_presort", "smg_engine_merge_maps", "smg_engine_set_blockmap_bits",
-    "smg_engine_symhash", "smg_engine_pass2", "smg_engine_stats",
+    "smg_engine_symhash", "smg_engine_pass2", "smg_engine_stats", "smg_engine_proof",
     "smg_engine_symm_hist", "smg_engine_symm_route", "smg_engine_symm_finish", "smg_engine_table",
     "smg_engine_extract", "smg_hetmers_extract", "smg_free", "smg_condition_table", "smg_version",
 ]
@@ -123,6 +123,7 @@ def load_library():
     lib.smg_engine_nreq.argtypes = [vp]
     lib.smg_engine_record_words.argtypes = [vp]
     lib.smg_engine_route.argtypes = [vp, vp, i32, vp, i64, C.POINTER(i64), *err]
+    lib.smg_engine_route_device.argtypes = [vp, vp, i32, vp, i64, vp, *err]
     lib.smg_engine_apply.argtypes = [vp, vp, i64, C.POINTER(i64), *err]
     lib.smg_engine_apply_own.argtypes = [vp, C.POINTER(i64), *err]
     lib.smg_engine_blockmap.argtypes = [vp, C.POINTER(i32), C.POINTER(i64)]
@@ -132,6 +133,7 @@ def load_library():
     lib.smg_engine_set_blockmap_bits.argtypes = [vp, i32]
     lib.smg_engine_merge_maps.argtypes = [vp, vp, i64, i32, C.POINTER(i64), C.POINTER(i64), vp, *err]
     lib.smg_engine_symhash.argtypes = [vp, C.POINTER(C.c_uint64), *err]
+    lib.smg_engine_proof.argtypes = [vp, vp, *err]
     lib.smg_engine_symm_hist.argtypes = [vp, i32, vp, *err]
     lib.smg_engine_symm_route.argtypes = [vp, vp, i32, vp, i64, C.POINTER(i64), *err]
     lib.smg_engine_symm_finish.argtypes = [vp, vp, i64, C.POINTER(i64), *err]
@@ -332,11 +334,26 @@ class Engine:
                                          capacity, counts, self._buf, 512), self._buf)
         return [int(c) for c in counts]
 
-    def apply(self, recv_ptr: int, nrecv: int) -> int:
+    def route_device(self, splitters: np.ndarray, nranks: int, send_ptr: int, capacity: int, counts_ptr: int):
+        """route with the per-rank counts left on the device (int64[nranks] at counts_ptr): no host wait"""
+        sp = np.ascontiguousarray(splitters, dtype=np.uint64)
+        _check(self.lib.smg_engine_route_device(self.h, sp.ctypes.data if sp.size else None, nranks, send_ptr,
+                                                capacity, counts_ptr, self._buf, 512), self._buf)
+
+    def apply(self, recv_ptr: int, nrecv: int, wait: bool = True):
+        """look-ups of received requests; wait=False queues them and returns None (the count of missing complements
+        stays on the device: proof_into)"""
+        if not wait:
+            _check(self.lib.smg_engine_apply(self.h, recv_ptr, nrecv, None, self._buf, 512), self._buf)
+            return None
         missing = C.c_int64(0)
         _check(self.lib.smg_engine_apply(self.h, recv_ptr, nrecv, C.byref(missing), self._buf, 512),
                self._buf)
         return int(missing.value)
+
+    def proof_into(self, dst_ptr: int):
+        """device uint64[3] at dst_ptr <- (missing complements, fingerprint residue words), in stream order"""
+        _check(self.lib.smg_engine_proof(self.h, dst_ptr, self._buf, 512), self._buf)
 
     def apply_own(self) -> int:
         missing = C.c_int64(0)

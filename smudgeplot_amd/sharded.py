@@ -64,11 +64,20 @@ class TorchEngine:
     def record_words(self):
         return self.e.record_words()
 
-    def route(self, splitters, nranks, send):
-        return self.e.route(splitters, nranks, send.data_ptr(), send.numel() // self.e.record_words())
+    def route(self, splitters, nranks, send, counts_out=None):
+        """counts_out: int64 device tensor [nranks] -- the per-rank counts stay on the device (returns None, no host wait)"""
+        cap = send.numel() // self.e.record_words()
+        if counts_out is not None:
+            self.e.route_device(splitters, nranks, send.data_ptr(), cap, counts_out.data_ptr())
+            return None
+        return self.e.route(splitters, nranks, send.data_ptr(), cap)
 
-    def apply(self, recv, nrecv):
-        return self.e.apply(recv.data_ptr(), nrecv)
+    def apply(self, recv, nrecv, wait=True):
+        return self.e.apply(recv.data_ptr(), nrecv, wait)
+
+    def proof_into(self, dst):
+        """dst: int64 tensor of >= 3 words on the device <- (missing, fingerprint residue), in stream order"""
+        self.e.proof_into(dst.data_ptr())
 
     def apply_own(self):
         return self.e.apply_own()
@@ -340,17 +349,20 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
             eng.merge_maps(parts, width, wlo, wlen, full)
             nreq = eng.filter(full)
         send = torch.empty(max(nreq, 1) * rw, dtype=torch.int64, device=dev)
-        send_counts = eng.route(splitters, world, send)
-        sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
-        rcnt = torch.empty_like(sc)
+        # grouped on the device; the per-destination totals go from the router into the count exchange without a host
+        # round trip, and the host reads what it sends and what it receives in ONE copy
+        both = torch.empty(2 * world, dtype=torch.int64, device=dev)
+        sc, rcnt = both[:world], both[world:]
+        eng.route(splitters, world, send, counts_out=sc)
         dist.all_to_all_single(rcnt, sc, group=group)
-        recv_counts = [int(v) for v in rcnt.cpu().tolist()]
+        hb = both.cpu().tolist()
+        send_counts, recv_counts = [int(v) for v in hb[:world]], [int(v) for v in hb[world:]]
         nrecv = sum(recv_counts)
         recv = torch.empty(max(nrecv, 1) * rw, dtype=torch.int64, device=dev)
         dist.all_to_all_single(recv[: nrecv * rw], send[: nreq * rw],
                                output_split_sizes=[c * rw for c in recv_counts],
                                input_split_sizes=[c * rw for c in send_counts], group=group)
-        missing = eng.apply(recv, nrecv)
+        missing = eng.apply(recv, nrecv, wait=False)       # queued: the count of missing complements stays on the device
     else:
         nrecv = nreq
         missing = eng.apply_own()          # every complement is local: no routing, no copy
@@ -364,13 +376,21 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
     buf = torch.zeros(PLOT_CELLS + 1 + 2 * nslot, dtype=torch.int64, device=dev)
     plot = buf[:PLOT_CELLS]
     eng.pass2(plot)
-    fpw = eng.symhash()
-    proof = np.zeros(1 + 2 * nslot, dtype=np.uint64)
-    proof[0] = missing
     me = rank if exchange else 0
-    proof[1 + 2 * me] = fpw[0] ^ fpw[2]
-    proof[2 + 2 * me] = fpw[1] ^ fpw[3]
-    buf[PLOT_CELLS:] = torch.from_numpy(proof.view(np.int64).copy()).to(dev)
+    if missing is None:
+        # the engine writes (missing, residue word 0, residue word 1) on the device, in stream order: no host round
+        # trip between the look-ups and the all_reduce.  Rank r's words go to [0] (summed) and to ITS slot.
+        tmp = torch.zeros(3, dtype=torch.int64, device=dev)
+        eng.proof_into(tmp)
+        buf[PLOT_CELLS] = tmp[0]
+        buf[PLOT_CELLS + 1 + 2 * me: PLOT_CELLS + 3 + 2 * me] = tmp[1:3]
+    else:
+        fpw = eng.symhash()
+        proof = np.zeros(1 + 2 * nslot, dtype=np.uint64)
+        proof[0] = missing
+        proof[1 + 2 * me] = fpw[0] ^ fpw[2]
+        proof[2 + 2 * me] = fpw[1] ^ fpw[3]
+        buf[PLOT_CELLS:] = torch.from_numpy(proof.view(np.int64).copy()).to(dev)
     if exchange:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     pv = buf[PLOT_CELLS:].cpu().numpy().view(np.uint64)

@@ -60,8 +60,10 @@ def _plant_repeats(h1: torch.Tensor, frac: float, gen) -> None:
     ar = torch.arange(3000, device=dev)
     # dispersed: frac/2 of the genome
     unit = torch.randint(0, 4, (3000,), dtype=torch.uint8, device=dev, generator=gen)
-    ncopy = max(int(G * frac / 2 / 3000), 2)
-    starts = torch.randint(0, G - 3000, (ncopy,), device=dev, generator=gen)
+    ncopy = min(max(int(G * frac / 2 / 3000), 2), G // 3000)
+    # (starts on a grid of the segment length: two segments of one kind never overlap -- an indexed store with
+    #  duplicate indices would leave the winner to the scheduler and the table would differ from run to run)
+    starts = torch.randperm(G // 3000, device=dev, generator=gen)[:ncopy] * 3000
     idx = (starts[:, None] + ar[None, :]).reshape(-1)
     mut = torch.rand(idx.numel(), device=dev, generator=gen) < 0.02
     val = unit.repeat(ncopy)
@@ -69,14 +71,16 @@ def _plant_repeats(h1: torch.Tensor, frac: float, gen) -> None:
     h1[idx] = val
     # tandem: frac/4, segments of 1000 bases, motif length 2..24
     nseg = max(int(G * frac / 4 / 1000), 1)
-    starts = torch.randint(0, G - 1000, (nseg,), device=dev, generator=gen)
+    starts = torch.randperm(G // 1000 - 1, device=dev, generator=gen)[:nseg] * 1000 + 37
+    nseg = starts.numel()
     mlen = torch.randint(2, 25, (nseg,), device=dev, generator=gen)
     motif = torch.randint(0, 4, (nseg, 24), dtype=torch.uint8, device=dev, generator=gen)
     pos = ar[None, :1000] % mlen[:, None]
     h1[(starts[:, None] + ar[None, :1000]).reshape(-1)] = torch.gather(motif, 1, pos).reshape(-1)
     # homopolymers: frac/4, runs of 300
     nrun = max(int(G * frac / 4 / 300), 1)
-    starts = torch.randint(0, G - 300, (nrun,), device=dev, generator=gen)
+    starts = torch.randperm(G // 300 - 1, device=dev, generator=gen)[:nrun] * 300 + 111
+    nrun = starts.numel()
     base = torch.randint(0, 4, (nrun,), dtype=torch.uint8, device=dev, generator=gen)
     h1[(starts[:, None] + ar[None, :300]).reshape(-1)] = base[:, None].expand(nrun, 300).reshape(-1)
 

@@ -199,7 +199,7 @@ class NumpyEngine:
         self.req = rec[keep].reshape(-1)
         return len(self.req) // rw
 
-    def route(self, splitters, nranks, send):
+    def route(self, splitters, nranks, send, counts_out=None):
         rw = self.W + 1
         rec = self.req.reshape(-1, rw)
         sp = self._ints(np.asarray(splitters, dtype=np.uint64)) if len(splitters) else []
@@ -208,7 +208,11 @@ class NumpyEngine:
         order = np.argsort(dest, kind="stable")
         out = rec[order].reshape(-1)
         send[: len(out)] = torch.from_numpy(out.view(np.int64).copy())
-        return [int((dest == r).sum()) for r in range(nranks)]
+        counts = [int((dest == r).sum()) for r in range(nranks)]
+        if counts_out is not None:
+            counts_out.copy_(torch.tensor(counts, dtype=torch.int64))
+            return None
+        return counts
 
     def _apply(self, rec):
         rw = self.W + 1
@@ -225,8 +229,13 @@ class NumpyEngine:
                 self.P[j] = 1
         return bad
 
-    def apply(self, recv, nrecv):
-        return self._apply(recv[: nrecv * (self.W + 1)].cpu().numpy().view(np.uint64))
+    def apply(self, recv, nrecv, wait=True):
+        self.missing = self._apply(recv[: nrecv * (self.W + 1)].cpu().numpy().view(np.uint64))
+        return self.missing if wait else None
+
+    def proof_into(self, dst):
+        w = np.array([self.missing, self.fp[0] ^ self.fp[2], self.fp[1] ^ self.fp[3]], dtype=np.uint64)
+        dst[:3] = torch.from_numpy(w.view(np.int64).copy())
 
     def apply_own(self):
         return self._apply(self.req)

@@ -170,7 +170,7 @@ def test_extract_on_raw_table_conditions_first(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shards", [3, 6])
-@pytest.mark.parametrize("name", ["k31_i1", "k51_i1_p3", "k65_i1"])
+@pytest.mark.parametrize("name", ["k31_i1", "k51_i1_p3", "k65_i1", "k100_i1", "k100_wrap"])
 def test_extract_over_prefix_shards_matches_reference_golden(name, shards, monkeypatch):
     """PloidyList.c:1207-1583 has no size or device limit: the extract leg over a table that is cut into prefix shards
     (several GPUs, or more than 2^32 entries on one) -- every shard lists the pairs among its own entries, the host

@@ -186,6 +186,43 @@ def test_large_table_sorted_lookup_path_vs_reference_binary(tmp_path, monkeypatc
     assert (tmp_path / "ref.smu").read_text() == texts["hash"]
 
 
+def test_repeat_rich_table_vs_reference_binary(tmp_path, monkeypatch):
+    """5 % of the genome are dispersed copies, tandem arrays and homopolymer runs (bench.py --workload repeats): window
+    blocks of hundreds to thousands of entries, so the deferred entries (kf_collect / kf_bigfix), the prefix-narrowing
+    block walk and the far partners of pass 2 (kf_pass2_far) all carry real weight -- against the REFERENCE binary,
+    on one shard and on three, and the table generator must give the same table twice"""
+    import torch
+    from conftest import REF_BIN
+    from smudgeplot_amd import synth_device
+    if not os.path.exists(REF_BIN):
+        pytest.skip("prebuilt reference binary not present")
+    k = 31
+    dev = torch.device("cuda:0")
+    tk, tc = synth_device.diploid_table(4_000_000, k=k, het=0.01, cov=50.0, L=10, seed=11, device=dev, repeats=0.05)
+    tk2, tc2 = synth_device.diploid_table(4_000_000, k=k, het=0.01, cov=50.0, L=10, seed=11, device=dev, repeats=0.05)
+    assert torch.equal(tk, tk2) and torch.equal(tc, tc2), "the repeats generator is not deterministic"
+    keys = tk.cpu().numpy().view(np.uint64)
+    cnt = tc.cpu().numpy().view(np.uint16)
+    synth.write_u64_table(str(tmp_path / "t"), keys, cnt, k, ibyte=2, nparts=3)
+    r = subprocess.run([REF_BIN, "-e10", f"-T{min(16, os.cpu_count() or 1)}", "-oref", "t.ktab"], cwd=tmp_path,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    want = (tmp_path / "ref.smu").read_text()
+    plot = torch.zeros(engine.PLOT_CELLS, dtype=torch.int64, device=dev)
+    e = engine.Engine(0)
+    e.bind(k, len(cnt), tk.data_ptr(), tc.data_ptr())
+    for mode in ("hash", "exact"):
+        st = e.run(plot.data_ptr(), mode)
+        torch.cuda.synchronize()
+        assert st["path"] == 1 and st["nbig"] > 10000, st
+        assert engine.smu_text(plot.cpu().numpy().reshape(1001, 501)) == want, mode
+    for env in ({"SMG_VIRTUAL_SHARDS": "3"}, {}):
+        r = subprocess.run([HETMERS_BIN, "-e10", "-T4", "-ogpu", "t.ktab"], cwd=tmp_path, capture_output=True, text=True,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr
+        assert (tmp_path / "gpu.smu").read_text() == want, env
+
+
 def test_engine_object_with_torch_tensors_and_manual_two_shard_exchange():
     """phase-level API on device tensors; then the same table split into two prefix shards on
     one GPU with the request exchange done by hand (what sharded.py does with all_to_all)"""
@@ -265,7 +302,7 @@ def test_request_filter_changes_nothing_but_the_request_count(k, m, seed, monkey
         assert st_f["nrequests"] < st_f["nemitted"]
 
 
-@pytest.mark.parametrize("k,symcheck", [(31, "hash"), (12, "hash"), (31, "exact"), (40, "hash")])
+@pytest.mark.parametrize("k,symcheck", [(31, "hash"), (12, "hash"), (31, "exact"), (40, "hash"), (97, "hash"), (128, "exact")])
 def test_sharded_driver_on_the_real_backend_one_rank_group(k, symcheck, monkeypatch):
     """`sharded.hetmers_sharded` as bench.py runs it for N > 1 -- splitter all_gather, block-map all_gather, request
     filter, route, all_to_all_single of counts and requests, apply, all_reduce of histogram + proof -- on RCCL with the
@@ -642,6 +679,46 @@ def test_multi_gpu_path_virtual_shards_golden(name, shards, monkeypatch):
         plot, st = engine.hetmers_run(make_table(g), symcheck=mode)
         assert engine.smu_text(plot) == g["smu"], (name, shards, mode)
         assert st["nels"] == len(g["counts"]) and st["path"] == 1
+
+
+@pytest.mark.parametrize("shards", [2, 5])
+@pytest.mark.parametrize("name", ["k100_i1", "k100_wrap"])
+def test_multi_gpu_path_above_k_85_golden(name, shards, monkeypatch):
+    """k > 85 (a uint8 degree can wrap, PloidyPlot.c:163): the counted kernels in the steps of the sharded protocol --
+    flat record list through the router, degrees added on the owner shard, no block map; the reference has no k limit"""
+    g = load_golden(name)
+    monkeypatch.setenv("SMG_VIRTUAL_SHARDS", str(shards))
+    for mode in ("hash", "exact"):
+        plot, st = engine.hetmers_run(make_table(g), symcheck=mode)
+        assert engine.smu_text(plot) == g["smu"], (name, shards, mode)
+        assert st["nels"] == len(g["counts"]) and st["path"] == 1
+    monkeypatch.delenv("SMG_VIRTUAL_SHARDS")
+    monkeypatch.setenv("SMG_FORCE_MULTI", "1")             # a one-rank RCCL communicator: send/recv to self, all-reduce
+    plot, st = engine.hetmers_run(make_table(g), symcheck="hash")
+    assert engine.smu_text(plot) == g["smu"]
+
+
+@pytest.mark.parametrize("k,seed,shards", [(86, 31, 3), (97, 32, 4), (128, 33, 2)])
+def test_multi_gpu_path_above_k_85_fresh_tables_and_raw_input(k, seed, shards, monkeypatch):
+    """fresh tables at three- and four-word k against the brute-force restatement, cut into shards; then the RAW table
+    (canonical k-mers, some below the threshold) trimmed and closed ACROSS the shards first; then a table that is not
+    closed: the shards take the general path together"""
+    (rp, rcnt), (cp, cc) = _raw_table(k, seed, 4)
+    want = brute.hetmers_plot(cp, cc, k)
+    monkeypatch.setenv("SMG_VIRTUAL_SHARDS", str(shards))
+    for mode in ("hash", "exact"):
+        plot, st = engine.hetmers_run(table_from(cp, cc, k), symcheck=mode)
+        assert np.array_equal(plot, want), (k, mode)
+        assert st["path"] == 1
+    plot, st = engine.hetmers_run(table_from(rp, rcnt, k), symcheck="hash",
+                                  condition=engine.COND_TRIM | engine.COND_SYMM, ethresh=4)
+    assert np.array_equal(plot, want)
+    assert st["nels"] == len(cc)
+    keep = np.ones(len(cc), bool)
+    keep[len(cc) // 3] = False                                         # one complement missing
+    want_g = brute.hetmers_plot(cp[keep], cc[keep], k)
+    plot, st = engine.hetmers_run(table_from(cp[keep], cc[keep], k), symcheck="hash")
+    assert np.array_equal(plot, want_g) and st["path"] == 2
 
 
 def test_multi_gpu_path_small_k_wide_index(monkeypatch):

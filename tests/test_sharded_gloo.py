@@ -123,7 +123,8 @@ def _wide_table(k, m, seed):
     return packed, np.ascontiguousarray(buf.view(">u8").astype(np.uint64)), cnt
 
 
-@pytest.mark.parametrize("world,k,symcheck", [(2, 40, "hash"), (3, 51, "hash"), (2, 51, "exact"), (2, 70, "hash")])
+@pytest.mark.parametrize("world,k,symcheck", [(2, 40, "hash"), (3, 51, "hash"), (2, 51, "exact"), (2, 70, "hash"),
+                                                 (2, 100, "hash"), (3, 128, "exact")])
 def test_two_and_three_word_kmers_through_the_sharded_driver(world, k, symcheck):
     """BASELINE configs[4] is k = 51: records of W + 1 words, splitters of W words, block ids from word 0"""
     packed, keys, cnt = _wide_table(k, 700, 90 + k)
