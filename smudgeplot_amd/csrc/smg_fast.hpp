@@ -78,7 +78,7 @@ struct FastCtl                    // device control words of the fast path
 { unsigned n_chunks;             // chunks handed out (may exceed max_chunks => rerun)
   unsigned missing;              // a complement was absent or carried another count
   unsigned unsorted;             // order violation seen
-  unsigned pad;
+  unsigned bf_next;              // kf_bigfix: the next slab of the deferred-entry list to be taken
   u64      nreq;                 // requests written
   unsigned nbig;                 // entries deferred to kf_bigfix (window block longer than the halo)
   unsigned nf_chunks;            // kf_filter: chunks of the filtered request list
@@ -125,8 +125,8 @@ template <int W> SMG_DEV int first_diff(const Key<W> &x, const Key<W> &y)
 //  block one after the other: ~550 dependent loads per entry; this one needs ~40 for a block of 500 entries.)
 #define BB_LIN  24
 
-template <int W> __device__ __noinline__ void
-big_block_scan(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, int64_t n,
+template <int W> __device__ __forceinline__ void
+big_block_walk(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, int64_t n,
                const Geo g, int64_t i, unsigned &s_all, unsigned &s_hi, int64_t &partner,
                unsigned &w2)
 { const Key<W> x = load_key<W>(keys, i);
@@ -231,6 +231,14 @@ big_block_scan(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, i
           }
     }
 }
+
+// out of line for the kernels that meet a long block once in a while (kf_bigfix inlines the walk: its register budget
+// is the walk's)
+template <int W> __device__ __noinline__ void
+big_block_scan(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, int64_t n,
+               const Geo g, int64_t i, unsigned &s_all, unsigned &s_hi, int64_t &partner,
+               unsigned &w2)
+{ big_block_walk<W>(keys, cnt, n, g, i, s_all, s_hi, partner, w2); }
 
 SMG_DEV unsigned make_code(unsigned s_all, int64_t delta, unsigned w2)
 { if (s_all == 0) return CODE_NONE;
@@ -823,12 +831,20 @@ template <int W> SMG_DEV void p2_far_entry(const FastArgs &A, int64_t i, u64 *__
   atomicAdd(plot + (size_t) sm * SMG_PLOT_COLS + mn, (u64) (w2 ? 2u : 1u));
 }
 
+// (kf_bigfix left the partner of such an entry in farp[q]: nothing is searched again)
 template <int W> __global__ void __launch_bounds__(256)
-kf_pass2_far(FastArgs A, const uint32_t *__restrict__ list, unsigned nlist, u64 *__restrict__ plot)
+kf_pass2_far(FastArgs A, const uint32_t *__restrict__ list, const uint32_t *__restrict__ farp, unsigned nlist, u64 *__restrict__ plot)
 { for (unsigned q = blockIdx.x * blockDim.x + threadIdx.x; q < nlist; q += gridDim.x * blockDim.x)
     { const int64_t i = list[q];
       const unsigned ci = A.code[i];
-      if ((ci & 63) == CODE_FAR && !(ci & CODE_P)) p2_far_entry<W>(A, i, plot);
+      if ((ci & 63) != CODE_FAR || (ci & CODE_P)) continue;
+      const int64_t j = farp[q];
+      if (j <= i) continue;
+      const unsigned cj = A.code[j], lj = cj & 63;
+      if (lj == CODE_NONE || lj == CODE_MULTI || (cj & CODE_P)) continue;
+      const unsigned ni = A.cnt[i], nj = A.cnt[j];
+      const unsigned sm = ni + nj, mn = ni < nj ? ni : nj;
+      atomicAdd(plot + (size_t) sm * SMG_PLOT_COLS + mn, (u64) ((ci & CODE_W2) ? 2u : 1u));
     }
 }
 
@@ -1072,7 +1088,7 @@ block_scan(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, int64
   { const int64_t lo = i - BF_LIN - 1, hi = i + BF_LIN + 1;
     const bool far_lo = lo >= 0 && same_block<W>(x, load_key<W>(keys, lo >= 0 ? lo : i), g);
     const bool far_hi = hi < n && same_block<W>(x, load_key<W>(keys, hi < n ? hi : i), g);
-    if (far_lo || far_hi) { big_block_scan<W>(keys, cnt, n, g, i, s_all, s_hi, partner, w2); return; }
+    if (far_lo || far_hi) { big_block_walk<W>(keys, cnt, n, g, i, s_all, s_hi, partner, w2); return; }
   }
   const unsigned c = cnt[i];
   s_all = 0; s_hi = 0; partner = -1; w2 = 0;
@@ -1141,48 +1157,63 @@ kf_collect(uint32_t *__restrict__ dbits, int64_t nwords, uint32_t *__restrict__ 
     }
 }
 
+// Work is dealt out twice: a workgroup takes a SLAB of BF_SLAB listed entries at a time (global counter: the entries of
+// a repeat region sit next to each other in the list), its waves take 64 of them at a time (LDS counter) and run without
+// a barrier until the slab is done -- a walk through a block of a thousand entries holds up its own wave, not the other
+// fifteen (the first version synchronised the workgroup after every 1024 entries: it waited for the longest walk 9000
+// times).  Entries that owe a request are only noted; after the slab's barrier the workgroup writes their requests out.
+#define BF_SLAB  8192
+
 template <int W, int RW> __global__ void __launch_bounds__(BF_TPB)
 kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, const unsigned *__restrict__ pcount, unsigned cap, u64 *__restrict__ req,
           uint32_t *__restrict__ chunk_fill, unsigned max_chunks, FastCtl *__restrict__ ctl,
-          unsigned *__restrict__ whist /* this kernel's rows */, unsigned owner0, unsigned owners, int hbits)
+          unsigned *__restrict__ whist /* this kernel's rows */, unsigned owner0, unsigned owners, int hbits,
+          uint32_t *__restrict__ farp /* [cap]: the partner of a listed entry whose code says "out of reach" */)
 { constexpr int rw = RW;
-  __shared__ u64      sq[BF_TPB * RW];
+  __shared__ uint32_t slist[BF_SLAB];   // entries of the slab that owe a request
   __shared__ unsigned hist[1024];       // requests of this workgroup per look-up bucket (a row of whist, like pass 1's)
-  __shared__ unsigned s_qn, s_chunk, s_used;
+  __shared__ unsigned s_nl, s_next, s_slab, s_chunk, s_used;
   __shared__ u64      s_base, s_total;
-  const int t = threadIdx.x;
-  if (t == 0) { s_qn = 0; s_chunk = F_NOCHUNK; s_used = 0; s_total = 0; }
+  const int t = threadIdx.x, lane = t & 63;
+  if (t == 0) { s_chunk = F_NOCHUNK; s_used = 0; s_total = 0; }
   for (int b = t; b < 1024; b += BF_TPB) hist[b] = 0;
-  __syncthreads();
   const unsigned nbig = *pcount;
   if (nbig > cap) return;                // the list overflowed (it has holes at its end): the host grows it and redoes the run
-  for (unsigned r0 = blockIdx.x * BF_TPB; r0 < nbig; r0 += gridDim.x * BF_TPB)
-    { const unsigned r = r0 + t;
-      if (r < nbig)
-        { const int64_t i = biglist[r];
-          unsigned s_all, s_hi, w2;
-          int64_t partner;
-          block_scan<W>(A.keys, A.cnt, A.n, A.g, i, s_all, s_hi, partner, w2);
-          A.code[i] = (uint8_t) make_code(s_all, partner - i, w2);
-          if (W <= 2 && A.bmap && s_all == 1)             // a candidate: mark its block for the request filter
-            { const uint32_t id = (uint32_t) (A.keys[i * W] >> 32) >> A.bmsh;
-              if (A.bm2) atomicOr(reinterpret_cast<u64 *>(A.bmap) + (id >> 5), bm2_bits(id, (uint32_t) A.keys[i * W]));
-              else atomicOr(&A.bmap[id >> 5], 1u << (id & 31));
-            }
-          if (s_hi > 0)
-            { const Key<W> kx = load_key<W>(A.keys, i);
-              const Key<W> rc = revcomp<W>(kx, A.g.k);
-              const unsigned q = atomicAdd(&s_qn, 1u);
-#pragma unroll
-              for (int w = 0; w < W; w++) sq[q * rw + w] = rc.w[w];
-              if (rw > W) sq[q * rw + W] = (u64) A.cnt[i] | (1ull << 16);
-              if (whist && hbits) atomicAdd(&hist[(unsigned) (rc.w[0] >> 32) >> (32 - hbits)], 1u);
+  for (;;)
+    { __syncthreads();
+      if (t == 0) { s_slab = atomicAdd(&ctl->bf_next, (unsigned) BF_SLAB); s_next = 0; s_nl = 0; }
+      __syncthreads();
+      const unsigned slab0 = s_slab;
+      if (slab0 >= nbig) break;
+      const unsigned slab_n = nbig - slab0 < BF_SLAB ? nbig - slab0 : BF_SLAB;
+      for (;;)
+        { unsigned b = 0;
+          if (lane == 0) b = atomicAdd(&s_next, 64u);
+          b = (unsigned) __builtin_amdgcn_readfirstlane((int) b);
+          if (b >= slab_n) break;
+          if (b + lane < slab_n)
+            { const unsigned r = slab0 + b + lane;
+              const int64_t i = biglist[r];
+              unsigned s_all, s_hi, w2;
+              int64_t partner;
+              block_scan<W>(A.keys, A.cnt, A.n, A.g, i, s_all, s_hi, partner, w2);
+              const unsigned code = make_code(s_all, partner - i, w2);
+              A.code[i] = (uint8_t) code;
+              if ((code & 63) == CODE_FAR) farp[r] = (uint32_t) partner;
+              if (W <= 2 && A.bmap && s_all == 1)             // a candidate: mark its block for the request filter
+                { const uint32_t id = (uint32_t) (A.keys[i * W] >> 32) >> A.bmsh;
+                  if (A.bm2) atomicOr(reinterpret_cast<u64 *>(A.bmap) + (id >> 5), bm2_bits(id, (uint32_t) A.keys[i * W]));
+                  else atomicOr(&A.bmap[id >> 5], 1u << (id & 31));
+                }
+              if (s_hi > 0) slist[atomicAdd(&s_nl, 1u)] = (uint32_t) i;
             }
         }
       __syncthreads();
-      const unsigned qn = s_qn;
-      if (qn > 0)
-        { if (t == 0)
+      // the slab's requests, BF_TPB at a time into the workgroup's chunks
+      const unsigned nl = s_nl;
+      for (unsigned q0 = 0; q0 < nl; q0 += BF_TPB)
+        { const unsigned qn = nl - q0 < BF_TPB ? nl - q0 : BF_TPB;
+          if (t == 0)
             { if (s_chunk == F_NOCHUNK || s_used + qn > F_CH)
                 { if (s_chunk != F_NOCHUNK && s_chunk < max_chunks) chunk_fill[s_chunk] = s_used;
                   // (look-up chain: chunk slots owner, owner + owners, .. as in pass 1; this kernel's owners follow pass 1's)
@@ -1191,21 +1222,29 @@ kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, const unsigned *__re
                   s_used = 0;
                 }
               s_base = (u64) s_chunk * F_CH + s_used;
-              s_used += qn; s_total += qn; s_qn = 0;
+              s_used += qn; s_total += qn;
             }
           __syncthreads();
-          if (s_chunk < max_chunks)
-            { u64 *o = req + s_base * rw;
-              for (unsigned e = t; e < qn * rw; e += BF_TPB) o[e] = sq[e];
+          if ((unsigned) t < qn)
+            { const int64_t i = slist[q0 + t];
+              const Key<W> rc = revcomp<W>(load_key<W>(A.keys, i), A.g.k);
+              if (s_chunk < max_chunks)
+                { u64 *o = req + (s_base + t) * rw;
+#pragma unroll
+                  for (int w = 0; w < W; w++) o[w] = rc.w[w];
+                  if (rw > W) o[W] = (u64) A.cnt[i] | (1ull << 16);
+                }
+              if (whist && hbits) atomicAdd(&hist[(unsigned) (rc.w[0] >> 32) >> (32 - hbits)], 1u);
             }
+          __syncthreads();
         }
-      __syncthreads();
     }
   if (t == 0)
     { if (s_chunk != F_NOCHUNK && s_chunk < max_chunks) chunk_fill[s_chunk] = s_used;
       if (whist && hbits && s_chunk != F_NOCHUNK) atomicMax(&ctl->n_chunks, s_chunk + 1u);
       if (s_total) atomicAdd(&ctl->nreq, s_total);
     }
+  __syncthreads();
   if (whist && hbits)
     for (int b = t; b < 1024; b += BF_TPB) whist[(size_t) blockIdx.x * 1024 + b] = hist[b];
 }

@@ -583,6 +583,7 @@ struct smg_engine
   uint32_t    *dbits;  int64_t dbits_cap;      // deferred entries of kf_pass1_d: one bit per table entry (bytes); all zero between runs
   bool         dbits_dirty;                     //   ... unless a run was abandoned between pass 1 and kf_bigfix
   uint32_t    *biglist; int64_t biglist_cap;    // the marked entries, compacted (kf_collect), bytes
+  uint32_t    *farp;    int64_t farp_cap;       // beside it: the partner of a listed entry whose code is CODE_FAR (kf_bigfix -> kf_pass2_far)
   int          rw;                           // 64-bit words per request record
   uint32_t    *chunk_fill; int64_t chunk_cap; // bytes
   unsigned     max_chunks;
@@ -688,7 +689,7 @@ extern "C" void smg_engine_destroy(smg_engine *e)
   hipSetDevice(e->device);
   hipStreamSynchronize(e->stream);
   hipFree(e->own_keys); hipFree(e->own_cnt); hipFree(e->deg); hipFree(e->sig); hipFree(e->bstart);
-  hipFree(e->req); hipFree(e->req2); hipFree(e->sort_tmp); hipFree(e->dense); hipFree(e->chunk_off); hipFree(e->skey[0]); hipFree(e->skey[1]); hipFree(e->sidx[0]); hipFree(e->sidx[1]); hipFree(e->dbits); hipFree(e->biglist); hipFree(e->chunk_fill); hipFree(e->bmap); hipFree(e->reqf); hipFree(e->chunk_fillf); hipFree(e->route_cnt); hipFree(e->route_off);
+  hipFree(e->req); hipFree(e->req2); hipFree(e->sort_tmp); hipFree(e->dense); hipFree(e->chunk_off); hipFree(e->skey[0]); hipFree(e->skey[1]); hipFree(e->sidx[0]); hipFree(e->sidx[1]); hipFree(e->dbits); hipFree(e->biglist); hipFree(e->farp); hipFree(e->chunk_fill); hipFree(e->bmap); hipFree(e->reqf); hipFree(e->chunk_fillf); hipFree(e->route_cnt); hipFree(e->route_off);
   hipFree(e->partials); hipFree(e->ctrl); hipFree(e->d_split); hipFree(e->p1cold); hipFree(e->ghist); hipFree(e->boff);
   hipFree(e->whist);
   hipHostFree(e->h_ctrl); hipHostFree(e->h_partials); hipHostFree(e->h_p1cold);
@@ -1215,6 +1216,7 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
           if (want_big < e->biglist_cap / 4) want_big = e->biglist_cap / 4;
           if (want_big > 0xFFFFFFF0ll) want_big = 0xFFFFFFF0ll;
           if ((rc = grow(&e->biglist, &e->biglist_cap, want_big * 4, errbuf, errlen))) return rc;
+          if ((rc = grow(&e->farp, &e->farp_cap, e->biglist_cap, errbuf, errlen))) return rc;
           bigcap = (unsigned) (e->biglist_cap / 4 > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : e->biglist_cap / 4);
           unsigned cb = (unsigned) ((dwords / 4 + BF_TPB - 1) / BF_TPB);
           if (cb > BF_MAXGRID) cb = BF_MAXGRID;
@@ -1222,7 +1224,7 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
           hipLaunchKernelGGL(kf_collect, dim3(cb), dim3(BF_TPB), 0, e->stream, e->dbits, dwords, e->biglist, bigcap, &e->ctrl->fast.nbig);
 #define BIGFIX(W_, RW_) hipLaunchKernelGGL((kf_bigfix<W_, RW_>), dim3(BF_MAXGRID), dim3(BF_TPB), 0, e->stream, a, e->biglist, &e->ctrl->fast.nbig, bigcap, e->req, \
                               e->chunk_fill, maxc, &e->ctrl->fast, e->lg.nb ? e->whist + (size_t) grid * L_BK : (unsigned *) NULL, \
-                              grid, grid + BF_MAXGRID, e->lg.nb)
+                              grid, grid + BF_MAXGRID, e->lg.nb, e->farp)
           if (e->W == 2 && e->rw == 2) BIGFIX(2, 2); else if (e->W == 2) BIGFIX(2, 3); else if (e->rw == 1) BIGFIX(1, 1); else BIGFIX(1, 2);
 #undef BIGFIX
           hipEventRecord(e->ev[3], e->stream);
@@ -1576,8 +1578,8 @@ static int fast_pass2(smg_engine *e, int64_t *d_plot, bool with_sum, char *errbu
         { const unsigned nl = (unsigned) e->st.nbig;
           unsigned fb = (nl + 255) / 256;
           if (fb > 4096) fb = 4096;
-          if (nl && e->W == 1) hipLaunchKernelGGL(kf_pass2_far<1>, dim3(fb), dim3(256), 0, e->stream, a, (const uint32_t *) e->biglist, nl, (u64 *) d_plot);
-          else if (nl)         hipLaunchKernelGGL(kf_pass2_far<2>, dim3(fb), dim3(256), 0, e->stream, a, (const uint32_t *) e->biglist, nl, (u64 *) d_plot);
+          if (nl && e->W == 1) hipLaunchKernelGGL(kf_pass2_far<1>, dim3(fb), dim3(256), 0, e->stream, a, (const uint32_t *) e->biglist, (const uint32_t *) e->farp, nl, (u64 *) d_plot);
+          else if (nl)         hipLaunchKernelGGL(kf_pass2_far<2>, dim3(fb), dim3(256), 0, e->stream, a, (const uint32_t *) e->biglist, (const uint32_t *) e->farp, nl, (u64 *) d_plot);
         }
       else
         { int64_t fb = ((e->n + 15) / 16 + 255) / 256;

@@ -260,46 +260,77 @@ static void revcomp_packed(const uint8_t *x, uint8_t *out, int k, int kbyte)
     }
 }
 
+/* One worker of the trim probe: the smallest count >= 1 among the entries [a, b) of the table (0x8000: none).
+   The reference builds a histogram of these counts and takes its first non-empty bin above 0 (PloidyPlot.c:1169-1197):
+   the decision needs the minimum only.  A worker stops as soon as it has seen a count below the threshold -- the
+   decision is made then, whatever the rest holds.                                                                    */
+typedef struct { const smg_ktab *t; int64_t a, b; int ethresh, minc, bad; } ProbeJob;
+
+static void *probe_worker(void *arg)
+{ ProbeJob *j = (ProbeJob *) arg;
+  const smg_ktab *t = j->t;
+  const int64_t blk = 65536;
+  uint8_t *buf = (uint8_t *) malloc((size_t) blk * (size_t) t->pbyte);
+  int p, minc = 0x8000;
+  j->minc = 0x8000; j->bad = 0;
+  if (buf == NULL) { j->bad = 2; return NULL; }
+  for (p = 0; p < t->nparts && !j->bad && minc >= j->ethresh; p++)
+    { const int64_t pb = p ? t->part_end[p - 1] : 0, pe = t->part_end[p];
+      const int64_t a = j->a > pb ? j->a : pb, b = j->b < pe ? j->b : pe;
+      int64_t i;
+      for (i = a; i < b && minc >= j->ethresh; i += blk)
+        { const int64_t m = b - i < blk ? b - i : blk;
+          int64_t q;
+          const uint8_t *r = buf;
+          if (t->part[p] != NULL) r = t->part[p] + (size_t) (i - pb) * (size_t) t->pbyte;
+          else if (smg_ktab_read(t, p, i - pb, m, buf) != 0) { j->bad = 1; break; }     /* a partial look would call an
+                                                                                            unreadable table "trimmed" */
+          r += t->hbyte;
+          for (q = 0; q < m; q++, r += t->pbyte)
+            { const int c = r[0] | (r[1] << 8);        /* (the reference reads an int16: counts above 32767 are outside
+                                                           what it and FastK support, they are ignored here)           */
+              if (c >= 1 && c < minc) minc = c;
+            }
+        }
+    }
+  free(buf);
+  j->minc = minc;
+  return NULL;
+}
+
 int smg_ktab_examine(const smg_ktab *t, int ethresh, int *trim, int *symm)
-{ int64_t frst, last, i, nz;
-  int     bad = 0;
-  int64_t *hist = (int64_t *) calloc(0x8000, sizeof(int64_t));
+{ return smg_ktab_examine_mt(t, ethresh, 1, trim, symm); }
+
+int smg_ktab_examine_mt(const smg_ktab *t, int ethresh, int nthreads, int *trim, int *symm)
+{ int64_t frst, last;
+  int     bad = 0, nz = 0x8000, w, started = 0;
+  ProbeJob job[16];
+  pthread_t th[16];
 
   *trim = 0; *symm = 0;
-  if (hist == NULL) return SMG_KTAB_NOMEM;
-
-  /* "Histogram of middle 100M counts and see if trimmed to ETHRESH", PloidyPlot.c:1169-1197.
-     The reference indexes with the count read as int16; counts above 32767 are outside what
-     it (and FastK) supports, they are ignored here instead of writing out of bounds.        */
+  /* "Histogram of middle 100M counts and see if trimmed to ETHRESH", PloidyPlot.c:1169-1197 */
   if (t->nels + 3 < 100000000) { frst = 0; last = t->nels; }
   else { frst = t->nels / 2 - 50000000; last = t->nels / 2 + 50000000; }
-  { /* part by part, 64K records at a time (from memory or, for a table left on disk, by pread) */
-    const int64_t blk = 65536;
-    uint8_t *buf = (uint8_t *) malloc((size_t) blk * (size_t) t->pbyte);
-    int p;
-    if (buf == NULL) { free(hist); return SMG_KTAB_NOMEM; }
-    for (p = 0; p < t->nparts && !bad; p++)
-      { const int64_t pb = p ? t->part_end[p - 1] : 0, pe = t->part_end[p];
-        int64_t a = frst > pb ? frst : pb, b = last < pe ? last : pe;
-        for (i = a; i < b; i += blk)
-          { const int64_t m = b - i < blk ? b - i : blk;
-            int64_t j;
-            const uint8_t *r = buf;
-            if (t->part[p] != NULL) r = t->part[p] + (size_t) (i - pb) * (size_t) t->pbyte;
-            else if (smg_ktab_read(t, p, i - pb, m, buf) != 0) { bad = 1; break; }   /* a partial histogram would call
-                                                                                         an unreadable table "trimmed" */
-            for (j = 0; j < m; j++, r += t->pbyte)
-              { int c = r[t->hbyte] | (r[t->hbyte + 1] << 8);
-                if (c < 0x8000) hist[c] += 1;
-              }
-          }
-      }
-    free(buf);
-  }
-  if (bad) { free(hist); return SMG_KTAB_SHORT; }
-  for (nz = 1; nz < 0x8000 && hist[nz] == 0; nz++) ;
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 16) nthreads = 16;
+  if (last - frst < 1000000) nthreads = 1;
+  for (w = 0; w < nthreads; w++)
+    { job[w].t = t; job[w].ethresh = ethresh;
+      job[w].a = frst + (last - frst) / nthreads * w;
+      job[w].b = w == nthreads - 1 ? last : frst + (last - frst) / nthreads * (w + 1);
+    }
+  for (w = 1; w < nthreads; w++)
+    { if (pthread_create(&th[started], NULL, probe_worker, &job[w]) == 0) started++;
+      else { int v; for (v = w; v < nthreads; v++) probe_worker(&job[v]); break; }      /* (no thread: do it here) */
+    }
+  probe_worker(&job[0]);
+  for (w = 0; w < started; w++) pthread_join(th[w], NULL);
+  for (w = 0; w < nthreads; w++)
+    { if (job[w].bad > bad) bad = job[w].bad;
+      if (job[w].minc < nz) nz = job[w].minc;
+    }
+  if (bad) return bad == 2 ? SMG_KTAB_NOMEM : SMG_KTAB_SHORT;
   *trim = (nz >= ethresh);
-  free(hist);
 
   /* "Walk to a non-palindromic k-mer and see if its complement is in T", PloidyPlot.c:1199-1229.
      Net effect of that loop (including its quirk for a self-complementary entry #1, see

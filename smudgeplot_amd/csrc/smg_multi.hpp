@@ -199,6 +199,7 @@ static void *multi_worker(void *argp)
   // ---- shard on the device -------------------------------------------------------------------------------
   if (hipSetDevice(c->devs[r]) != hipSuccess) MFAIL(SMG_ENODEV, "cannot select HIP device");
   if (MOK && !(e = smg_engine_create(c->devs[r], NULL, eb, el))) { c->rc[r] = SMG_ENODEV; c->failed = 1; }
+  if (MOK && !c->virt && n >= 8) smg_engine_set_blockmap_bits(e, 29);     // (the exchanged map: see TorchEngine.pass1 in sharded.py)
   const int64_t lo = c->cut[r], hi = c->cut[r + 1], ns = hi - lo;
   const size_t ixbytes = sizeof(int64_t) << (8 * tv->ibyte);
   if (MOK)

@@ -53,9 +53,12 @@ class TorchEngine:
         self.words = (k + 31) // 32
         self.e.bind(k, counts.numel(), keys.data_ptr(), counts.data_ptr())
 
-    def pass1(self, symcheck, exchange=True):
-        # nobody to exchange block maps with: the finest map (32 id bits) costs nothing but its memset
-        self.e.set_blockmap_bits(0 if exchange else 32)
+    def pass1(self, symcheck, exchange=True, world=1):
+        # nobody to exchange block maps with: the finest map (32 id bits) costs nothing but its memset.  Exchanged maps:
+        # 30 id bits (256 MB over all ranks); from 8 ranks on 29 -- a rank's share of the requests is small enough that
+        # the coarser map costs nothing (profiles/r03_rank_share_forced_exchange.txt: 3.21 vs 3.30 ms at 1/8 of the table)
+        # and the all_gather, whose size does not shrink with the number of ranks, is halved
+        self.e.set_blockmap_bits((29 if world >= 8 else 0) if exchange else 32)
         self.e.pass1(symcheck)
 
     def nreq(self):
@@ -322,7 +325,7 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
     else:
         splitters, sizes = np.zeros(0, np.uint64), [n]
 
-    eng.pass1(symcheck, exchange)
+    eng.pass1(symcheck, exchange, world)
     rw = eng.record_words()
     nreq = eng.nreq()
 

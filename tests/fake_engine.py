@@ -113,7 +113,7 @@ class NumpyEngine:
         self.n = len(xs)
         return self.n
 
-    def pass1(self, symcheck, exchange=True):
+    def pass1(self, symcheck, exchange=True, world=1):
         k, keys, cnt, n = self.k, self.keys, self.cnt, self.n
         bits = 64 * self.W
         p0 = k // 2

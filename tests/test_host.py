@@ -145,6 +145,24 @@ def test_hetmers_conditioning_decision_and_no_cpu_fallback(tmp_path):
         engine.Engine(0)
 
 
+def test_trim_probe_over_several_threads_sees_a_single_low_count(tmp_path):
+    """the count scan of the probe runs on several threads above 1e6 entries: one count below the threshold, in the range
+    of the last thread (or the first, or nowhere), must give the reference's decision (PloidyPlot.c:1169-1197)"""
+    if engine.device_count() > 0:
+        pytest.skip("a GPU is visible: the run would go on")
+    k = 31
+    keys, cnt = synth.diploid_table_u64(600000, k=k, seed=21, het_frac=0.01, cov=40, L=8)
+    assert len(cnt) > 1_000_000
+    for where, want in ((None, "trimmed"), (len(cnt) - 7, "untrimmed"), (3, "untrimmed")):
+        c = cnt.copy()
+        if where is not None:
+            c[where] = 5
+        synth.write_u64_table(str(tmp_path / "t"), keys, c, k, ibyte=2, nparts=3)
+        r = run(["-e8", "-v", "-T8", "-oout", "t"], tmp_path)
+        assert r.returncode == 1
+        assert f"  The input table is {want}" in r.stderr, (where, r.stderr)
+
+
 def test_blockmap_ranges_cover_the_map_and_share_only_boundary_words():
     """sharded.blockmap_ranges: the word ranges of the ranks' k-mer ranges tile the candidate block map"""
     from smudgeplot_amd import sharded
