@@ -30,6 +30,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <new>
+#include <vector>
 #include <rocprim/rocprim.hpp>
 
 #include "smg_hetmers.h"
@@ -583,6 +584,8 @@ struct smg_engine
   uint32_t    *dbits;  int64_t dbits_cap;      // deferred entries of kf_pass1_d: one bit per table entry (bytes); all zero between runs
   bool         dbits_dirty;                     //   ... unless a run was abandoned between pass 1 and kf_bigfix
   uint32_t    *biglist; int64_t biglist_cap;    // the marked entries, compacted (kf_collect), bytes
+  u64         *p1times; int64_t p1times_cap;    // SMG_P1_TIMES
+  unsigned    *p1tick;  int64_t p1tick_cap;     // tile tickets of kf_pass1_d
   uint32_t    *farp;    int64_t farp_cap;       // beside it: the partner of a listed entry whose code is CODE_FAR (kf_bigfix -> kf_pass2_far)
   int          rw;                           // 64-bit words per request record
   uint32_t    *chunk_fill; int64_t chunk_cap; // bytes
@@ -689,7 +692,7 @@ extern "C" void smg_engine_destroy(smg_engine *e)
   hipSetDevice(e->device);
   hipStreamSynchronize(e->stream);
   hipFree(e->own_keys); hipFree(e->own_cnt); hipFree(e->deg); hipFree(e->sig); hipFree(e->bstart);
-  hipFree(e->req); hipFree(e->req2); hipFree(e->sort_tmp); hipFree(e->dense); hipFree(e->chunk_off); hipFree(e->skey[0]); hipFree(e->skey[1]); hipFree(e->sidx[0]); hipFree(e->sidx[1]); hipFree(e->dbits); hipFree(e->biglist); hipFree(e->farp); hipFree(e->chunk_fill); hipFree(e->bmap); hipFree(e->reqf); hipFree(e->chunk_fillf); hipFree(e->route_cnt); hipFree(e->route_off);
+  hipFree(e->req); hipFree(e->req2); hipFree(e->sort_tmp); hipFree(e->dense); hipFree(e->chunk_off); hipFree(e->skey[0]); hipFree(e->skey[1]); hipFree(e->sidx[0]); hipFree(e->sidx[1]); hipFree(e->dbits); hipFree(e->biglist); hipFree(e->farp); hipFree(e->p1times); hipFree(e->p1tick); hipFree(e->chunk_fill); hipFree(e->bmap); hipFree(e->reqf); hipFree(e->chunk_fillf); hipFree(e->route_cnt); hipFree(e->route_off);
   hipFree(e->partials); hipFree(e->ctrl); hipFree(e->d_split); hipFree(e->p1cold); hipFree(e->ghist); hipFree(e->boff);
   hipFree(e->whist);
   hipHostFree(e->h_ctrl); hipHostFree(e->h_partials); hipHostFree(e->h_p1cold);
@@ -1184,6 +1187,15 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
           e->dbits_dirty = true;                                               // until kf_bigfix has cleared the bits again
           e->h_p1cold->partials = e->partials; e->h_p1cold->ctl = &e->ctrl->fast; e->h_p1cold->max_chunks = maxc;
           e->h_p1cold->whist = e->whist; e->h_p1cold->owners = grid + BF_MAXGRID;
+          e->h_p1cold->times = NULL;
+          if ((rc = grow(&e->p1tick, &e->p1tick_cap, (int64_t) D_NCLS * D_TICKW * 4, errbuf, errlen))) return rc;
+          HIPCHK(hipMemsetAsync(e->p1tick, 0, (size_t) D_NCLS * D_TICKW * 4, e->stream));
+          e->h_p1cold->tick = e->p1tick;
+          if (getenv("SMG_P1_TIMES"))                                          // tuning: when did every workgroup start and end?
+            { if ((rc = grow(&e->p1times, &e->p1times_cap, (int64_t) grid * 24, errbuf, errlen))) return rc;
+              HIPCHK(hipMemsetAsync(e->p1times, 0, (size_t) grid * 24, e->stream));
+              e->h_p1cold->times = e->p1times;
+            }
           HIPCHK(hipMemcpyAsync(e->p1cold, e->h_p1cold, sizeof(P1Cold), hipMemcpyHostToDevice, e->stream));
 #define LAUNCH_R(W_, RW_, ODD_, KF_) hipLaunchKernelGGL((kf_pass1_d<W_, RW_, ODD_, KF_>), dim3(grid), dim3(D_TPB), 0, e->stream, hot, \
                               (const P1Cold *) e->p1cold)
@@ -1231,6 +1243,25 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
           HIPCHK(hipGetLastError());
         }
       if ((rc = read_ctrl(e, errbuf, errlen))) return rc;
+      if (narrow && e->h_p1cold->times)
+        { std::vector<u64> tm((size_t) grid * 3);
+          HIPCHK(hipMemcpy(tm.data(), e->p1times, (size_t) grid * 24, hipMemcpyDeviceToHost));
+          u64 t0 = ~0ull, t1 = 0;
+          for (unsigned b = 0; b < grid; b++) { if (tm[3 * b] < t0) t0 = tm[3 * b]; if (tm[3 * b + 1] > t1) t1 = tm[3 * b + 1]; }
+          // per XCD (bits of HW_ID differ between generations: printed raw as well): latest start, earliest / mean / latest end
+          double sum = 0; u64 smax = 0, emin = ~0ull;
+          for (unsigned b = 0; b < grid; b++)
+            { sum += (double) (tm[3 * b + 1] - t0); if (tm[3 * b] - t0 > smax) smax = tm[3 * b] - t0; if (tm[3 * b + 1] - t0 < emin) emin = tm[3 * b + 1] - t0; }
+          fprintf(stderr, "  [smg] pass-1 workgroups (100 MHz ticks = 10 ns): span %llu, latest start %llu, earliest end %llu, mean end %.0f\n",
+                  (unsigned long long) (t1 - t0), (unsigned long long) smax, (unsigned long long) emin, sum / grid);
+          unsigned hist[20]; memset(hist, 0, sizeof(hist));
+          for (unsigned b = 0; b < grid; b++) { unsigned q = (unsigned) ((tm[3 * b + 1] - t0) * 20 / (t1 - t0 + 1)); hist[q < 20 ? q : 19]++; }
+          fprintf(stderr, "  [smg] ends per 5 %% of the span:");
+          for (int q = 0; q < 20; q++) fprintf(stderr, " %u", hist[q]);
+          fprintf(stderr, "\n  [smg] first 16 workgroups: start end hw_id:");
+          for (unsigned b = 0; b < 16 && b < grid; b++) fprintf(stderr, " (%llu %llu %llx)", (unsigned long long) (tm[3 * b] - t0), (unsigned long long) (tm[3 * b + 1] - t0), (unsigned long long) tm[3 * b + 2]);
+          fprintf(stderr, "\n");
+        }
       e->dbits_dirty = false;
       if (e->h_ctrl->fast.unsorted)
         return fail(errbuf, errlen, SMG_EFORMAT, "table entries are not strictly increasing%s");

@@ -144,8 +144,10 @@ template <int W> SMG_DEV void mix_hash(const Key<W> &x, unsigned cnt, u64 &ha, u
 // the 4 entries of a thread, loaded one tile ahead
 template <int W> struct DPrefetch
 { Key<W> k[4]; ushort4 c; bool valid;
-  SMG_DEV void load(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, int64_t i0)
-  { if constexpr (W == 1)
+  uint32_t anchor;               // leading 32 bits of the tile's first owned entry (the base of the tile's block-map window)
+  SMG_DEV void load(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, int64_t i0, int64_t ianchor)
+  { anchor = (uint32_t) (keys[ianchor * W] >> 32);
+    if constexpr (W == 1)
       { const ulonglong2 v0 = *reinterpret_cast<const ulonglong2 *>(keys + i0);
         const ulonglong2 v1 = *reinterpret_cast<const ulonglong2 *>(keys + i0 + 2);
         k[0].w[0] = v0.x; k[1].w[0] = v0.y; k[2].w[0] = v1.x; k[3].w[0] = v1.y;
@@ -156,6 +158,17 @@ template <int W> struct DPrefetch
         for (int e = 0; e < 4; e++) k[e] = load_key<W>(keys, i0 + e);
       }
     c = *reinterpret_cast<const ushort4 *>(cnt + i0);
+  }
+  // "the registers are needed HERE": makes the compiler place its wait for the loads at this point
+  SMG_DEV void arrive()
+  {
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+#pragma unroll
+      for (int w = 0; w < W; w++) asm volatile("" : "+v"(k[e].w[w]));
+    unsigned c01 = (unsigned) c.x | ((unsigned) c.y << 16), c23 = (unsigned) c.z | ((unsigned) c.w << 16);
+    asm volatile("" : "+v"(c01), "+v"(c23), "+v"(anchor));
+    c.x = (unsigned short) c01; c.y = (unsigned short) (c01 >> 16); c.z = (unsigned short) c23; c.w = (unsigned short) (c23 >> 16);
   }
 };
 
@@ -190,6 +203,8 @@ struct P1Cold                             // in device memory: what only a flush
   unsigned  owners;              //   chunk slots are dealt out without a counter: owner w fills w, w + owners, w + 2 owners, ..
   unsigned  max_chunks;
   uint32_t *dbits;               // deferred entries: one bit per table entry (kf_bigfix redoes them exactly and clears the bits)
+  u64      *times;               // SMG_P1_TIMES (tuning): start / end of every workgroup on the constant 100 MHz clock, or NULL
+  unsigned *tick;                // tile tickets: D_NCLS counters, 128 bytes apart (zeroed before the launch)
 };
 
 struct DShared                            // the workgroup's LDS arrays (pointers: the tile body is a function)
@@ -288,12 +303,15 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
   // ---- loads ----------------------------------------------------------------------------------------------
   //@mark D_LOAD
   Key<W> kk[4]; unsigned cn[4];
+  uint32_t pf_anchor = 0;
   unsigned vmask = 0xF;                    // entries i0 .. i0+3 inside the table?
   if (INNER)
-    { if (!pf.valid) pf.load(A.keys, A.cnt, i0);        // (the first tile of a workgroup, or the one after an edge tile)
+    { // (the caller has loaded them if the tile before this one did not: the first tile of a workgroup, or the one after an
+      //  edge tile)
 #pragma unroll
       for (int e = 0; e < 4; e++) kk[e] = pf.k[e];
       cn[0] = pf.c.x; cn[1] = pf.c.y; cn[2] = pf.c.z; cn[3] = pf.c.w;
+      pf_anchor = (uint32_t) __builtin_amdgcn_readfirstlane((int) pf.anchor);
     }
   else
     { vmask = 0;
@@ -468,7 +486,8 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
   //@mark D_BMAP
   D_FENCE_P();
   // word 0 of the tile's LDS bit map = the map word of the tile's first owned entry (a uniform, scalar load)
-  const uint32_t bmbase = D_BM ? (((uint32_t) (A.keys[(g0 + D_LEAD) * W] >> 32) >> bmsh) & ~31u) : 0u;
+  // (inner tiles: loaded one tile ahead with the entries -- as a load of its own it was waited for on the spot)
+  const uint32_t bmbase = D_BM ? (((INNER ? pf_anchor : (uint32_t) (A.keys[(g0 + D_LEAD) * W] >> 32)) >> bmsh) & ~31u) : 0u;
   if (D_BM && A.bmap && !(D_ABL & 8))
     { // leading word of the thread's own entries, back from the staged copy (cheaper than four registers kept alive
       // across the tests)
@@ -604,7 +623,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
   // the next tile's entries: issued here, used after the flush -- the latency of the loads (a few thousand cycles on a
   // busy chip) disappears behind the flush phase and the barriers instead of stalling the head of the next tile
   pf.valid = false;
-  if (g0_next >= 0) { pf.load(A.keys, A.cnt, g0_next + slot0); pf.valid = true; }
+  if (g0_next >= 0) { pf.load(A.keys, A.cnt, g0_next + slot0, g0_next + D_LEAD); pf.valid = true; }
 
   //@mark D_STORE
   if (owned)
@@ -672,6 +691,12 @@ d_detect(const P1Hot &A, const u64 *ent, const uint16_t *lcn, int64_t g0, int sa
 #endif
 #define D_WAVES(W_, RW_) ((W_) == 2 ? ((RW_) == 2 ? D_WAVES_W2K : D_WAVES_W2) : ((RW_) == 1 ? D_WAVES_PER_EU : 5))
 
+// tile tickets: one counter per class of workgroups (blockIdx.x mod D_NCLS -- the workgroups of one XCD, as the dispatcher
+// deals them out); class c draws the tiles grid + D_NCLS r + c.  ONE counter for all was the bottleneck of the kernel:
+// 2.6e6 returning atomics on one address go through at ~11 ns each (31 ms, whatever else the kernel does).
+#define D_NCLS   8
+#define D_TICKW  32                       // words between two counters
+
 template <int W, int RW, bool ODD, bool KF> __global__ void __launch_bounds__(D_TPB)
 __attribute__((amdgpu_waves_per_eu(D_WAVES(W, RW), D_WAVES(W, RW))))
 kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
@@ -684,6 +709,8 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
   __shared__ __attribute__((aligned(16))) unsigned bm[D_BM ? 2 * D_BMW : 1];
   __shared__ unsigned hist[(D_BM && RW == W) ? D_HB : 1];
   __shared__ unsigned s_tn[2], s_qn, s_unsorted, s_chunk, s_used;      // (s_tn: one counter per tile parity)
+  __shared__ unsigned s_tk[2], s_tk0;      // the ticket thread 0 hands on at the head of a tile, read at its end (one word per
+                                           // tile parity: thread 0 is at the next head while other waves still read); the first one
   __shared__ u64      s_base, s_total;
 
   const int t = threadIdx.x;
@@ -697,26 +724,63 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
   S.bm = bm; S.hist = hist;
   if (D_BM) for (int w = t; w < 2 * D_BMW; w += D_TPB) bm[w] = 0;
   if (D_BM && RW == W) for (int w = t; w < D_HB; w += D_TPB) hist[w] = 0;
-  if (t == 0) { s_chunk = F_NOCHUNK; s_used = 0; s_total = 0; s_tn[0] = 0; s_tn[1] = 0; s_qn = 0; s_unsorted = 0; }
+  // Tiles are drawn from a counter, not dealt out by stride: the SIMDs favour their oldest waves, so of the five
+  // workgroups that share a CU one is served first and finishes its (equal) share at 60 % of the kernel's time, the
+  // next at 68, 78, 88 % -- and the last one runs alone, at a fraction of the CU's issue rate (profiles/
+  // r03_pass1_workgroup_ends.txt).  With tickets every workgroup works until the table is done.  A workgroup starts
+  // with tile blockIdx.x and knows its next TWO tiles (the next one is being prefetched while a tile is worked on); the
+  // ticket for the third is drawn by thread 0 at the head of a tile and picked up at the head of the next one, where the
+  // wave waits for its prefetched entries anyway -- a returning atomic and the loads behind it share one in-order counter
+  // (vmcnt), so waiting for the ticket anywhere else means waiting for the prefetch (31 ms instead of 15).
+  if (t == 0)
+    { s_chunk = F_NOCHUNK; s_used = 0; s_total = 0; s_tn[0] = 0; s_tn[1] = 0; s_qn = 0; s_unsorted = 0;
+      s_tk0 = atomicAdd(&cold->tick[(blockIdx.x % D_NCLS) * D_TICKW], 3u);
+    }
   lds_barrier();
   (void) lane; (void) slot0; (void) n;
+  if (cold->times && t == 0)
+    { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      cold->times[3 * (size_t) blockIdx.x] = wall_clock64(); cold->times[3 * (size_t) blockIdx.x + 2] = hw;
+    }
 
   DPrefetch<W> pf;
   pf.valid = false;
   int par = 0;
-  for (int64_t tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x, par ^= 1)
+  const unsigned cls = blockIdx.x % D_NCLS;
+  unsigned ticket = (unsigned) __builtin_amdgcn_readfirstlane((int) s_tk0);      // ticket r stands for tile grid + D_NCLS r + cls
+  int64_t tnext = (int64_t) gridDim.x + (int64_t) ticket * D_NCLS + cls, tnext2 = tnext + D_NCLS;
+  ticket += 2u;                                 // thread 0: the ticket on its way (the first one is known)
+  for (int64_t tile = blockIdx.x; tile < A.ntiles; par ^= 1)
     { const int64_t g0 = tile * D_OWN - D_LEAD;
       S.s_tn = &s_tn[par];
+      // (the wait for the prefetched entries belongs in front of the ticket: behind it, the compiler -- which sees one
+      //  path with the atomic and one without -- waits for everything, the atomic included)
+      const bool inner = g0 >= 0 && g0 + D_SLOTS + 32 <= n;
+      if (inner && !pf.valid) { pf.load(A.keys, A.cnt, g0 + slot0, g0 + D_LEAD); pf.valid = true; }
+      pf.arrive();
+      if (t == 0)
+        { // `ticket` was drawn one tile ago (for the tile after `tnext2`)
+          s_tk[par] = ticket;
+          // Nothing may use the result before the next head.  It has to be a GLOBAL atomic that the compiler knows: a
+          // flat one counts as an LDS operation too (the tile's first LDS wait would wait for it), one written in inline
+          // assembly makes the compiler's counted waits for its own loads unsafe, and a global atomic on a uniform
+          // address is rebuilt from a broadcast by the compiler's atomic optimiser on the spot -- which is a wait.  The
+          // address is therefore made to look divergent: a zero that only the hardware knows is added to it.
+          unsigned zero;
+          asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+          ticket = __hip_atomic_fetch_add((__attribute__((address_space(1))) unsigned *) &cold->tick[cls * D_TICKW] + zero, 1u,
+                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       // the tile after this one, if it is an inner tile too (-1: none, or an edge tile, which loads for itself)
-      int64_t g0n = g0 + (int64_t) gridDim.x * D_OWN;
-      if (tile + gridDim.x >= A.ntiles || g0n + D_SLOTS + 32 > n) g0n = -1;
-      if (g0 >= 0 && g0 + D_SLOTS + 32 <= n)
+      int64_t g0n = tnext * D_OWN - D_LEAD;
+      if (tnext >= A.ntiles || g0n + D_SLOTS + 32 > n) g0n = -1;
+      if (inner)
         d_tile<W, RW, ODD, KF, true>(A, S, g0, g0n, t, fa, fb, pf);
       else
         d_tile<W, RW, ODD, KF, false>(A, S, g0, g0n, t, fa, fb, pf);
       if (!(D_ABL & 4096)) lds_barrier();          // the staged copy and the queues of this tile are complete
       //@mark D_FLUSH
-      const bool last = tile + gridDim.x >= A.ntiles;
+      const bool last = tnext >= A.ntiles;
       const unsigned tn = s_tn[par];               // (zeroed again behind the barrier at the end of this iteration: the
       const unsigned qn = s_qn;                    //  next tile counts in the other one)
       if (D_BM && A.bmap)                           // candidate-block bits of this tile -> global map
@@ -792,8 +856,11 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
         }
       if (!(D_ABL & 8192)) lds_barrier();
       if (t == 0) s_tn[par] = 0;
+      tile = tnext; tnext = tnext2;
+      tnext2 = (int64_t) gridDim.x + (int64_t) (unsigned) __builtin_amdgcn_readfirstlane((int) s_tk[par]) * D_NCLS + cls;
     }
 
+  if (cold->times && t == 0) cold->times[3 * (size_t) blockIdx.x + 1] = wall_clock64();
   if (D_BM && RW == W && A.hbits())                   // this workgroup's row of the request histogram (kl_tot / kl_woff)
     for (int w = t; w < D_HB; w += D_TPB) cold->whist[(size_t) blockIdx.x * D_HB + w] = hist[w];
   if (t == 0)
