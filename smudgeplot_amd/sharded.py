@@ -7,14 +7,18 @@ prefix-subtree task decomposition of `small_window` (src/lib/PloidyPlot.c:1040-1
 Data path per run (see DESIGN.md "Multi-GPU"):
   1. pass 1 on every shard (window scan of the suffix-side positions: always shard local);
   2. request filter (hash proof, k <= 85): one all_gather of the candidate block maps (each rank contributes the
-     words its k-mer range covers: 128 MB / world at k = 31) -- a request whose target block holds no candidate
-     of pass 2 is dropped before it is sent (about 4 in 5 on a diploid table);
-     ONE exchange: every entry that owns a suffix-side pair sends (rc(kmer), count, S_hi) to the
-     rank that owns the reverse complement  -> all_to_all_single over xGMI;
-     the symmetry proof (fingerprints 4 x u64 + missing count) rides on the final all_reduce;
-  3. pass 2 on every shard;
-  4. ONE all_reduce(SUM, int64[1001*501 + 1 + 2*world]) of the per-GPU 2-D histograms with the proof words appended
-     (missing count + one 128-bit XOR-fingerprint slot per rank).
+     words its k-mer range covers: two-bit map of 30 id bits, 29 from 8 ranks on: 256 / 128 MB over all ranks) while
+     the map-independent half of the filter (the request partition) runs -- a request whose target block holds no
+     candidate of pass 2 is dropped before it is sent (12 in 13);
+  3. ONE exchange: every surviving request rc(kmer) goes to the rank that owns it: grouped by destination on the
+     device, the per-destination counts go from the router into an all_to_all_single without a host round trip, the
+     host reads what it sends and receives in one copy, then the records follow in a second all_to_all_single;
+  4. look-ups of the received requests and pass 2, both queued without a host wait;
+  5. ONE all_reduce(SUM, int64[1001*501 + 1 + 2*world]) of the per-GPU 2-D histograms with the symmetry proof appended
+     (missing count + one 128-bit XOR-fingerprint slot per rank, written on the device in stream order).
+  k > 85 takes the same steps with the counted kernels (no block map: step 2 falls away).
+  condition_sharded: a RAW table (canonical k-mers, untrimmed) is trimmed and closed under reverse complement across the
+  ranks first (histogram of the closed table -> balanced splitters, entries + complements exchanged, sorted per rank).
 
 torch is plumbing here: device buffers and collectives.  The compute is the C-ABI engine
 (`engine.Engine`); `engine_factory` lets the CPU test-suite substitute a numpy stand-in so the
