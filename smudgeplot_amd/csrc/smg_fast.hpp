@@ -1179,13 +1179,17 @@ kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, const unsigned *__re
   for (int b = t; b < 1024; b += BF_TPB) hist[b] = 0;
   const unsigned nbig = *pcount;
   if (nbig > cap) return;                // the list overflowed (it has holes at its end): the host grows it and redoes the run
+  // slab size: at least four slabs per workgroup (a short list -- one rank's eighth of a table -- in 8192-entry slabs kept
+  // 50 of 512 workgroups busy: 175 us instead of 35), whole waves, at most what the note list holds
+  unsigned slab = ((nbig / (gridDim.x * 4u)) + 63u) & ~63u;
+  slab = slab < 256u ? 256u : slab > (unsigned) BF_SLAB ? (unsigned) BF_SLAB : slab;
   for (;;)
     { __syncthreads();
-      if (t == 0) { s_slab = atomicAdd(&ctl->bf_next, (unsigned) BF_SLAB); s_next = 0; s_nl = 0; }
+      if (t == 0) { s_slab = atomicAdd(&ctl->bf_next, slab); s_next = 0; s_nl = 0; }
       __syncthreads();
       const unsigned slab0 = s_slab;
       if (slab0 >= nbig) break;
-      const unsigned slab_n = nbig - slab0 < BF_SLAB ? nbig - slab0 : BF_SLAB;
+      const unsigned slab_n = nbig - slab0 < slab ? nbig - slab0 : slab;
       for (;;)
         { unsigned b = 0;
           if (lane == 0) b = atomicAdd(&s_next, 64u);

@@ -1404,9 +1404,9 @@ static int filter_presort(smg_engine *e, char *errbuf, size_t errlen)
       if ((rc = grow(&e->req2, &e->req2_cap, (nreq > 0 ? nreq : 1) * (int64_t) sizeof(u64) * e->rw, errbuf, errlen))) return rc;
       const int nbk = 1 << e->lg.nb;
       // bucket sizes = column sums of the owners' histogram rows -> bucket offsets -> first slot of every owner in every bucket
-      hipLaunchKernelGGL(kl_tot, dim3(L_BK / LW_BPW), dim3(64 * LW_BPW), 0, e->stream, (const unsigned *) e->whist, e->nown, e->ghist);
+      hipLaunchKernelGGL(kl_tot, dim3(L_BK / LW_BPW), dim3(LW_SL * LW_BPW), 0, e->stream, (const unsigned *) e->whist, e->nown, e->ghist);
       hipLaunchKernelGGL(kl_scan, dim3(1), dim3(L_BK), 0, e->stream, e->ghist, nbk, e->boff, e->boff + L_BK + 2, e->ghist + L_BK);
-      hipLaunchKernelGGL(kl_woff, dim3(L_BK / LW_BPW), dim3(64 * LW_BPW), 0, e->stream, e->whist, e->nown, (const u64 *) e->boff);
+      hipLaunchKernelGGL(kl_woff, dim3(L_BK / LW_BPW), dim3(LW_SL * LW_BPW), 0, e->stream, e->whist, e->nown, (const u64 *) e->boff);
       if (e->n_chunks && e->rw == 1)
         hipLaunchKernelGGL(kl_part<1>, dim3(e->nown), dim3(PT_TPB), 0, e->stream, e->req, e->chunk_fill, e->nown,
                            (const unsigned *) e->whist, e->max_chunks, e->lg.nb, e->req2);

@@ -70,17 +70,19 @@ kl_scan(const unsigned *__restrict__ ghist, int nbk, u64 *__restrict__ boff /* [
 // ---- per-owner offsets ---------------------------------------------------------------------------------------------
 // Every workgroup of pass 1 (and of kf_bigfix) is the OWNER of the chunks it filled and has counted its requests per
 // bucket (row w of whist).  kl_tot sums the rows (-> the bucket sizes kl_scan turns into bucket offsets), kl_woff turns
-// row w into the first output slot of owner w in every bucket.  One wave per bucket, a lane per slice of the owners.
+// row w into the first output slot of owner w in every bucket.  A workgroup takes LW_BPW buckets (one 64-byte segment
+// of every row); thread t = (slice of the owners t >> 4, bucket t & 15): the 16 lanes of a slice read one whole segment,
+// a load instruction of a wave touches 4 lines instead of 64 (a wave per bucket with a lane per slice: 71 us for
+// kl_woff, whatever the size of the table).
 #define LW_BPW 16                          // buckets per workgroup (one 64-byte segment of a row)
+#define LW_SL  64                          // slices of the owners per workgroup
+#define LW_UNR 8                           // rows of a thread loaded together (independent loads in flight)
 
-// (the rows of a lane are loaded eight at a time, independent loads in flight together: a lane that walked its ~24 rows
-//  one dependent L2 round trip after the other made kl_woff take 55 us)
-#define LW_UNR 8
-
-__global__ void __launch_bounds__(64 * LW_BPW)
+__global__ void __launch_bounds__(LW_SL * LW_BPW)
 kl_tot(const unsigned *__restrict__ whist, unsigned nown, unsigned *__restrict__ tot /* [L_BK] */)
-{ const int lane = threadIdx.x & 63, b = blockIdx.x * LW_BPW + (threadIdx.x >> 6);
-  const unsigned per = (nown + 63) / 64, w0 = lane * per, w1 = w0 + per < nown ? w0 + per : nown;
+{ __shared__ unsigned red[LW_SL][LW_BPW];
+  const int bb = threadIdx.x & (LW_BPW - 1), g = threadIdx.x / LW_BPW, b = blockIdx.x * LW_BPW + bb;
+  const unsigned per = (nown + LW_SL - 1) / LW_SL, w0 = g * per, w1 = w0 + per < nown ? w0 + per : nown;
   unsigned s = 0;
   for (unsigned w = w0; w < w1; w += LW_UNR)
     { unsigned v[LW_UNR];
@@ -89,15 +91,20 @@ kl_tot(const unsigned *__restrict__ whist, unsigned nown, unsigned *__restrict__
 #pragma unroll
       for (int j = 0; j < LW_UNR; j++) s += v[j];
     }
-#pragma unroll
-  for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o, 64);
-  if (lane == 0) tot[b] = s;
+  red[g][bb] = s;
+  __syncthreads();
+  if (g == 0)
+    { unsigned a = 0;
+      for (int q = 0; q < LW_SL; q++) a += red[q][bb];
+      tot[b] = a;
+    }
 }
 
-__global__ void __launch_bounds__(64 * LW_BPW)
+__global__ void __launch_bounds__(LW_SL * LW_BPW)
 kl_woff(unsigned *__restrict__ whist /* in: counts, out: first slots */, unsigned nown, const u64 *__restrict__ boff)
-{ const int lane = threadIdx.x & 63, b = blockIdx.x * LW_BPW + (threadIdx.x >> 6);
-  const unsigned per = (nown + 63) / 64, w0 = lane * per, w1 = w0 + per < nown ? w0 + per : nown;
+{ __shared__ unsigned red[LW_SL][LW_BPW];
+  const int bb = threadIdx.x & (LW_BPW - 1), g = threadIdx.x / LW_BPW, b = blockIdx.x * LW_BPW + bb;
+  const unsigned per = (nown + LW_SL - 1) / LW_SL, w0 = g * per, w1 = w0 + per < nown ? w0 + per : nown;
   unsigned s = 0;
   for (unsigned w = w0; w < w1; w += LW_UNR)
     { unsigned v[LW_UNR];
@@ -106,13 +113,10 @@ kl_woff(unsigned *__restrict__ whist /* in: counts, out: first slots */, unsigne
 #pragma unroll
       for (int j = 0; j < LW_UNR; j++) s += v[j];
     }
-  unsigned incl = s;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1)
-    { const unsigned v = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += v;
-    }
-  unsigned run = (unsigned) boff[b] + incl - s;               // (slots are 32-bit: a shard holds < 2^32 requests)
+  red[g][bb] = s;
+  __syncthreads();
+  unsigned run = (unsigned) boff[b];                           // (slots are 32-bit: a shard holds < 2^32 requests)
+  for (int q = 0; q < g; q++) run += red[q][bb];               // the slices in front of this one
   for (unsigned w = w0; w < w1; w += LW_UNR)
     { unsigned v[LW_UNR];
 #pragma unroll
