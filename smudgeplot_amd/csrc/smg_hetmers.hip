@@ -586,6 +586,7 @@ struct smg_engine
   uint32_t    *biglist; int64_t biglist_cap;    // the marked entries, compacted (kf_collect), bytes
   u64         *p1times; int64_t p1times_cap;    // SMG_P1_TIMES
   unsigned    *p1tick;  int64_t p1tick_cap;     // tile tickets of kf_pass1_d
+  unsigned    *xtick;   int64_t xtick_cap;      // (bucket, part) tickets of kl_probe_x, one counter per XCD
   uint32_t    *farp;    int64_t farp_cap;       // beside it: the partner of a listed entry whose code is CODE_FAR (kf_bigfix -> kf_pass2_far)
   int          rw;                           // 64-bit words per request record
   uint32_t    *chunk_fill; int64_t chunk_cap; // bytes
@@ -692,7 +693,7 @@ extern "C" void smg_engine_destroy(smg_engine *e)
   hipSetDevice(e->device);
   hipStreamSynchronize(e->stream);
   hipFree(e->own_keys); hipFree(e->own_cnt); hipFree(e->deg); hipFree(e->sig); hipFree(e->bstart);
-  hipFree(e->req); hipFree(e->req2); hipFree(e->sort_tmp); hipFree(e->dense); hipFree(e->chunk_off); hipFree(e->skey[0]); hipFree(e->skey[1]); hipFree(e->sidx[0]); hipFree(e->sidx[1]); hipFree(e->dbits); hipFree(e->biglist); hipFree(e->farp); hipFree(e->p1times); hipFree(e->p1tick); hipFree(e->chunk_fill); hipFree(e->bmap); hipFree(e->reqf); hipFree(e->chunk_fillf); hipFree(e->route_cnt); hipFree(e->route_off);
+  hipFree(e->req); hipFree(e->req2); hipFree(e->sort_tmp); hipFree(e->dense); hipFree(e->chunk_off); hipFree(e->skey[0]); hipFree(e->skey[1]); hipFree(e->sidx[0]); hipFree(e->sidx[1]); hipFree(e->dbits); hipFree(e->biglist); hipFree(e->farp); hipFree(e->p1times); hipFree(e->p1tick); hipFree(e->xtick); hipFree(e->chunk_fill); hipFree(e->bmap); hipFree(e->reqf); hipFree(e->chunk_fillf); hipFree(e->route_cnt); hipFree(e->route_off);
   hipFree(e->partials); hipFree(e->ctrl); hipFree(e->d_split); hipFree(e->p1cold); hipFree(e->ghist); hipFree(e->boff);
   hipFree(e->whist);
   hipHostFree(e->h_ctrl); hipHostFree(e->h_partials); hipHostFree(e->h_p1cold);
@@ -1440,8 +1441,35 @@ static int lookup_probe(smg_engine *e, const uint32_t *map, bool list, unsigned 
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) == hipSuccess && cus > 0) grid = (unsigned) cus;
   }
   const unsigned nbk = 1u << e->lg.nb;
-  if (grid > nbk) grid = nbk;
   FastArgs a = make_fast(e);
+  // The fused probe + look-up of a single shard has two forms.  kl_probe (a bucket per workgroup, the bucket's map folded
+  // into LDS) is the faster one on a table without long window blocks: 2.5 against 2.7 ms at 2.5e9 entries.  kl_probe_x
+  // (XCD by XCD straight from the full-resolution map, small independent workgroups) does not care how long a look-up
+  // takes: with 5 % repeats in the genome the survivors' look-ups bisect directory buckets of thousands of k-mers, the
+  // sixteen waves of a kl_probe workgroup wait for each other at every bucket, and it takes 4.5 ms against 2.9.  The
+  // share of deferred entries that pass 1 reported tells the two kinds of table apart (0.13 % / 0.39 % in the two
+  // bench workloads); SMG_PROBE_X=0/1 overrides.
+  { const char *px = getenv("SMG_PROBE_X");
+    const bool auto_x = e->st.nbig > 0 && e->st.nbig * 400 > e->n;
+    if (!list && e->lg.nb >= 3 && (px ? atoi(px) != 0 : auto_x))
+      { int rc2;
+        if ((rc2 = grow(&e->xtick, &e->xtick_cap, (int64_t) PX_NXCD * PX_TICKW * 4, errbuf, errlen))) return rc2;
+        HIPCHK(hipMemsetAsync(e->xtick, 0, (size_t) PX_NXCD * PX_TICKW * 4, e->stream));
+        unsigned xw = PX_WGS, part = PX_PART;               // (tuning: SMG_PX_WGS workgroups per CU, SMG_PX_PART requests per ticket)
+        { const char *v = getenv("SMG_PX_WGS"); if (v && atoi(v) > 0 && atoi(v) <= 8) xw = (unsigned) atoi(v);
+          v = getenv("SMG_PX_PART"); if (v && atoi(v) >= 512) part = (unsigned) atoi(v) & ~511u;
+        }
+        const unsigned xg = grid * xw;
+#define PROBEX(TWO_, RW_) hipLaunchKernelGGL((kl_probe_x<TWO_, RW_>), dim3(xg), dim3(PX_TPB), 0, e->stream, a, (const u64 *) e->req2, \
+                            (const u64 *) e->boff, map, e->lg, e->xtick, &e->ctrl->fast, part)
+        if (two) { if (e->rw == 1) PROBEX(true, 1); else PROBEX(true, 2); }
+        else     { if (e->rw == 1) PROBEX(false, 1); else PROBEX(false, 2); }
+#undef PROBEX
+        HIPCHK(hipGetLastError());
+        return SMG_OK;
+      }
+  }
+  if (grid > nbk) grid = nbk;
 #define PROBE(LIST_, TWO_, RW_, OUT_, FILL_, MAX_) hipLaunchKernelGGL((kl_probe<LIST_, TWO_, RW_>), dim3(grid), dim3(PB_TPB), 0, e->stream, a, \
                        (const u64 *) e->req2, (const u64 *) e->boff, map, e->lg, e->ghist + L_BK, OUT_, FILL_, MAX_, &e->ctrl->fast)
 #define PROBE_RW(LIST_, TWO_, OUT_, FILL_, MAX_) { if (e->rw == 1) PROBE(LIST_, TWO_, 1, OUT_, FILL_, MAX_); else PROBE(LIST_, TWO_, 2, OUT_, FILL_, MAX_); }

@@ -390,3 +390,118 @@ kl_probe(FastArgs A, const u64 *__restrict__ recs, const u64 *__restrict__ boff,
   if (LIST && chunk != F_NOCHUNK && chunk < max_out && lane == 0) out_fill[chunk] = used;
   if (kept && lane == 0) atomicAdd(&ctl->nf_req, kept);
 }
+
+// ---- kl_probe_x: the same test without the LDS map, XCD by XCD -------------------------------------------------------
+// kl_probe folds a bucket's slice of the map 4:1 into LDS because a bucket's requests hit its 1 MB of map at random:
+// from 256 buckets in flight that is 256 MB of working set, every probe that passes the coarse test costs a 128-byte
+// line of HBM for 8 bytes (12 of the kernel's 17 GB).  Here the workgroups of ONE XCD take the SAME bucket at the same
+// time -- buckets b = xcd (mod 8) belong to XCD xcd, its workgroups draw (bucket, part) tickets from the XCD's own
+// counter, PX_PART requests per ticket -- so the slice in use is 1-2 MB per XCD and stays in that XCD's 4 MB L2: every
+// request probes the full-resolution map word directly, the map crosses HBM once.  The request stream is read with
+// non-temporal loads (it is touched once and must not push the map out).  Survivors are looked up on the spot as in
+// kl_probe.  Needs >= 8 buckets (nb >= 3) and the hardware's XCC id (HW_REG_XCC_ID: the dispatcher's round-robin is
+// not taken for granted).
+#define PX_TPB   256
+#define PX_PART  4096                     // requests per ticket (with PX_WGS workgroups per CU: ~1.2 buckets in flight per XCD)
+#define PX_WGS   4
+#define PX_PER   8                        // requests per lane and step
+#define PX_NXCD  8
+#define PX_TICKW 32                       // words between two XCD counters
+
+template <bool TWO, int RW> __global__ void __launch_bounds__(PX_TPB)
+kl_probe_x(FastArgs A, const u64 *__restrict__ recs, const u64 *__restrict__ boff, const uint32_t *__restrict__ fmap,
+           LookupGeo g, unsigned *__restrict__ xtick, FastCtl *__restrict__ ctl, unsigned part /* requests per ticket */)
+{ __shared__ unsigned pstart[L_BK / PX_NXCD + 1];        // first ticket of the XCD's j-th bucket
+  __shared__ u64      wq[PX_TPB / 64][PB_WQ];
+  __shared__ unsigned s_item;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  xcc &= PX_NXCD - 1;
+  const int nbk = 1 << g.nb, mine = nbk / PX_NXCD;        // (nb >= 3)
+  // tickets per bucket of this XCD: an exclusive scan over <= 128 buckets, by one wave
+  if (t < 64)
+    { unsigned run = 0;
+      for (int j0 = 0; j0 < mine; j0 += 64)
+        { const int j = j0 + lane;
+          unsigned np = 0;
+          if (j < mine) { const int b = j * PX_NXCD + (int) xcc; np = (unsigned) ((boff[b + 1] - boff[b] + part - 1) / part); }
+          unsigned incl = np;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+          if (j < mine) pstart[j] = run + incl - np;
+          run += __shfl(incl, 63, 64);
+        }
+      if (lane == 0) pstart[mine] = run;
+    }
+  __syncthreads();
+  const unsigned nitem = pstart[mine];
+  u64 *q = wq[wv];
+  unsigned qn = 0;
+  u64 kept = 0;
+  auto drain = [&](unsigned take)
+  { const u64 yv = q[qn - take + ((unsigned) lane < take ? lane : 0)];
+    Key<RW> y;
+    if constexpr (RW == 1) y.w[0] = yv;
+    else
+      { const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(recs + (size_t) yv * 2);
+        y.w[0] = v.x; y.w[1] = v.y;
+      }
+    if ((unsigned) lane < take)
+      { const int64_t j = sig_find<RW>(A, y, false);
+        if (j < 0) { if (ctl->missing == 0) ctl->missing = 1; }
+        else SET_P(A, j);
+      }
+    qn -= take; kept += take;
+  };
+  for (;;)
+    { __syncthreads();
+      if (t == 0) s_item = atomicAdd(&xtick[xcc * PX_TICKW], 1u);
+      __syncthreads();
+      const unsigned item = s_item;
+      if (item >= nitem) break;
+      int lo = 0, hi = mine;                               // the bucket of this ticket: last j with pstart[j] <= item
+      while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (pstart[m] <= item) lo = m; else hi = m; }
+      const int b = lo * PX_NXCD + (int) xcc;
+      const u64 r0 = boff[b] + (u64) (item - pstart[lo]) * part;
+      const u64 r1 = r0 + part < boff[b + 1] ? r0 + part : boff[b + 1];
+      for (u64 i0 = r0 + (u64) wv * (64 * PX_PER); i0 < r1; i0 += (u64) (PX_TPB / 64) * 64 * PX_PER)
+        { u64 y[PX_PER]; bool keep[PX_PER]; unsigned fwd[PX_PER], fw2[PX_PER];
+#pragma unroll
+          for (int j = 0; j < PX_PER; j++)
+            { const u64 i = i0 + (u64) j * 64 + lane;
+              keep[j] = i < r1;
+              y[j] = keep[j] ? __builtin_nontemporal_load(recs + i * RW) : 0ull;
+            }
+#pragma unroll
+          for (int j = 0; j < PX_PER; j++)
+            { const unsigned fid = (unsigned) (y[j] >> (64 - g.fb));
+              if (TWO)
+                { const uint2 f = keep[j] ? reinterpret_cast<const uint2 *>(fmap)[fid >> 5] : make_uint2(0u, 0u);
+                  fwd[j] = f.x; fw2[j] = f.y;
+                }
+              else { fwd[j] = keep[j] ? fmap[fid >> 5] : 0u; fw2[j] = 0u; }
+            }
+#pragma unroll
+          for (int j = 0; j < PX_PER; j++)
+            { const unsigned fid = (unsigned) (y[j] >> (64 - g.fb));
+              keep[j] = keep[j] && ((fwd[j] >> (fid & 31)) & 1u);
+              if (TWO) keep[j] = keep[j] && ((fw2[j] >> bm2_pos((uint32_t) y[j])) & 1u);
+            }
+#pragma unroll
+          for (int j = 0; j < PX_PER; j += 2)
+            { const u64 m0 = __ballot(keep[j]), m1 = __ballot(keep[j + 1]);
+              const unsigned n0 = (unsigned) __popcll(m0), n1 = (unsigned) __popcll(m1);
+              const u64 v0 = RW == 1 ? y[j] : i0 + (u64) j * 64 + lane, v1 = RW == 1 ? y[j + 1] : i0 + (u64) (j + 1) * 64 + lane;
+              if (keep[j]) q[qn + __builtin_amdgcn_mbcnt_hi((unsigned) (m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m0, 0u))] = v0;
+              if (keep[j + 1]) q[qn + n0 + __builtin_amdgcn_mbcnt_hi((unsigned) (m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m1, 0u))] = v1;
+              qn += n0 + n1;
+              while (qn >= 64) drain(64);
+            }
+        }
+      if (qn) drain(qn);
+    }
+  if (kept && lane == 0) atomicAdd(&ctl->nf_req, kept);
+}
+
