@@ -1458,6 +1458,7 @@ static int lookup_probe(smg_engine *e, const uint32_t *map, bool list, unsigned 
         unsigned xw = PX_WGS, part = PX_PART;               // (tuning: SMG_PX_WGS workgroups per CU, SMG_PX_PART requests per ticket)
         { const char *v = getenv("SMG_PX_WGS"); if (v && atoi(v) > 0 && atoi(v) <= 8) xw = (unsigned) atoi(v);
           v = getenv("SMG_PX_PART"); if (v && atoi(v) >= 512) part = (unsigned) atoi(v) & ~511u;
+          if (getenv("SMG_PX_ONE_XCC")) part |= 0x80000000u;                    // (tests: every workgroup claims XCD 0)
         }
         const unsigned xg = grid * xw;
 #define PROBEX(TWO_, RW_) hipLaunchKernelGGL((kl_probe_x<TWO_, RW_>), dim3(xg), dim3(PX_TPB), 0, e->stream, a, (const u64 *) e->req2, \

@@ -399,8 +399,8 @@ kl_probe(FastArgs A, const u64 *__restrict__ recs, const u64 *__restrict__ boff,
 // counter, PX_PART requests per ticket -- so the slice in use is 1-2 MB per XCD and stays in that XCD's 4 MB L2: every
 // request probes the full-resolution map word directly, the map crosses HBM once.  The request stream is read with
 // non-temporal loads (it is touched once and must not push the map out).  Survivors are looked up on the spot as in
-// kl_probe.  Needs >= 8 buckets (nb >= 3) and the hardware's XCC id (HW_REG_XCC_ID: the dispatcher's round-robin is
-// not taken for granted).
+// kl_probe.  Needs >= 8 buckets (nb >= 3); the XCD is the hardware's XCC id (HW_REG_XCC_ID: the dispatcher's round-robin is
+// not taken for granted, nor is the number of XCDs -- see the stealing loop).
 #define PX_TPB   256
 #define PX_PART  4096                     // requests per ticket (with PX_WGS workgroups per CU: ~1.2 buckets in flight per XCD)
 #define PX_WGS   4
@@ -419,24 +419,8 @@ kl_probe_x(FastArgs A, const u64 *__restrict__ recs, const u64 *__restrict__ bof
   unsigned xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   xcc &= PX_NXCD - 1;
+  if (part >> 31) { xcc = 0; part &= 0x7FFFFFFFu; }        // test hook (SMG_PX_ONE_XCC): a device that shows ONE XCC id
   const int nbk = 1 << g.nb, mine = nbk / PX_NXCD;        // (nb >= 3)
-  // tickets per bucket of this XCD: an exclusive scan over <= 128 buckets, by one wave
-  if (t < 64)
-    { unsigned run = 0;
-      for (int j0 = 0; j0 < mine; j0 += 64)
-        { const int j = j0 + lane;
-          unsigned np = 0;
-          if (j < mine) { const int b = j * PX_NXCD + (int) xcc; np = (unsigned) ((boff[b + 1] - boff[b] + part - 1) / part); }
-          unsigned incl = np;
-#pragma unroll
-          for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
-          if (j < mine) pstart[j] = run + incl - np;
-          run += __shfl(incl, 63, 64);
-        }
-      if (lane == 0) pstart[mine] = run;
-    }
-  __syncthreads();
-  const unsigned nitem = pstart[mine];
   u64 *q = wq[wv];
   unsigned qn = 0;
   u64 kept = 0;
@@ -455,15 +439,36 @@ kl_probe_x(FastArgs A, const u64 *__restrict__ recs, const u64 *__restrict__ bof
       }
     qn -= take; kept += take;
   };
+  // The buckets of this workgroup's own XCD first, then -- once those are handed out -- the other classes' in turn: the
+  // tail is shared, and a device that shows fewer XCC ids than eight (another partition mode) still does every bucket.
+  for (int st = 0; st < PX_NXCD; st++)
+  { const unsigned cls = (xcc + (unsigned) st) & (PX_NXCD - 1);
+    __syncthreads();
+    if (t < 64)                                            // tickets per bucket of this class: an exclusive scan, by one wave
+      { unsigned run = 0;
+        for (int j0 = 0; j0 < mine; j0 += 64)
+          { const int j = j0 + lane;
+            unsigned np = 0;
+            if (j < mine) { const int b = j * PX_NXCD + (int) cls; np = (unsigned) ((boff[b + 1] - boff[b] + part - 1) / part); }
+            unsigned incl = np;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+            if (j < mine) pstart[j] = run + incl - np;
+            run += __shfl(incl, 63, 64);
+          }
+        if (lane == 0) pstart[mine] = run;
+      }
+    __syncthreads();
+    const unsigned nitem = pstart[mine];
   for (;;)
     { __syncthreads();
-      if (t == 0) s_item = atomicAdd(&xtick[xcc * PX_TICKW], 1u);
+      if (t == 0) s_item = atomicAdd(&xtick[cls * PX_TICKW], 1u);
       __syncthreads();
       const unsigned item = s_item;
       if (item >= nitem) break;
       int lo = 0, hi = mine;                               // the bucket of this ticket: last j with pstart[j] <= item
       while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (pstart[m] <= item) lo = m; else hi = m; }
-      const int b = lo * PX_NXCD + (int) xcc;
+      const int b = lo * PX_NXCD + (int) cls;
       const u64 r0 = boff[b] + (u64) (item - pstart[lo]) * part;
       const u64 r1 = r0 + part < boff[b + 1] ? r0 + part : boff[b + 1];
       for (u64 i0 = r0 + (u64) wv * (64 * PX_PER); i0 < r1; i0 += (u64) (PX_TPB / 64) * 64 * PX_PER)
@@ -502,6 +507,7 @@ kl_probe_x(FastArgs A, const u64 *__restrict__ recs, const u64 *__restrict__ bof
         }
       if (qn) drain(qn);
     }
+  }
   if (kept && lane == 0) atomicAdd(&ctl->nf_req, kept);
 }
 

@@ -211,14 +211,17 @@ def test_repeat_rich_table_vs_reference_binary(tmp_path, monkeypatch):
     plot = torch.zeros(engine.PLOT_CELLS, dtype=torch.int64, device=dev)
     e = engine.Engine(0)
     e.bind(k, len(cnt), tk.data_ptr(), tc.data_ptr())
-    for mode, px in (("hash", None), ("exact", None), ("hash", "0"), ("hash", "1")):
-        if px is not None:
+    for mode, px in (("hash", None), ("exact", None), ("hash", "0"), ("hash", "1"), ("hash", "one-xcc")):
+        if px == "one-xcc":                              # ... and a device that shows one XCC id: the other classes are stolen
+            monkeypatch.setenv("SMG_PX_ONE_XCC", "1")
+        elif px is not None:
             monkeypatch.setenv("SMG_PROBE_X", px)        # both forms of the fused probe (the default picks by the deferred share)
         st = e.run(plot.data_ptr(), mode)
         torch.cuda.synchronize()
         assert st["path"] == 1 and st["nbig"] > 10000, st
         assert engine.smu_text(plot.cpu().numpy().reshape(1001, 501)) == want, (mode, px)
     monkeypatch.delenv("SMG_PROBE_X")
+    monkeypatch.delenv("SMG_PX_ONE_XCC")
     for env in ({"SMG_VIRTUAL_SHARDS": "3"}, {}):
         r = subprocess.run([HETMERS_BIN, "-e10", "-T4", "-ogpu", "t.ktab"], cwd=tmp_path, capture_output=True, text=True,
                            env=dict(os.environ, **env))
@@ -1067,7 +1070,8 @@ def _brute_cached(k, m, seed, packed, cnt):
                                  {"SMG_SIG": "1"}, {"SMG_SIG": "0", "SMG_BM_BITS": "30"},
                                  {"SMG_BM_BITS": "24", "SMG_ONE_BIT_MAP": "1"}, {"SMG_DIR_PER": "8"}, {"SMG_DIR_PER": "200"},
                                  {"SMG_NO_FILTER": "1"}, {"SMG_PROBE_X": "1"}, {"SMG_PROBE_X": "1", "SMG_ONE_BIT_MAP": "1"},
-                                 {"SMG_PROBE_X": "1", "SMG_PX_PART": "512", "SMG_PX_WGS": "8"}, {"SMG_PROBE_X": "0"}])
+                                 {"SMG_PROBE_X": "1", "SMG_PX_PART": "512", "SMG_PX_WGS": "8"}, {"SMG_PROBE_X": "0"},
+                                 {"SMG_PROBE_X": "1", "SMG_PX_ONE_XCC": "1"}])
 @pytest.mark.parametrize("k,m,seed", [(31, 60000, 21), (27, 40000, 22), (24, 30000, 23)])
 def test_every_variant_of_the_lookup_chain_gives_the_same_plot(k, m, seed, env, monkeypatch):
     """the A/B switches of the look-up chain: two-bit / one-bit map, round-1 chain, survivor list
