@@ -32,6 +32,7 @@ struct Ingest
   uint8_t     *d_ring[ING_MAXT + 2];
   IngestHook   hook; void *hook_ctx;
   hipStream_t  stream, kstream;      // copies; the hook's kernels
+  hipStream_t  cstream[4]; int ncs;  // the copy streams (piece c goes to cstream[c % ncs]; stream == cstream[0])
   hipEvent_t   kev[ING_MAXT + 2];    // the hook's kernel on device slot s has finished
   IngPiece    *piece; long npiece, next;
   char        *sent;                 // piece c has been handed to the copy stream
@@ -61,10 +62,11 @@ static void *ingest_worker(void *arg)
       const IngPiece &p = g->piece[c];
       if (!bad && g->src->read(g->src->ctx, p.part, p.first, p.nent, g->ring[slot]) != 0) bad = 1;
       uint8_t *dst = g->d_rec ? g->d_rec + p.dst : g->d_ring[slot];
+      hipStream_t cs = g->cstream[c % g->ncs];
       // (a device slot is written again nslots pieces on: that copy waits for the kernel that read the slot last)
-      if (!bad && g->hook && !g->d_rec && c >= g->nslots && hipStreamWaitEvent(g->stream, g->kev[slot], 0) != hipSuccess) bad = 2;
-      if (!bad && (hipMemcpyAsync(dst, g->ring[slot], (size_t) p.nent * g->pbyte, hipMemcpyHostToDevice, g->stream) != hipSuccess
-                   || hipEventRecord(g->ev[slot], g->stream) != hipSuccess))
+      if (!bad && g->hook && !g->d_rec && c >= g->nslots && hipStreamWaitEvent(cs, g->kev[slot], 0) != hipSuccess) bad = 2;
+      if (!bad && (hipMemcpyAsync(dst, g->ring[slot], (size_t) p.nent * g->pbyte, hipMemcpyHostToDevice, cs) != hipSuccess
+                   || hipEventRecord(g->ev[slot], cs) != hipSuccess))
         bad = 2;
       if (!bad && g->hook
           && (hipStreamWaitEvent(g->kstream, g->ev[slot], 0) != hipSuccess
@@ -122,8 +124,13 @@ static int ingest_records(const smg_table_source *src, int pbyte, int64_t lo, in
   g.nslots = nthreads + 2;
   int rc = SMG_OK, made = 0, evs = 0;
   hipEvent_t t0 = NULL, t1 = NULL;
-  if (hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking) != hipSuccess
-      || (hook && hipStreamCreateWithFlags(&g.kstream, hipStreamNonBlocking) != hipSuccess))
+  g.ncs = 1;
+  { const char *v = getenv("SMG_COPY_STREAMS"); if (v && atoi(v) >= 1 && atoi(v) <= 4) g.ncs = atoi(v); }      // (tuning)
+  for (int i = 0; i < g.ncs && rc == SMG_OK; i++)
+    if (hipStreamCreateWithFlags(&g.cstream[i], hipStreamNonBlocking) != hipSuccess)
+      rc = fail(errbuf, errlen, SMG_ENODEV, "cannot create the copy stream%s");
+  g.stream = g.cstream[0];
+  if (rc == SMG_OK && hook && hipStreamCreateWithFlags(&g.kstream, hipStreamNonBlocking) != hipSuccess)
     rc = fail(errbuf, errlen, SMG_ENODEV, "cannot create the copy stream%s");
   for (; rc == SMG_OK && made < g.nslots; made++)
     if (hipHostMalloc((void **) &g.ring[made], ING_CHUNK) != hipSuccess)
@@ -141,8 +148,10 @@ static int ingest_records(const smg_table_source *src, int pbyte, int64_t lo, in
       { rc = fail(errbuf, errlen, SMG_ENODEV, "cannot create an event%s"); break; }
   if (rc == SMG_OK && (hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess))
     rc = fail(errbuf, errlen, SMG_ENODEV, "cannot create an event%s");
-  if (rc == SMG_OK && after && hipStreamWaitEvent(hook ? g.kstream : g.stream, after, 0) != hipSuccess)
+  if (rc == SMG_OK && after && hook && hipStreamWaitEvent(g.kstream, after, 0) != hipSuccess)
     rc = fail(errbuf, errlen, SMG_ENODEV, "cannot order the copy stream%s");
+  for (int i = 0; i < g.ncs && rc == SMG_OK && after && !hook; i++)
+    if (hipStreamWaitEvent(g.cstream[i], after, 0) != hipSuccess) rc = fail(errbuf, errlen, SMG_ENODEV, "cannot order the copy stream%s");
   if (rc == SMG_OK)
     { pthread_mutex_init(&g.mu, NULL); pthread_cond_init(&g.cv, NULL);
       struct timespec a, b;
@@ -153,7 +162,8 @@ static int ingest_records(const smg_table_source *src, int pbyte, int64_t lo, in
         if (pthread_create(&th[started], NULL, ingest_worker, &g) == 0) started++;
       ingest_worker(&g);
       for (int i = 0; i < started; i++) pthread_join(th[i], NULL);
-      if (hipStreamSynchronize(g.stream) != hipSuccess && !g.failed) g.failed = 2;
+      for (int i = 0; i < g.ncs; i++)
+        if (hipStreamSynchronize(g.cstream[i]) != hipSuccess && !g.failed) g.failed = 2;
       if (g.kstream && hipStreamSynchronize(g.kstream) != hipSuccess && !g.failed) g.failed = 2;
       clock_gettime(CLOCK_MONOTONIC, &b);
       if (seconds) *seconds = (double) (b.tv_sec - a.tv_sec) + 1e-9 * (double) (b.tv_nsec - a.tv_nsec);
@@ -168,7 +178,7 @@ static int ingest_records(const smg_table_source *src, int pbyte, int64_t lo, in
   if (g.kstream) hipStreamDestroy(g.kstream);
   for (int i = 0; i < made; i++) hipHostFree(g.ring[i]);
   for (int i = 0; i < dmade; i++) hipFree(g.d_ring[i]);
-  if (g.stream) hipStreamDestroy(g.stream);
+  for (int i = 0; i < 4; i++) if (g.cstream[i]) hipStreamDestroy(g.cstream[i]);
   free(g.piece); free(g.sent);
   return rc;
 }
