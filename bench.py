@@ -38,7 +38,56 @@ def alg_bytes_per_kmer_pass(k):
     return (k + 3) // 4 + 2 + 1
 
 
-def cpu_baseline(sample_genome: int, k: int, L: int, dev, repeats: float):
+WORKLOADS = ("uniform", "repeats", "octoploid", "hexaploid")
+
+
+def default_k(workload: str) -> int:
+    return 51 if workload == "hexaploid" else 31
+
+
+def default_genome(workload: str, k: int = 31) -> int:
+    """haploid genome size: BASELINE configs[2] is 1 Gbp; configs[3] "8 haplotypes x 0.2 Gbp (scaled to fit)" (SURVEY.md
+    section 8d); configs[4] is a 10 Gbp hexaploid on 8 GPUs -- 4e8 bp of six haplotypes give one GPU 1.4e9 two-word entries,
+    about an eighth of that table"""
+    return {"uniform": 10 ** 9, "repeats": 10 ** 9, "octoploid": 2 * 10 ** 8, "hexaploid": 4 * 10 ** 8}[workload]
+
+
+def make_table(workload: str, G: int, k: int, dev, seed: int = 1):
+    """-> (keys, counts, L, description): the conditioned (trimmed, rc-closed) table of a workload, generated on `dev`"""
+    if workload in ("uniform", "repeats"):
+        L = 10
+        rep = 0.05 if workload == "repeats" else 0.0
+        if k <= 31:
+            keys, cnt = synth_device.diploid_table(G, k=k, het=0.01, cov=50.0, L=L, seed=seed, device=dev, repeats=rep)
+        elif G <= 5 * 10 ** 8:                 # two-word k-mers (BASELINE configs[4] is k=51); keys is [n, 2]
+            keys, cnt = synth_device.diploid_table_wide(G, k=k, het=0.01, cov=50.0, L=L, seed=seed, device=dev)
+        else:                                  # the same model generated chunk by chunk of the key space (1 Gbp fits)
+            keys, cnt = synth_device.polyploid_table_wide(G, ploidy=2, rates=(0.01,), cov_hap=25.0, k=k, L=L, seed=seed, device=dev)
+        desc = f"synthetic diploid {G:.3g} bp, 50x, 1% het, k={k}, L={L}" + \
+               (", 5% of the genome repeats (dispersed, tandem, homopolymer)" if rep else "")
+    elif workload == "octoploid":
+        assert k <= 31
+        L = 8
+        keys, cnt = synth_device.polyploid_table_graded(G, ploidy=8, cov_hap=14.0, k=k, L=L, seed=3 + seed, device=dev)
+        desc = (f"synthetic octoploid {G:.3g} bp x 8 haplotypes, graded divergences (variant sets carried by 1, 2, 3 and 4 of 8 "
+                f"haplotypes at 0.1 / 0.15 / 0.1 / 0.2 %), 14x per haplotype, k={k}, L={L}")
+    else:
+        assert 33 <= k <= 64
+        L = 5
+        keys, cnt = synth_device.polyploid_table_wide(G, ploidy=6, cov_hap=10.0, k=k, L=L, seed=4 + seed, device=dev)
+        desc = (f"synthetic hexaploid {G:.3g} bp x 6 haplotypes, graded divergences (variant sets carried by 1, 2 and 3 of 6 "
+                f"haplotypes at 0.1 / 0.15 / 0.2 %), 10x per haplotype, k={k}, L={L}")
+    return keys, cnt, L, desc
+
+
+def lib_hash() -> str:
+    """identity of the engine build: profiles/hbm_traffic.json carries the one its counters were read on"""
+    import hashlib
+    with open(os.path.join(ROOT, "smudgeplot_amd", "libsmg_hetmers.so"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def cpu_baseline(workload: str, sample_genome: int, k: int, dev):
     """Time the REFERENCE hetmers binary (oracle/_ref, compiled from the reference's own sources) on a bounded sample
     of the SAME workload -- the bench's own generator at 1/25 of the genome: ~1e8 table entries, ~6 s of wall time
     at -T64 -- on this box's host cores.  (Round 1 timed a 2e7-entry table, on which the reference reaches 1.1e7
@@ -47,17 +96,11 @@ def cpu_baseline(sample_genome: int, k: int, L: int, dev, repeats: float):
     if not os.path.exists(ref):
         return None
     cores = min(64, os.cpu_count() or 1)
-    if k <= 31:
-        tk, tc = synth_device.diploid_table(sample_genome, k=k, het=0.01, cov=50.0, L=L, seed=7, device=dev, repeats=repeats)
-        packed = ktab.u64_to_packed(tk.cpu().numpy().view(np.uint64), k)
-    else:
-        tk, tc = synth_device.diploid_table_wide(sample_genome, k=k, het=0.01, cov=50.0, L=L, seed=7, device=dev)
-        kw = tk.cpu().numpy().view(np.uint64).reshape(tc.numel(), -1)
-        packed = np.ascontiguousarray(np.ascontiguousarray(kw.astype(">u8")).view(np.uint8).reshape(len(kw), -1)[:, : (k + 3) // 4])
-    cnt = tc.cpu().numpy().view(np.uint16)
-    del tk, tc
+    tk, tc, L, _ = make_table(workload, sample_genome, k, dev, seed=7)
+    cnt = tc
     with tempfile.TemporaryDirectory(prefix="smg_cpu") as d:
-        ktab.write_ktab(os.path.join(d, "t"), k, packed, cnt, ibyte=3, nparts=4)
+        synth_device.write_table_from_device(os.path.join(d, "t"), tk, tc, k, nparts=4)
+        del tk
         best = None
         for _ in range(2):                       # second run = warm page cache
             out = os.path.join(d, "cpu.smu")
@@ -67,8 +110,8 @@ def cpu_baseline(sample_genome: int, k: int, L: int, dev, repeats: float):
             subprocess.run([ref, f"-e{L}", f"-T{cores}", "-ocpu", "t.ktab"], cwd=d, check=True,
                            capture_output=True)
             best = time.time() - t0
-    return {"value": len(cnt) / best, "unit": "k-mers/s", "cores": cores, "kind": "reference",
-            "sample": f"reference hetmers -T{cores} on a {len(cnt)}-entry table of the same generator "
+    return {"value": cnt.numel() / best, "unit": "k-mers/s", "cores": cores, "kind": "reference",
+            "sample": f"reference hetmers -T{cores} on a {cnt.numel()}-entry table of the same generator "
                       f"(genome {sample_genome} bp, k={k}; warm second run, {best:.1f} s wall)"}
 
 
@@ -77,16 +120,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genome", type=float, default=1e9, help="haploid genome size in bases")
-    ap.add_argument("--k", type=int, default=31)
-    ap.add_argument("--L", type=int, default=10)
+    ap.add_argument("--genome", type=float, default=0, help="haploid genome size in bases (default: the workload's, 1e9 for uniform)")
+    ap.add_argument("--k", type=int, default=0, help="default 31 (hexaploid: 51)")
     ap.add_argument("--symcheck", default="hash", choices=["exact", "hash"])
     ap.add_argument("--cpu-sample", type=float, default=0, help="genome size of the CPU baseline's sample (default: genome / 25)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--workload", default="uniform", choices=["uniform", "repeats"],
+    ap.add_argument("--workload", default="uniform", choices=list(WORKLOADS),
                     help="uniform: BASELINE configs[2] (uniform random genome); repeats: 5 %% of the genome are dispersed / "
-                         "tandem repeats and homopolymer runs (exercises kf_bigfix and the repeat tail of the plot)")
+                         "tandem repeats and homopolymer runs (exercises kf_bigfix and the repeat tail of the plot); "
+                         "octoploid: stand-in for configs[3] (8 graded haplotypes, k=31); hexaploid: for configs[4] (6, k=51)")
     args = ap.parse_args()
+    if not args.k:
+        args.k = default_k(args.workload)
+    if not args.genome:
+        args.genome = default_genome(args.workload, args.k)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -103,11 +150,7 @@ def main():
 
     # ---- workload: identical table on every rank, then keep this rank's prefix shard ----------
     G = int(args.genome)
-    repeats = 0.05 if args.workload == "repeats" else 0.0
-    if args.k <= 31:
-        keys, cnt = synth_device.diploid_table(G, k=args.k, het=0.01, cov=50.0, L=args.L, seed=1, device=dev, repeats=repeats)
-    else:                                  # two-word k-mers (BASELINE configs[4] is k=51); keys is [n, 2]
-        keys, cnt = synth_device.diploid_table_wide(G, k=args.k, het=0.01, cov=50.0, L=args.L, seed=1, device=dev)
+    keys, cnt, L, desc = make_table(args.workload, G, args.k, dev)
     n_total = cnt.numel()
     kw0 = keys if keys.dim() == 1 else keys[:, 0]          # the word that holds the window-block prefix
     if world > 1:
@@ -186,25 +229,29 @@ def main():
     if os.path.exists(tj):
         with open(tj) as f:
             t = json.load(f)
-        t = t.get("k%d%s" % (args.k, "_repeats" if repeats else ""), {})
+        t = t.get("k%d%s" % (args.k, "" if args.workload == "uniform" else "_" + args.workload), {})
         if dom in t.get("bytes_per_entry", {}):
-            traffic = t["bytes_per_entry"][dom] * n_local
-            traffic_src = t.get("source")
+            # counters are read in separate rocprofv3 passes (tools/r04_measure.sh), so the figure belongs to the build it
+            # was read on: another build of the engine gets no traffic figure instead of a stale one
+            if t.get("lib_sha256_16") == lib_hash():
+                traffic = t["bytes_per_entry"][dom] * n_local
+                traffic_src = t.get("source")
+            else:
+                traffic_src = "stale: profiles/hbm_traffic.json was measured on engine build %s, this is %s" % (
+                    t.get("lib_sha256_16"), lib_hash())
 
     if rank == 0:
         # the CPU baseline is timed on rank 0 of the single-GPU run only (it takes ~25 s of host time)
         cpu = None
         if not (args.no_cpu or world > 1):
-            cpu = cpu_baseline(int(args.cpu_sample) if args.cpu_sample else max(G // 25, 100000), args.k, args.L, dev, repeats)
+            cpu = cpu_baseline(args.workload, int(args.cpu_sample) if args.cpu_sample else max(G // 25, 100000), args.k, dev)
         value = n_total * args.steps / dt
         out = {
             "metric": "k-mers/sec through hetmers (k=%d)" % args.k,
             "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u64" if args.k <= 32 else "u64x%d" % ((args.k + 31) // 32), "data": "synthetic",
-            "config": {"workload": f"synthetic diploid {G:.3g} bp, 50x, 1% het, k={args.k}, L={args.L}"
-                                   + (", 5% of the genome repeats (dispersed, tandem, homopolymer)" if repeats else "")
-                                   + f": {n_total} table entries (conditioned, rc-closed)",
+            "config": {"workload": desc + f": {n_total} table entries (conditioned, rc-closed)",
                        "symcheck": args.symcheck, "sharding": f"prefix x{world}"},
             "roofline": {"bound": "hbm", "kernel": single[dom],
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -152,14 +152,14 @@ class Smudges:
             lo = hi = winner
             if depth and log:
                 log.write(f"Best coverage to precision of 1/{10 ** depth}: {winner:.2f}\n")
-        # the reference's last look: half of the winner competes with the finest grid, and takes over only if it is
-        # strictly better (numpy.argmin keeps the first of equal minima, the grid stands in front)
+        # the reference's last look: half of the winner is appended to the finest grid and numpy.argmin picks again
+        # (the first of equal minima wins -- the grid stands in front -- and the first NaN, if there is one: the same
+        # formulation as smudgeplot.py:136-148, so that a NaN centrality selects what it selects there)
         half = winner / 2
         cen_half = float(self._score(np.array([half]), smudge_size_cutoff)[0])
-        if cen_half < float(np.min(scores[-1])):
-            winner = half
         tried[-1] = np.append(tried[-1], half)
         scores[-1] = np.append(scores[-1], cen_half)
+        winner = tried[-1][int(np.argmin(scores[-1]))]
         if log:
             log.write(f"Best coverage to precision of 1/{10 ** (len(self.REFINEMENTS) - 1)} (just to be sure): {winner:.2f}\n")
         self.cov = winner

@@ -154,7 +154,7 @@ __attribute__((unused)) static char *smg_cli_open_table(const smg_cli *c, const 
 
   Load_Threads = c->nthreads;
   load_or_die(SRC, T);
-  switch (smg_ktab_examine_mt(T, c->ethresh, c->nthreads > 8 ? c->nthreads : 8, &trim, &symm))
+  switch (smg_ktab_examine_mt(T, c->ethresh, c->nthreads < 1 ? 1 : c->nthreads > 16 ? 16 : c->nthreads, &trim, &symm)   /* -T is honoured (1..16 probe threads) */)
   { case SMG_KTAB_OK:
       break;
     case SMG_KTAB_NOMEM:

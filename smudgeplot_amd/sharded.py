@@ -232,6 +232,8 @@ def condition_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, ethresh:
     Returns (eng, splitters): the engine OWNS this rank's shard of the conditioned table afterwards (sorted, one
     entry per k-mer, ranges given by `splitters`); hand both to hetmers_sharded(k, None, None, eng=eng,
     splitters=splitters)."""
+    if not symm:      # (checked before anything is bound, trimmed or exchanged: the caller's table and engine stay as they were)
+        raise ValueError("condition_sharded(symm=False): trim a closed table with the engine's own condition()")
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     dev = keys.device
@@ -243,8 +245,6 @@ def condition_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, ethresh:
     n = counts.numel()
     if trim:
         n = eng.trim(ethresh)
-    if not symm:
-        raise ValueError("condition_sharded(symm=False): trim a closed table with the engine's own condition()")
     bits = max(2, min(12, 2 * (k // 2)))
     hist = torch.from_numpy(eng.symm_hist(bits).astype(np.int64)).to(dev)
     if world > 1:
@@ -308,6 +308,13 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
     cached = getattr(eng, "_splitter_cache", None)
     if splitters is not None:
         splitters, sizes = np.ascontiguousarray(splitters, dtype=np.uint64).reshape(-1), None
+        if not owned and fallback and exchange:
+            # the caller's splitters come without shard sizes, and the general path on rank 0 needs them: one
+            # all_gather, as in the uncached branch (without it rank 0 raised while the others sat in dist.send)
+            mine = torch.tensor([n], dtype=torch.int64, device=dev)
+            allv = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(allv, mine, group=group)
+            sizes = [int(v) for v in torch.cat(allv).cpu().tolist()]
     elif cached is not None and cached[0] == tag:
         splitters, sizes = cached[1], cached[2]
     elif exchange:

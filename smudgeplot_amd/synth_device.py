@@ -263,3 +263,244 @@ def diploid_table_wide(G: int, k: int = 51, het: float = 0.01, cov: float = 50.0
     keys[:, 0] = u0                            # (torch.stack / 2-D boolean indexing came back scrambled
     keys[:, 1] = u1                            #  beyond ~1e8 rows with this torch/ROCm build)
     return keys, cnt
+
+
+# ---- polyploid stand-ins with GRADED divergences (BASELINE configs[3] octoploid k=31, configs[4] hexaploid k=51) ----------
+
+def graded_haplotypes(G: int, ploidy: int, rates, gen, device):
+    """`ploidy` haplotypes (uint8 [G], bases 0..3) of one uniform random genome.  rates[m-1] = SNP rate of the variant
+    sets that are carried by exactly m haplotypes: every haplotype has a private set (m = 1), every pair (2j, 2j+1) a
+    shared one (m = 2), and so on for groups of m consecutive haplotypes -- so the k-mer pairs of the table fall on the
+    smudges A..AB (1 of P), A..ABB (2 of P), ... ("graded divergences so smudges
+    AAAAAAAB ... AAAABBBB appear"), and k-mers that span two sites of different sets form the groups of 3-4 one-away
+    neighbours that polyploid tables are made of."""
+    base = torch.randint(0, 4, (G,), dtype=torch.uint8, device=device, generator=gen)
+    haps = [base.clone() for _ in range(ploidy)]
+    for m, rate in enumerate(rates, start=1):
+        if rate <= 0 or m > ploidy:
+            continue
+        step = m
+        if ploidy % m:
+            step = 1
+            while step < m:
+                step *= 2
+        for s in range(0, ploidy - m + 1, step):
+            snp = torch.rand(G, device=device, generator=gen) < rate
+            delta = torch.randint(1, 4, (G,), dtype=torch.uint8, device=device, generator=gen)
+            for h in range(s, s + m):
+                haps[h] = torch.where(snp, (haps[h] + delta) & 3, haps[h])
+            del snp, delta
+    del base
+    return haps
+
+
+def _normal_from_hash(canon: torch.Tensor) -> torch.Tensor:
+    """a standard normal deviate per canonical k-mer (Box-Muller on two hashes): x and rc(x) get the same one"""
+    u1 = (_mix(canon ^ 0x243F6A8885A308D3) >> 11).to(torch.float64) / float(1 << 53)
+    u2 = (_mix(canon ^ 0x13198A2E03707344) >> 11).to(torch.float64) / float(1 << 53)
+    u1 = u1 - torch.floor(u1); u2 = u2 - torch.floor(u2)
+    return torch.sqrt(-2.0 * torch.log(u1.clamp_min(1e-300))) * torch.cos(2 * math.pi * u2)
+
+
+def polyploid_table_graded(G: int, ploidy: int = 8, rates=(0.001, 0.0015, 0.001, 0.002), cov_hap: float = 14.0,
+                           k: int = 31, L: int = 8, seed: int = 4, device="cuda"):
+    """Octoploid-like table at any size that fits (k <= 31): the haplotypes of `graded_haplotypes`, every k-mer of both
+    strands, a k-mer carried by d haplotypes ~ Normal(d * cov_hap) (the deviate hashed from the canonical k-mer),
+    entries below L dropped.  The key space is cut by leading bits so that no torch.unique sees more than 1.2e9 elements.
+    -> (keys int64 left aligned, sorted as unsigned; counts int16): trimmed and closed under reverse complement."""
+    assert k <= 31
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    haps = graded_haplotypes(G, ploidy, rates, gen, device)
+    km = [_kmers_of(h, k) for h in haps]
+    del haps
+    total = 2 * ploidy * km[0].numel()
+    nchunk = 1
+    while total / nchunk > 1.0e9:
+        nchunk *= 2
+    cb = nchunk.bit_length() - 1
+    shift = 2 * k - cb
+    key_parts, cnt_parts = [], []
+    for c in range(nchunk):
+        sel = []
+        for a in km:
+            sel.append(a[(a >> shift) == c] if cb else a)
+            r = _revcomp_right(a, k)
+            sel.append(r[(r >> shift) == c] if cb else r)
+            del r
+        allk = torch.cat(sel)
+        del sel
+        keys, mult = torch.unique(allk, sorted=True, return_counts=True)
+        del allk
+        z = _normal_from_hash(torch.minimum(keys, _revcomp_right(keys, k)))
+        mean = float(cov_hap) * mult.clamp(max=ploidy).to(torch.float64)
+        cnt = torch.round(mean + torch.sqrt(mean) * z).clamp_(0, 32767).to(torch.int16)
+        del z, mean, mult
+        keep = cnt >= L
+        key_parts.append(keys[keep]); cnt_parts.append(cnt[keep])
+        del keys, cnt, keep
+    del km
+    keys = torch.cat(key_parts) if nchunk > 1 else key_parts[0]
+    cnt = torch.cat(cnt_parts) if nchunk > 1 else cnt_parts[0]
+    del key_parts, cnt_parts
+    keys <<= (64 - 2 * k)
+    return keys, cnt.contiguous()
+
+
+def polyploid_table_wide(G: int, ploidy: int = 6, rates=(0.001, 0.0015, 0.002), cov_hap: float = 10.0, k: int = 51,
+                         L: int = 5, seed: int = 5, device="cuda", max_chunk: float = 6.0e8):
+    """Two-word k-mers (33 <= k <= 64) of `ploidy` graded haplotypes (ploidy = 2, rates = (het,) is the diploid model of
+    diploid_table_wide; ploidy = 6 the hexaploid stand-in of BASELINE configs[4]), generated CHUNK BY CHUNK of the
+    key space (the leading bases of a k-mer pick its chunk, a chunk is at most `max_chunk` occurrences), so that the
+    peak is the finished table plus one chunk's scratch instead of four copies of everything.
+
+    Every occurrence (haplotype, strand, position) carries the normal deviate of its position (mirrored for the
+    reverse strand); an entry takes the minimum over its occurrences and Normal(d * cov_hap) with d = occurrences
+    (<= ploidy): the occurrence sets of x and rc(x) mirror each other, so both get the same count.  Entries below L are
+    dropped.  -> (keys int64 [n, 2] viewing left-aligned uint64 words, sorted as unsigned pairs; counts int16)."""
+    assert 33 <= k <= 64
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    haps = graded_haplotypes(G, ploidy, rates, gen, device)
+    m = G - k + 1
+    z = torch.randn(m, device=device, generator=gen, dtype=torch.float32)
+    SIGN = -(1 << 63)
+    total = 2 * ploidy * m
+    cbases = 0
+    while total / (4 ** cbases) > max_chunk:
+        cbases += 1
+    nchunk = 4 ** cbases
+    strands = []
+    for h in haps:
+        strands.append((h, z))
+        strands.append(((3 - h).flip(0), z.flip(0)))        # occurrence i of h mirrors occurrence m-1-i of rc(h)
+    del haps
+
+    def chunk_ids(h):
+        cid = torch.zeros(m, dtype=torch.int32, device=device)
+        for j in range(cbases):
+            cid = (cid << 2) | h[j: m + j].to(torch.int32)
+        return cid
+
+    def words_at(h, idx):
+        w0 = torch.zeros(idx.numel(), dtype=torch.int64, device=device)
+        for j in range(32):
+            w0 <<= 2
+            w0 |= h[idx + j].to(torch.int64)
+        w1 = torch.zeros(idx.numel(), dtype=torch.int64, device=device)
+        for j in range(32, k):
+            w1 <<= 2
+            w1 |= h[idx + j].to(torch.int64)
+        w1 <<= 2 * (64 - k)
+        return w0 ^ SIGN, w1 ^ SIGN            # biased: signed order == unsigned order
+
+    cids = [chunk_ids(h) for h, _ in strands] if cbases else None
+    K0, K1, CN = [], [], []
+    for c in range(nchunk):
+        W0, W1, Z = [], [], []
+        for s, (h, zs) in enumerate(strands):
+            idx = torch.nonzero(cids[s] == c).reshape(-1) if cbases else torch.arange(m, device=device)
+            a0, a1 = words_at(h, idx)
+            W0.append(a0); W1.append(a1); Z.append(zs[idx])
+            del idx
+        w0 = torch.cat(W0); w1 = torch.cat(W1); zz = torch.cat(Z)
+        del W0, W1, Z
+        if w0.numel() == 0:
+            continue
+        # order by (w0, w1): one sort on w0, then odd-even transposition inside the (short) runs of equal w0
+        w0, o = torch.sort(w0)
+        w1, zz = w1[o], zz[o]
+        del o
+        n = w0.numel()
+        for rnd in range(4 * ploidy + 64):
+            swapped = 0
+            for parity in (0, 1):
+                n2 = (n - parity) // 2
+                if n2 <= 0:
+                    continue
+                ia = torch.arange(parity, parity + 2 * n2, 2, device=device)
+                bad = (w0[ia] == w0[ia + 1]) & (w1[ia] > w1[ia + 1])
+                idx = ia[bad]
+                swapped += int(idx.numel())
+                if idx.numel():
+                    t1, tz = w1[idx].clone(), zz[idx].clone()
+                    w1[idx], zz[idx] = w1[idx + 1], zz[idx + 1]
+                    w1[idx + 1], zz[idx + 1] = t1, tz
+                del ia, bad, idx
+            if swapped == 0:
+                break
+        assert bool(((w0[1:] > w0[:-1]) | ((w0[1:] == w0[:-1]) & (w1[1:] >= w1[:-1]))).all()), "generator: not sorted"
+        first = torch.ones(n, dtype=torch.bool, device=device)
+        first[1:] = (w0[1:] != w0[:-1]) | (w1[1:] != w1[:-1])
+        run = torch.cumsum(first, 0) - 1
+        nrun = int(run[-1].item()) + 1
+        zmin = torch.full((nrun,), float("inf"), device=device, dtype=torch.float32)
+        zmin.scatter_reduce_(0, run, zz, reduce="amin")
+        mult = torch.zeros(nrun, dtype=torch.int64, device=device)
+        mult.scatter_add_(0, run, torch.ones_like(run))
+        u0, u1 = w0[first] ^ SIGN, w1[first] ^ SIGN
+        del w0, w1, zz, run, first
+        mean = float(cov_hap) * mult.clamp(max=ploidy).to(torch.float32)
+        cnt = torch.round(mean + torch.sqrt(mean) * zmin).clamp_(0, 32767).to(torch.int16)
+        keep = cnt >= L                        # x and rc(x) carry the same count: trimming keeps the closure
+        K0.append(u0[keep]); K1.append(u1[keep]); CN.append(cnt[keep])
+        del u0, u1, cnt, keep, mean, mult, zmin
+    del strands, cids, z
+    ntot = sum(int(a.numel()) for a in K0)
+    keys = torch.empty((ntot, 2), dtype=torch.int64, device=device)
+    cnt = torch.empty(ntot, dtype=torch.int16, device=device)
+    at = 0
+    for a0, a1, cc in zip(K0, K1, CN):         # (column by column, piece by piece: see diploid_table_wide on torch.stack)
+        e = at + a0.numel()
+        keys[at:e, 0] = a0
+        keys[at:e, 1] = a1
+        cnt[at:e] = cc
+        at = e
+    return keys, cnt
+
+
+def write_table_from_device(path: str, keys: torch.Tensor, cnt: torch.Tensor, k: int, nparts: int = 4) -> int:
+    """Write a device-resident table (keys int64 [n] or [n, W] left aligned, counts int16) as a FastK table, format F
+    with ibyte = 3 (libfastk.c:786-908): the records and the 2^24-entry prefix index are put together on the device,
+    the host only copies and writes -- a 2.5e9-entry table takes its 18 GB of records and nothing else of host memory.
+    Parts are cut on prefix boundaries.  Returns the bytes written."""
+    import os
+    import numpy as np
+    kw = keys.reshape(cnt.numel(), -1)
+    n, kb = cnt.numel(), (k + 3) // 4
+    hb = kb - 3
+    pre = (kw[:, 0] >> 40) & 0xFFFFFF
+    index = torch.cumsum(torch.bincount(pre, minlength=1 << 24), 0)
+    del pre
+    cuts = [0]
+    for p in range(1, nparts):
+        b = int(torch.searchsorted(index, torch.tensor([(n * p) // nparts], device=index.device), right=False).item())
+        cuts.append(max(int(index[min(b, (1 << 24) - 1)].item()), cuts[-1]))
+    cuts.append(n)
+    d, base = os.path.split(path)
+    d = d or "."
+    total = 0
+    with open(os.path.join(d, base + ".ktab"), "wb") as f:
+        np.array([k, nparts, 1, 3], dtype="<i4").tofile(f)
+        index.cpu().numpy().astype("<i8").tofile(f)
+        total += f.tell()
+    del index
+    c = cnt.to(torch.int32) & 0xFFFF
+    for p in range(nparts):
+        lo, hi = cuts[p], cuts[p + 1]
+        with open(os.path.join(d, f".{base}.ktab.{p + 1}"), "wb") as f:
+            np.array([k], dtype="<i4").tofile(f)
+            np.array([hi - lo], dtype="<i8").tofile(f)
+            step = 1 << 27                    # records of 2^27 entries at a time through the device
+            for a in range(lo, hi, step):
+                e = min(a + step, hi)
+                rec = torch.empty((e - a, hb + 2), dtype=torch.uint8, device=keys.device)
+                for j in range(hb):           # suffix bytes: bytes 3 .. kb-1 of the left-aligned k-mer
+                    bj = 3 + j
+                    rec[:, j] = ((kw[a:e, bj // 8] >> (8 * (7 - bj % 8))) & 0xFF).to(torch.uint8)
+                rec[:, hb] = (c[a:e] & 0xFF).to(torch.uint8)
+                rec[:, hb + 1] = (c[a:e] >> 8).to(torch.uint8)
+                rec.cpu().numpy().tofile(f)
+                del rec
+            total += f.tell()
+    return total

@@ -1089,3 +1089,62 @@ def test_every_variant_of_the_lookup_chain_gives_the_same_plot(k, m, seed, env, 
         assert st["nrequests"] == st["nemitted"]
     elif env == {"SMG_ONE_BIT_MAP": "1"}:
         assert st["nrequests"] >= st0["nrequests"]          # the second bit can only drop more
+
+
+def _polyploid_vs_reference(tmp_path, k, tk, tc, L, min_entries, shards):
+    """device-generated polyploid table -> (i) the engine on the resident table, as a bench step runs it, (ii) the drop-in
+    executable on the FastK files, on one GPU and as `shards` prefix shards -- all byte identical to the REFERENCE binary"""
+    import torch
+    from conftest import REF_BIN
+    from smudgeplot_amd import sharded, synth_device
+    if not os.path.exists(REF_BIN):
+        pytest.skip("prebuilt reference binary not present")
+    n = tc.numel()
+    assert n >= min_entries, n
+    plot, st = sharded.hetmers_sharded(k, tk.reshape(-1), tc, symcheck="hash", eng=sharded.TorchEngine(tk.device))
+    assert st["path"] == 1                                  # the generator's table is closed: the symmetry proof holds
+    eng_smu = engine.smu_text(plot.cpu().numpy().reshape(1001, 501))
+    synth_device.write_table_from_device(str(tmp_path / "t"), tk, tc, k, nparts=8)
+    del tk, tc, plot
+    torch.cuda.empty_cache()
+    r = subprocess.run([REF_BIN, f"-e{L}", f"-T{min(64, os.cpu_count() or 1)}", "-oref", "t.ktab"], cwd=tmp_path,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    want = (tmp_path / "ref.smu").read_text()
+    assert want.count("\n") > 1000
+    assert eng_smu == want
+    for gpus, out in ((1, "g1"), (shards, "gs")):
+        env = dict(os.environ, SMUDGEPLOT_GPUS=str(gpus))
+        if gpus > 1:
+            env["SMG_VIRTUAL_SHARDS"] = str(gpus)
+        q = subprocess.run([HETMERS_BIN, f"-e{L}", "-T8", "-v", f"-o{out}", "t.ktab"], cwd=tmp_path, capture_output=True,
+                           text=True, env=env)
+        assert q.returncode == 0, q.stderr
+        assert (tmp_path / f"{out}.smu").read_text() == want, gpus
+    return want
+
+
+def test_octoploid_graded_table_of_1e8_entries_vs_reference_binary(tmp_path):
+    """BASELINE configs[3] stand-in at >= 1e8 entries: 8 haplotypes with GRADED divergences (variant sets carried by 1, 2, 3
+    and 4 of the 8 haplotypes: the smudges AAAAAAAB .. AAAABBBB; k-mers that span sites of two sets form the groups of
+    3-4 one-away neighbours of a polyploid table) -- `bench.py --workload octoploid` at a sixth of its genome"""
+    import torch
+    from smudgeplot_amd import synth_device
+    k, L = 31, 8
+    tk, tc = synth_device.polyploid_table_graded(34_000_000, ploidy=8, cov_hap=14.0, k=k, L=L, seed=4, device=torch.device("cuda:0"))
+    want = _polyploid_vs_reference(tmp_path, k, tk, tc, L, 100_000_000, 8)
+    # the smudges that make it an octoploid: pairs whose minor share is about 1/8, 2/8, 3/8 and 4/8 of the pair's coverage
+    rows = np.array([[int(v) for v in l.split("\t")] for l in want.splitlines()])
+    share = np.round(8.0 * rows[:, 0] / (rows[:, 0] + rows[:, 1])).astype(int)
+    for m in (1, 2, 3, 4):
+        assert rows[share == m, 2].sum() > 0.05 * rows[:, 2].sum(), m
+
+
+def test_hexaploid_k51_table_of_1e8_entries_vs_reference_binary(tmp_path):
+    """BASELINE configs[4] stand-in at >= 1e8 entries: six graded haplotypes, k = 51 (two-word k-mers, the kl_part<2> /
+    kl_probe<..,2> chain) -- `bench.py --workload hexaploid` at a thirteenth of its genome"""
+    import torch
+    from smudgeplot_amd import synth_device
+    k, L = 51, 5
+    tk, tc = synth_device.polyploid_table_wide(30_000_000, ploidy=6, cov_hap=10.0, k=k, L=L, seed=5, device=torch.device("cuda:0"))
+    _polyploid_vs_reference(tmp_path, k, tk, tc, L, 100_000_000, 6)

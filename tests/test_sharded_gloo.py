@@ -26,7 +26,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, k, keys, cnt, cuts, symcheck, drop, q, fallback=True):
+def _worker(rank, world, port, k, keys, cnt, cuts, symcheck, drop, q, fallback=True, own_splitters=False):
     sys.path.insert(0, HERE)
     from fake_engine import NumpyEngine
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -39,8 +39,12 @@ def _worker(rank, world, port, k, keys, cnt, cuts, symcheck, drop, q, fallback=T
             kk = np.delete(kk, drop - lo, axis=0); cc = np.delete(cc, drop - lo)
         tk = torch.from_numpy(np.ascontiguousarray(kk).view(np.int64).reshape(-1).copy())
         tc = torch.from_numpy(cc.view(np.int16).copy())
+        split = None
+        if own_splitters:      # the caller knows the cut k-mers (first k-mer of ranks 1..world-1 of the UNDAMAGED table)
+            split = np.concatenate([np.ascontiguousarray(keys[cuts[r]]).reshape(-1) for r in range(1, world)]).astype(np.uint64)
         try:
-            plot, st = sharded.hetmers_sharded(k, tk, tc, symcheck=symcheck, engine_factory=NumpyEngine, fallback=fallback)
+            plot, st = sharded.hetmers_sharded(k, tk, tc, symcheck=symcheck, engine_factory=NumpyEngine, fallback=fallback,
+                                               splitters=split)
             q.put((rank, "ok" if st["path"] == 1 else "general", plot.numpy().copy(), st["sent"], st["received"]))
         except sharded.NotSymmetric:
             q.put((rank, "notsym", None, 0, 0))
@@ -48,11 +52,11 @@ def _worker(rank, world, port, k, keys, cnt, cuts, symcheck, drop, q, fallback=T
         dist.destroy_process_group()
 
 
-def _run(world, k, keys, cnt, cuts, symcheck, drop=None, fallback=True):
+def _run(world, k, keys, cnt, cuts, symcheck, drop=None, fallback=True, own_splitters=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, k, keys, cnt, cuts, symcheck, drop, q, fallback))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, k, keys, cnt, cuts, symcheck, drop, q, fallback, own_splitters))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -112,6 +116,27 @@ def test_asymmetric_table_falls_back_to_the_general_path_on_rank_0():
             assert np.array_equal(r[2].reshape(1001, 501), want)
         res = _run(2, k, keys, cnt, cuts, symcheck, drop=drop, fallback=False)      # the strict mode still exists
         assert [r[1] for r in res] == ["notsym", "notsym"]
+
+
+def test_callers_splitters_with_a_table_that_fails_the_proof():
+    """splitters handed in by the caller (no shard sizes with them) + a table that is not closed: the general path on
+    rank 0 needs the sizes of the other shards -- it used to raise on rank 0 while rank 1 sat in its send"""
+    k = 31
+    keys, cnt = synth.diploid_table_u64(1500, k=k, seed=79, het_frac=0.5, cov=30, L=5)
+    n = len(cnt)
+    cuts = [sharded.fix_cut(keys, 1, k, c) for c in sharded.shard_bounds(n, 2)]
+    rc = ktab.revcomp_u64(keys, k)
+    cand = np.nonzero(rc != keys)[0]
+    drop = int(cand[(cand != cuts[1])][7])                  # (not the cut k-mer itself: it is a splitter)
+    kept = np.ones(n, bool); kept[drop] = False
+    want = brute.hetmers_plot(ktab.u64_to_packed(keys[kept], k), cnt[kept], k)
+    res = _run(2, k, keys, cnt, cuts, "hash", drop=drop, own_splitters=True)
+    assert [r[1] for r in res] == ["general", "general"]
+    for r in res:
+        assert np.array_equal(r[2].reshape(1001, 501), want)
+    good = brute.hetmers_plot(ktab.u64_to_packed(keys, k), cnt, k)
+    res = _run(2, k, keys, cnt, cuts, "hash", own_splitters=True)          # ... and the closed table with them
+    assert [r[1] for r in res] == ["ok", "ok"] and np.array_equal(res[0][2].reshape(1001, 501), good)
 
 
 def _wide_table(k, m, seed):

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""BASELINE.md section 3's gate at FULL size: `cmp` of the .smu files on the table the bench numbers are quoted on.
+
+   tools/e2e_full_table.py [workload] [genome] [k]      workload: uniform | repeats | octoploid | hexaploid | diploid-wide
+
+ 1. the bench's own generator puts the table into HBM (same seed, same size as `bench.py` for that workload);
+ 2. the engine runs on the DEVICE-RESIDENT table exactly as a bench step does (sharded.hetmers_sharded) -> engine .smu text;
+ 3. the table is written as a FastK table (format F, ibyte 3, 4 parts) from the device;
+ 4. the REFERENCE binary (oracle/_ref/hetmers_ref, PloidyPlot.c compiled from the reference's sources) runs on those files
+    at -T min(64, cores) -- that wall time is also the identical-table CPU baseline BASELINE.md section 3 asks for;
+ 5. the drop-in executable runs on the same files;
+ 6. all three .smu texts must be byte identical.  Prints one JSON object.
+Test / measurement infrastructure (the reference binary is the judge here, never part of the product path)."""
+import json, os, subprocess, sys, tempfile, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from smudgeplot_amd import engine, sharded, synth_device
+import bench
+
+workload = sys.argv[1] if len(sys.argv) > 1 else "uniform"
+G = int(float(sys.argv[2])) if len(sys.argv) > 2 else bench.default_genome(workload)
+k = int(sys.argv[3]) if len(sys.argv) > 3 else bench.default_k(workload)
+RUN_REF = os.environ.get("E2E_SKIP_REF") != "1"
+dev = torch.device("cuda:0")
+t0 = time.time()
+keys, cnt, L, desc = bench.make_table(workload, G, k, dev)
+torch.cuda.synchronize()
+n = cnt.numel()
+out = {"workload": desc, "entries": int(n), "k": k, "L": L, "host_cores": os.cpu_count(), "generate_s": round(time.time() - t0, 1)}
+eng = sharded.TorchEngine(dev)
+plot, st = sharded.hetmers_sharded(k, keys.reshape(-1), cnt, symcheck="hash", eng=eng)
+plot, st = sharded.hetmers_sharded(k, keys.reshape(-1), cnt, symcheck="hash", eng=eng)
+torch.cuda.synchronize()
+eng_smu = engine.smu_text(plot.cpu().numpy().reshape(1001, 501))
+out["engine_step_ms"] = {kk: round(float(st[kk]), 3) for kk in ("ms_pass1", "ms_rclookup", "ms_pass2", "ms_total") if kk in st}
+out["engine_path"] = int(st.get("path", 0))
+del eng, plot
+tmp = os.environ.get("E2E_TMP") or tempfile.gettempdir()
+with tempfile.TemporaryDirectory(prefix="smg_full", dir=tmp) as d:
+    t0 = time.time()
+    out["table_bytes"] = synth_device.write_table_from_device(os.path.join(d, "t"), keys, cnt, k, nparts=4)
+    out["write_s"] = round(time.time() - t0, 1)
+    del keys, cnt
+    torch.cuda.empty_cache()
+    ref = os.path.join(ROOT, "oracle", "_ref", "hetmers_ref")
+    ours = os.path.join(ROOT, "smudgeplot_amd", "bin", "hetmers")
+    cores = min(64, os.cpu_count() or 1)
+    if RUN_REF:
+        t0 = time.time()
+        r = subprocess.run([ref, f"-e{L}", f"-T{cores}", "-oref", "t.ktab"], cwd=d, capture_output=True, text=True)
+        dt = time.time() - t0
+        assert r.returncode == 0, r.stderr
+        out[f"reference_T{cores}"] = {"wall_s": round(dt, 2), "kmers_per_s": n / dt,
+                                      "note": "identical table files, page cache warm from the write (one run)"}
+        ref_smu = open(os.path.join(d, "ref.smu")).read()
+    best = None
+    for _ in range(2):
+        p = os.path.join(d, "gpu.smu")
+        if os.path.exists(p):
+            os.remove(p)
+        t0 = time.time()
+        r = subprocess.run([ours, f"-e{L}", "-T4", "-v", "-ogpu", "t.ktab"], cwd=d, capture_output=True, text=True)
+        dt = time.time() - t0
+        assert r.returncode == 0, r.stderr
+        if best is None or dt < best[0]:
+            best = (dt, r.stderr)
+    out["mi355x_hetmers_end_to_end_T4"] = {"wall_s": round(best[0], 3), "kmers_per_s": n / best[0],
+                                           "engine_line": [l.strip() for l in best[1].splitlines() if "[smg]" in l]}
+    gpu_smu = open(os.path.join(d, "gpu.smu")).read()
+    out["smu_bytes"] = len(gpu_smu)
+    out["smu_rows"] = gpu_smu.count("\n")
+    out["engine_on_resident_table_equals_executable_on_files"] = eng_smu == gpu_smu
+    if RUN_REF:
+        out["byte_identical"] = (gpu_smu == ref_smu) and (eng_smu == ref_smu)
+        out["executable_vs_reference"] = gpu_smu == ref_smu
+        out["engine_vs_reference"] = eng_smu == ref_smu
+        out["speedup_end_to_end"] = out[f"reference_T{cores}"]["wall_s"] / best[0]
+print(json.dumps(out, indent=1))
