@@ -75,6 +75,12 @@
 #ifndef D_TAILB
 #define D_TAILB  8                         // tail: distances 4 .. D_TAILB + 3 come in batches of four LDS reads
 #endif
+#ifndef D_BMDENSE
+#define D_BMDENSE 1                        // request filter: candidates are queued (one u16 slot, with the long-block entries) and
+#endif                                     //   marked in the tile's map window by the dense pass behind the tile, a lane each --
+                                           //   not by every thread for each of its four entries (0: the round-3 per-entry sequence)
+#define D_Q_TAIL 1024u                     // queue word: slot | D_Q_TAIL (detect a pair beyond distance 3) | D_Q_CAND (mark the map)
+#define D_Q_CAND 2048u
 #define D_RD     3                         // distances tested register-to-register; the deferred tail starts at D_RD + 1 (a fourth
                                            //   distance in registers: ten vector registers spill, 16.4 instead of 14.7 ms)
 #ifndef D_ABL
@@ -102,6 +108,18 @@ SMG_DEV unsigned d_next(unsigned v) { return (unsigned) __builtin_amdgcn_update_
 SMG_DEV u64 d_next(u64 v) { return (u64) d_next((unsigned) v) | ((u64) d_next((unsigned) (v >> 32)) << 32); }
 
 SMG_DEV bool d_lane(u64 mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }       // scalar mask -> per-lane predicate, free
+
+// One lane of a wave adds to an LDS counter and the wave takes the old value.  Written out: for `if (lane == 0) atomicAdd(..)`
+// the compiler's atomic optimiser cannot see that one lane is active and builds its general sequence around the atomic
+// (two mbcnt, a compare, a saveexec, a scalar population count and multiply, a multiply-add to hand every lane its share:
+// ~12 instructions for each of the three wave-aggregated atomics of a tile).  LDS operations return in order and the wait
+// is for all of them, so the compiler's own counting stays valid.
+SMG_DEV unsigned d_wave_add(unsigned *ctr, unsigned v, int lane)
+{ unsigned old = 0;
+  if (lane == 0)
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"((unsigned) (uintptr_t) ctr), "v"(v) : "memory");
+  return (unsigned) __builtin_amdgcn_readfirstlane((int) old);
+}
 
 template <int W, bool KF> SMG_DEV void
 d_unpack(const Key<W> &x, const GeoR &G, typename DWord<W>::type &pre, typename DWord<W>::type &suf)
@@ -142,11 +160,11 @@ template <int W> SMG_DEV void mix_hash(const Key<W> &x, unsigned cnt, u64 &ha, u
 }
 
 // the 4 entries of a thread, loaded one tile ahead
-template <int W> struct DPrefetch
+template <int W, bool ANCH> struct DPrefetch
 { Key<W> k[4]; ushort4 c; bool valid;
   uint32_t anchor;               // leading 32 bits of the tile's first owned entry (the base of the tile's block-map window)
   SMG_DEV void load(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, int64_t i0, int64_t ianchor)
-  { anchor = (uint32_t) (keys[ianchor * W] >> 32);
+  { anchor = ANCH ? (uint32_t) (keys[ianchor * W] >> 32) : 0u;
     if constexpr (W == 1)
       { const ulonglong2 v0 = *reinterpret_cast<const ulonglong2 *>(keys + i0);
         const ulonglong2 v1 = *reinterpret_cast<const ulonglong2 *>(keys + i0 + 2);
@@ -167,7 +185,8 @@ template <int W> struct DPrefetch
 #pragma unroll
       for (int w = 0; w < W; w++) asm volatile("" : "+v"(k[e].w[w]));
     unsigned c01 = (unsigned) c.x | ((unsigned) c.y << 16), c23 = (unsigned) c.z | ((unsigned) c.w << 16);
-    asm volatile("" : "+v"(c01), "+v"(c23), "+v"(anchor));
+    if (ANCH) asm volatile("" : "+v"(c01), "+v"(c23), "+v"(anchor));
+    else      asm volatile("" : "+v"(c01), "+v"(c23));
     c.x = (unsigned short) c01; c.y = (unsigned short) (c01 >> 16); c.z = (unsigned short) c23; c.w = (unsigned short) (c23 >> 16);
   }
 };
@@ -287,8 +306,11 @@ SMG_DEV bool d_code_uq(unsigned c) { return ((c & 63u) - 1u) < 62u && c < 128u; 
 
 // One tile.  INNER tiles lie completely inside the table: vector loads, no bounds checks, no table-end cases.
 // RW = 64-bit words per request record: W (the complement k-mer) or W + 1 (+ count | has-hi-pair << 16).
+// does the tile need the leading word of its first owned entry ahead of time? (the per-entry map marking of round 3 does)
+template <int W, int RW> constexpr bool d_anch() { return ((W == 1 && RW == 1) || (W == 2 && RW != 1)) && !D_BMDENSE; }
+
 template <int W, int RW, bool ODD, bool KF, bool INNER> SMG_DEV void
-d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64 &fa, u64 &fb, DPrefetch<W> &pf)
+d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64 &fa, u64 &fb, DPrefetch<W, d_anch<W, RW>()> &pf)
 { typedef typename DWord<W>::type WT;
   constexpr bool D_BM = (W == 1 && RW == 1) || (W == 2 && RW != 1);     // variants that feed the request filter
   const GeoR &G = A.G;
@@ -432,15 +454,16 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
   for (int e = 0; e < D_RD; e++) Sm[4 + e] = Sm[e] >> 1;
 
   // entries whose block continues past distance 3: deferred (their owner queues their slot)
-  if (!(D_ABL & 32))
+  constexpr bool D_BM0 = (W == 1 && RW == 1) || (W == 2 && RW != 1);
+  constexpr bool DENSE = D_BMDENSE && D_BM0;              // (queued behind the tests, together with the candidates)
+  if (!(D_ABL & 32) && !DENSE)
     { u64 Al[4];
 #pragma unroll
       for (int e = 0; e < 4; e++) Al[e] = Sm[e] & Sm[e + 1] & Sm[e + 2] & Sm[e + 3] & ownM;
       const unsigned na = (unsigned) (__popcll(Al[0]) + __popcll(Al[1]) + __popcll(Al[2]) + __popcll(Al[3]));
       if (na)
         { unsigned base = 0;
-          if (lane == 0) base = atomicAdd(S.s_tn, na);
-          base = (unsigned) __builtin_amdgcn_readfirstlane((int) base);
+          base = d_wave_add(S.s_tn, na, lane);
 #pragma unroll
           for (int e = 0; e < 4; e++)
             { if (d_lane(Al[e]))
@@ -485,10 +508,36 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
   // ---- request filter: a CANDIDATE (exactly one suffix-side pair) sets the bit of its block id -------------------
   //@mark D_BMAP
   D_FENCE_P();
+  if (DENSE)
+    { // one queue for both kinds of work the dense pass behind the tile does: an entry whose block goes on past distance 3
+      // (D_Q_TAIL) and a candidate (D_Q_CAND: its block id gets its map bits there) -- at most one word per owned entry
+      u64 Al[4], Cm[4], Qm[4];
+      const bool wantmap = A.bmap != nullptr && !(D_ABL & 8);
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        { Al[e] = (D_ABL & 32) ? 0ull : Sm[e] & Sm[e + 1] & Sm[e + 2] & Sm[e + 3] & ownM;
+          Cm[e] = wantmap ? uniqM[e] & ownM : 0ull;
+          if (!INNER) Cm[e] &= V[e];
+          Qm[e] = Al[e] | Cm[e];
+        }
+      const unsigned nq = (unsigned) (__popcll(Qm[0]) + __popcll(Qm[1]) + __popcll(Qm[2]) + __popcll(Qm[3]));
+      if (nq)
+        { unsigned base = 0;
+          base = d_wave_add(S.s_tn, nq, lane);
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+            { if (d_lane(Qm[e]))
+                { const unsigned q = __builtin_amdgcn_mbcnt_hi((unsigned) (Qm[e] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) Qm[e], base));
+                  S.tailq[q] = (uint16_t) ((unsigned) (slot0 + e) | (d_lane(Al[e]) ? D_Q_TAIL : 0u) | (d_lane(Cm[e]) ? D_Q_CAND : 0u));
+                }
+              base += (unsigned) __popcll(Qm[e]);
+            }
+        }
+    }
   // word 0 of the tile's LDS bit map = the map word of the tile's first owned entry (a uniform, scalar load)
   // (inner tiles: loaded one tile ahead with the entries -- as a load of its own it was waited for on the spot)
-  const uint32_t bmbase = D_BM ? (((INNER ? pf_anchor : (uint32_t) (A.keys[(g0 + D_LEAD) * W] >> 32)) >> bmsh) & ~31u) : 0u;
-  if (D_BM && A.bmap && !(D_ABL & 8))
+  const uint32_t bmbase = (D_BM && !DENSE) ? (((INNER ? pf_anchor : (uint32_t) (A.keys[(g0 + D_LEAD) * W] >> 32)) >> bmsh) & ~31u) : 0u;
+  if (D_BM && !DENSE && A.bmap && !(D_ABL & 8))
     { // leading word of the thread's own entries, back from the staged copy (cheaper than four registers kept alive
       // across the tests)
       u64 kw[4];
@@ -557,9 +606,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
       const unsigned cnt_w = (unsigned) (__popcll(E0) + __popcll(E1) + __popcll(E2) + __popcll(E3));
       unsigned base = 0;
       if (cnt_w)
-        { if (lane == 0) base = atomicAdd(S.s_qn, cnt_w);
-          base = (unsigned) __builtin_amdgcn_readfirstlane((int) base);
-        }
+        base = d_wave_add(S.s_qn, cnt_w, lane);
       const bool fp = A.want_fp() && !(D_ABL & 1);
       // Unrolled, the four entries kept apart by scheduling fences (interleaved they need ~30 more vector registers
       // than the kernel has).  The rolled loop -- the masks rotating through one register pair, a counter, two branches
@@ -743,7 +790,7 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
       cold->times[3 * (size_t) blockIdx.x] = wall_clock64(); cold->times[3 * (size_t) blockIdx.x + 2] = hw;
     }
 
-  DPrefetch<W> pf;
+  DPrefetch<W, d_anch<W, RW>()> pf;
   pf.valid = false;
   int par = 0;
   const unsigned cls = blockIdx.x % D_NCLS;
@@ -783,22 +830,44 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
       const bool last = tnext >= A.ntiles;
       const unsigned tn = s_tn[par];               // (zeroed again behind the barrier at the end of this iteration: the
       const unsigned qn = s_qn;                    //  next tile counts in the other one)
-      if (D_BM && A.bmap)                           // candidate-block bits of this tile -> global map
+      constexpr bool DENSE = D_BMDENSE && D_BM;
+      // word of the global map that word 0 of the tile's LDS window stands for (the window starts at the map word of the
+      // tile's first owned entry)
+      const uint32_t bmw0 = D_BM ? (uint32_t) __builtin_amdgcn_readfirstlane((int) (((uint32_t) (ent[D_LEAD * W] >> 32) >> A.bmsh()) >> 5)) : 0u;
+      if (D_BM && !DENSE && A.bmap)                 // candidate-block bits of this tile -> global map
         { const int two = A.two() ? 1 : 0;          // (two-bit map: twice the words, at twice the word offset)
           for (int w = t; w < (D_BMW << two); w += D_TPB)
             { const unsigned v = bm[w];
               if (v)
-                { atomicOr(&A.bmap[(((size_t) (((uint32_t) (ent[D_LEAD * W] >> 32) >> A.bmsh()) >> 5)) << two) + w], v);
+                { atomicOr(&A.bmap[((size_t) bmw0 << two) + w], v);
                   bm[w] = 0;
                 }
             }
         }
 
-      // ---- deferred tail: one dense detection pass over this tile's queued entries (a lane each) ---------------------
-      // A hit sets the bits of the entry and of its partners in the deferred-entry map (one bit per table entry, so an
-      // entry named twice is redone once).
+      // ---- the dense pass over this tile's queued entries (a lane each) ------------------------------------------------
+      // D_Q_TAIL: does the entry own a pair at distance 4..30, or does its block go on past 30?  A hit sets the bits of the
+      // entry and of its partners in the deferred-entry map (one bit per table entry, so an entry named twice is redone once).
+      // D_Q_CAND: a candidate marks its block id in the tile's window of the map (LDS; ids beyond the window -- a sparse
+      // table -- straight in the global map).
       for (unsigned q = t; q < tn && !(D_ABL & 512); q += D_TPB)
-        { const int sa = (int) tailq[q];
+        { const unsigned qw = tailq[q];
+          const int sa = (int) (DENSE ? qw & 1023u : qw);
+          if (DENSE && (qw & D_Q_CAND))
+            { const u64 kw = ent[sa * W];
+              const uint32_t id = (uint32_t) (kw >> 32) >> A.bmsh();
+              const uint32_t rel = id - (bmw0 << 5);
+              if (A.two())
+                { const u64 v = bm2_bits(id, (uint32_t) kw);
+                  if (rel < D_BMF) atomicOr(&reinterpret_cast<u64 *>(bm)[rel >> 5], v);
+                  else             atomicOr(&reinterpret_cast<u64 *>(A.bmap)[id >> 5], v);
+                }
+              else
+                { if (rel < D_BMF) atomicOr(&bm[rel >> 5], 1u << (rel & 31));
+                  else             atomicOr(&A.bmap[id >> 5], 1u << (id & 31));
+                }
+            }
+          if (DENSE && !(qw & D_Q_TAIL)) continue;
           unsigned hm; bool big;
           d_detect<W, ODD, KF>(A, ent, lcn, g0, sa, hm, big);
           if (hm | (unsigned) big)                           // rare: mark the entry and its partners for kf_bigfix
@@ -856,6 +925,16 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
         }
       if (!(D_ABL & 8192)) lds_barrier();
       if (t == 0) s_tn[par] = 0;
+      if (DENSE && A.bmap)                          // the tile's window is complete behind the barrier: -> global map.  (The
+        { const int two = A.two() ? 1 : 0;          //  next marks fall behind the next tile's barrier: no third one is needed.)
+          for (int w = t; w < (D_BMW << two); w += D_TPB)
+            { const unsigned v = bm[w];
+              if (v)
+                { atomicOr(&A.bmap[((size_t) bmw0 << two) + w], v);
+                  bm[w] = 0;
+                }
+            }
+        }
       tile = tnext; tnext = tnext2;
       tnext2 = (int64_t) gridDim.x + (int64_t) (unsigned) __builtin_amdgcn_readfirstlane((int) s_tk[par]) * D_NCLS + cls;
     }

@@ -1091,7 +1091,7 @@ def test_every_variant_of_the_lookup_chain_gives_the_same_plot(k, m, seed, env, 
         assert st["nrequests"] >= st0["nrequests"]          # the second bit can only drop more
 
 
-def _polyploid_vs_reference(tmp_path, k, tk, tc, L, min_entries, shards):
+def _polyploid_vs_reference(tmp_path, k, tk, tc, L, min_entries, shards, min_rows=1000):
     """device-generated polyploid table -> (i) the engine on the resident table, as a bench step runs it, (ii) the drop-in
     executable on the FastK files, on one GPU and as `shards` prefix shards -- all byte identical to the REFERENCE binary"""
     import torch
@@ -1111,7 +1111,7 @@ def _polyploid_vs_reference(tmp_path, k, tk, tc, L, min_entries, shards):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     want = (tmp_path / "ref.smu").read_text()
-    assert want.count("\n") > 1000
+    assert want.count("\n") > min_rows
     assert eng_smu == want
     for gpus, out in ((1, "g1"), (shards, "gs")):
         env = dict(os.environ, SMUDGEPLOT_GPUS=str(gpus))
@@ -1147,4 +1147,4 @@ def test_hexaploid_k51_table_of_1e8_entries_vs_reference_binary(tmp_path):
     from smudgeplot_amd import synth_device
     k, L = 51, 5
     tk, tc = synth_device.polyploid_table_wide(30_000_000, ploidy=6, cov_hap=10.0, k=k, L=L, seed=5, device=torch.device("cuda:0"))
-    _polyploid_vs_reference(tmp_path, k, tk, tc, L, 100_000_000, 6)
+    _polyploid_vs_reference(tmp_path, k, tk, tc, L, 100_000_000, 6, min_rows=300)
