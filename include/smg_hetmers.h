@@ -181,6 +181,16 @@ int smg_engine_decode(smg_engine *e, int kmer, int ibyte, int64_t nels,
 int smg_engine_bind(smg_engine *e, int kmer, int64_t nels, const uint64_t *d_keys,
                     const uint16_t *d_counts, char *errbuf, size_t errlen);
 
+/* Hand over the prefix index that a FastK table carries in its stub (`index[p]` = number of entries whose first ibyte
+   bytes are <= p, 2^(8 ibyte) int64 in DEVICE memory; libfastk.c:841, the table GoTo_Kmer_Entry bisects on,
+   libfastk.c:1360-1386) for the table that is bound / decoded right now; first_entry = number of this shard's first
+   entry in the whole table (0 for a whole table).  With ibyte = 3 and k >= 12 the engine takes it as its look-up
+   directory (a bucket per 24 leading k-mer bits) and pass 1 builds none of its own; a coarser index is accepted and not
+   used.  The index is read during this call's stream work only (it may be freed after the stream has drained).
+   Binding, decoding or conditioning another table forgets it.                                                       */
+int smg_engine_set_prefix_index(smg_engine *e, const int64_t *d_prefix_index, int ibyte, int64_t first_entry,
+                                char *errbuf, size_t errlen);
+
 /* Condition the engine's table in place (decoded or bound; the result is engine-owned):
    trim to count >= ethresh and / or close it under reverse complement.  *new_nels (may be NULL)
    receives the new number of entries.

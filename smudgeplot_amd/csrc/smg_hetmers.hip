@@ -574,6 +574,10 @@ struct smg_engine
   uint8_t     *deg;    int64_t deg_cap;      // degree bytes (counted path) / code bytes (fast path)
   uint16_t    *sig;    int64_t sig_cap;       // k <= 32: look-up signatures (2 bytes per entry)
   uint32_t    *bstart; int64_t bstart_cap;
+  uint32_t    *ixdir;  int64_t ixdir_cap;    // the table's own FastK prefix index (2^24 + 1 bucket starts, relative to this shard) as directory
+  bool         have_ixdir;                   //   ... handed over with the current table (smg_engine_set_prefix_index); gone when the table changes
+  bool         dir_preset;                   //   the current run looks up through ixdir: pass 1 writes no directory
+  bool         have_ends;  u64 end_first, end_last;     // leading words of the first and the last entry of the bound table (read once)
   u64         *req;    int64_t req_cap;      // bytes
   u64         *req2;   int64_t req2_cap;     // radix sort output
   void        *sort_tmp; int64_t sort_tmp_cap;
@@ -692,7 +696,7 @@ extern "C" void smg_engine_destroy(smg_engine *e)
 { if (!e) return;
   hipSetDevice(e->device);
   hipStreamSynchronize(e->stream);
-  hipFree(e->own_keys); hipFree(e->own_cnt); hipFree(e->deg); hipFree(e->sig); hipFree(e->bstart);
+  hipFree(e->own_keys); hipFree(e->own_cnt); hipFree(e->deg); hipFree(e->sig); hipFree(e->bstart); hipFree(e->ixdir);
   hipFree(e->req); hipFree(e->req2); hipFree(e->sort_tmp); hipFree(e->dense); hipFree(e->chunk_off); hipFree(e->skey[0]); hipFree(e->skey[1]); hipFree(e->sidx[0]); hipFree(e->sidx[1]); hipFree(e->dbits); hipFree(e->biglist); hipFree(e->farp); hipFree(e->p1times); hipFree(e->p1tick); hipFree(e->xtick); hipFree(e->chunk_fill); hipFree(e->bmap); hipFree(e->reqf); hipFree(e->chunk_fillf); hipFree(e->route_cnt); hipFree(e->route_off);
   hipFree(e->partials); hipFree(e->ctrl); hipFree(e->d_split); hipFree(e->p1cold); hipFree(e->ghist); hipFree(e->boff);
   hipFree(e->whist);
@@ -710,6 +714,7 @@ static int set_table(smg_engine *e, int kmer, int64_t nels, char *errbuf, size_t
   e->W = (kmer + 31) / 32;
   e->n = nels;
   e->prepared = false; e->counted_done = false; e->lookup_pending = false;
+  e->have_ixdir = false; e->dir_preset = false; e->have_ends = false;        // (properties of the table that was bound before)
   memset(&e->st, 0, sizeof(e->st));
   e->st.nels = nels;
   e->st.key_words = e->W;
@@ -810,6 +815,38 @@ extern "C" int smg_engine_decode(smg_engine *e, int kmer, int ibyte, int64_t nel
                                  char *errbuf, size_t errlen)
 { return decode_at(e, kmer, ibyte, nels, 0, d_records, d_prefix_index, errbuf, errlen); }
 
+// ---- the table's own prefix index as look-up directory -------------------------------------------------------------
+// A FastK table carries the number of entries up to every 3-byte prefix (libfastk.c:841, `index[p]` = entries whose first
+// ibyte bytes are <= p).  With ibyte = 3 that IS a bucket directory over the leading 24 k-mer bits (bucket = hi32 >> 8;
+// ~150 entries per bucket at 2.5e9 entries): ixdir[b] = first entry of bucket b relative to this shard, ixdir[2^24] = n.
+// Pass 1 then writes no directory at all (round 3: a shift, a compare and a rare store per entry, and 130 MB cleared per
+// run); the few million look-ups that survive the request filter bisect one or two steps longer.
+#define IXDIR_BITS 24
+__global__ void __launch_bounds__(TPB)
+k_index_dir(const int64_t *__restrict__ index, int64_t ibase, int64_t n, uint32_t *__restrict__ out)
+{ const int64_t b = (int64_t) blockIdx.x * TPB + threadIdx.x;
+  if (b > (1ll << IXDIR_BITS)) return;
+  int64_t v = (b ? index[b - 1] : 0) - ibase;
+  if (b == (1ll << IXDIR_BITS)) v = n;
+  out[b] = (uint32_t) (v < 0 ? 0 : v > n ? n : v);
+}
+
+extern "C" int smg_engine_set_prefix_index(smg_engine *e, const int64_t *d_prefix_index, int ibyte, int64_t first_entry,
+                                           char *errbuf, size_t errlen)
+{ if (!e) return fail(errbuf, errlen, SMG_EINVAL, "null engine%s");
+  if (ibyte < 1 || ibyte > 3 || !d_prefix_index) return fail(errbuf, errlen, SMG_EINVAL, "prefix index: ibyte must be 1, 2 or 3%s");
+  e->have_ixdir = false;
+  if (ibyte != 3 || e->kmer < 12 || getenv("SMG_NO_INDEX_DIR")) return SMG_OK;     // (a coarser index is of no use as a directory)
+  HIPCHK(hipSetDevice(e->device));
+  int rc = grow(&e->ixdir, &e->ixdir_cap, (int64_t) sizeof(uint32_t) * ((1ll << IXDIR_BITS) + 2), errbuf, errlen);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_index_dir, dim3((unsigned) (((1ll << IXDIR_BITS) + 1 + TPB - 1) / TPB)), dim3(TPB), 0, e->stream,
+                     d_prefix_index, first_entry, e->n, e->ixdir);
+  HIPCHK(hipGetLastError());
+  e->have_ixdir = true;
+  return SMG_OK;
+}
+
 static int read_ctrl(smg_engine *e, char *errbuf, size_t errlen)
 { HIPCHK(hipMemcpyAsync(e->h_ctrl, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -820,13 +857,21 @@ static int read_ctrl(smg_engine *e, char *errbuf, size_t errlen)
 // every entry is looked up (exact proof, counted and general paths); 64 for the hash proof, whose filter leaves a few
 // million look-ups: their bisection still stays inside one or two lines of signatures, while pass 1 writes -- and every
 // run clears -- an eighth of the directory (1 GB -> 128 MB at 2.5e9 entries: -0.5 ms per run).
-static int dir_geometry(smg_engine *e, int per, char *errbuf, size_t errlen)
-{ u64 first = 0, last = 0;
-  if (e->n > 0)
-    { HIPCHK(hipMemcpyAsync(&first, e->keys, 8, hipMemcpyDeviceToHost, e->stream));
-      HIPCHK(hipMemcpyAsync(&last, e->keys + (size_t) (e->n - 1) * e->W, 8, hipMemcpyDeviceToHost, e->stream));
-      HIPCHK(hipStreamSynchronize(e->stream));
+static int dir_geometry(smg_engine *e, int per, char *errbuf, size_t errlen, bool index_ok = false)
+{ e->dir_preset = false;
+  if (index_ok && e->have_ixdir && e->n > 0)
+    { e->dir.bstart = e->ixdir; e->dir.b0 = 0; e->dir.dsh = 32 - IXDIR_BITS; e->dir.nb = 1u << IXDIR_BITS;
+      e->dir_preset = true;
+      return SMG_OK;
     }
+  u64 first = 0, last = 0;
+  if (e->n > 0 && !e->have_ends)      // (read once per bound table: a host round trip)
+    { HIPCHK(hipMemcpyAsync(&e->end_first, e->keys, 8, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipMemcpyAsync(&e->end_last, e->keys + (size_t) (e->n - 1) * e->W, 8, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      e->have_ends = true;
+    }
+  if (e->n > 0) { first = e->end_first; last = e->end_last; }
   if (last < first) return fail(errbuf, errlen, SMG_EFORMAT, "table entries are not strictly increasing%s");
   int bits = 4;
   { const char *v = getenv("SMG_DIR_PER"); if (v && atoi(v) >= 1) per = atoi(v); }       // tuning override
@@ -1065,7 +1110,8 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
   if ((rc = grow(&e->deg, &e->deg_cap, ((e->n + 15) & ~15ll) + 32, errbuf, errlen))) return rc;
   const int64_t pbytes = ((e->n + 15) & ~15ll) + 32;
   e->use_sig = e->W <= 2;
-  if ((rc = dir_geometry(e, (emit_all || e->W > 1) ? 8 : 64, errbuf, errlen))) return rc;
+  // (hash proof of one- and two-word k-mers: the table's own prefix index, when it came with one, is the directory)
+  if ((rc = dir_geometry(e, (emit_all || e->W > 1) ? 8 : 64, errbuf, errlen, !emit_all && e->W <= 2))) return rc;
   // request filter: the candidate block map (an empty shard has one too -- all zero -- so that every rank of a
   // sharded run reports the same geometry and takes part in the exchange of the maps)
   e->bm_bits = 0; e->bm2 = 0;
@@ -1091,7 +1137,7 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
     }
   { const char *v = getenv("SMG_SIG"); if (v && e->W <= 2) e->use_sig = atoi(v) != 0; }
   if (e->use_sig && (rc = grow(&e->sig, &e->sig_cap, 2 * pbytes, errbuf, errlen))) return rc;
-  if (e->n > 0)
+  if (e->n > 0 && !e->dir_preset)
     HIPCHK(hipMemsetAsync(e->bstart, 0xFF, sizeof(uint32_t) * ((size_t) e->dir.nb + 2), e->stream));
   if (e->n == 0)
     { HIPCHK(hipMemsetAsync(e->bstart, 0, sizeof(uint32_t) * ((size_t) e->dir.nb + 2), e->stream));
@@ -1180,7 +1226,7 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
       if (narrow)
         {
           P1Hot hot;
-          hot.keys = a.keys; hot.cnt = a.cnt; hot.n = a.n; hot.code = a.code; hot.sig = a.sig; hot.bstart = e->bstart;
+          hot.keys = a.keys; hot.cnt = a.cnt; hot.n = a.n; hot.code = a.code; hot.sig = a.sig; hot.bstart = e->dir_preset ? (uint32_t *) NULL : e->bstart;
           hot.bmap = a.bmap; hot.b0 = e->dir.b0; hot.nb = e->dir.nb; hot.shifts = (unsigned) e->dir.dsh | ((unsigned) a.sigsh << 6) | (((unsigned) a.bmsh & 31u) << 12)
                        | ((emit_all ? 1u : 0u) << 18) | ((want_fp ? 1u : 0u) << 19) | ((unsigned) e->lg.nb << 20) | ((unsigned) e->bm2 << 24);
           hot.G = gr; hot.ntiles = ntiles;
@@ -2078,6 +2124,7 @@ extern "C" int smg_engine_condition(smg_engine *e, int ethresh, int do_trim, int
 #undef CRC
   e->n = n;
   e->prepared = false; e->counted_done = false;
+  e->have_ixdir = false; e->dir_preset = false; e->have_ends = false;      // (another table now: its index and ends are gone)
   e->st.nels = n;
   e->st.ms_decode += ms;
   if (new_nels) *new_nels = n;
@@ -2403,6 +2450,7 @@ extern "C" int smg_engine_symm_finish(smg_engine *e, const uint64_t *d_recv, int
     }
   e->n = kept;
   e->prepared = false; e->counted_done = false;
+  e->have_ixdir = false; e->dir_preset = false; e->have_ends = false;
   e->st.nels = kept;
   if (new_nels) *new_nels = kept;
   return SMG_OK;
@@ -2541,6 +2589,7 @@ static int host_run(const smg_table_source *tv, const smg_opts *opts, int64_t *p
     { if ((rc = smg_engine_condition(e, opts->ethresh, opts->condition & SMG_COND_TRIM, opts->condition & SMG_COND_SYMM,
                                      NULL, errbuf, errlen))) goto done;
     }
+  else if ((rc = smg_engine_set_prefix_index(e, d_index, tv->ibyte, 0, errbuf, errlen))) goto done;   // the table's index = its directory
   clock_gettime(CLOCK_MONOTONIC, &w2); cond_s = SECS(w1, w2);
   if ((rc = smg_engine_run(e, symcheck, d_plot, NULL, errbuf, errlen))) goto done;
   clock_gettime(CLOCK_MONOTONIC, &w1); run_s = SECS(w2, w1);

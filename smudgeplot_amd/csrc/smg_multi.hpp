@@ -214,6 +214,9 @@ static void *multi_worker(void *argp)
       DecodeHook hk; hk.e = e; hk.d_index = d_index; hk.ibyte = tv->ibyte; hk.ibase = lo;
       if ((c->rc[r] = ingest_records(tv, c->pbyte, lo, hi, NULL, c->devs[r], c->io_threads, NULL, eb, el, decode_hook, &hk))) c->failed = 1;
     }
+  // a shard that is taken as it is keeps the table's prefix index as its look-up directory (bucket starts relative to entry lo)
+  if (MOK && !c->condition && (c->rc[r] = smg_engine_set_prefix_index(e, d_index, tv->ibyte, lo, eb, el))) c->failed = 1;
+  if (MOK && !c->condition && hipStreamSynchronize(e->stream) != hipSuccess) MFAIL(SMG_ENODEV, "index conversion failed");
   if (d_index) { hipFree(d_index); d_index = NULL; }
   if (MOK && (c->condition & SMG_COND_TRIM))
     { int64_t nn = 0;

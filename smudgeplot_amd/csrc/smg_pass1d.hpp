@@ -401,6 +401,8 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
         }
       if (bad & scanM) *S.s_unsorted = 1u;
       // raw bucket numbers; the offset and the bound are applied on the (rare) store path only
+      // (no directory is written when the table came with its own: the FastK prefix index, smg_engine_set_prefix_index)
+      if (A.bstart != nullptr) {
       uint32_t bq[5];
 #pragma unroll
       for (int e = 0; e < 4; e++) bq[e] = (uint32_t) (kk[e].w[0] >> 32) >> A.dsh();
@@ -418,6 +420,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
               if (!INNER && ((vmask >> e) & 1u) && i0 + e + 1 == n) A.bstart[A.nb] = (uint32_t) n;
             }
         }
+      }
     }
 
   // ---- signatures ---------------------------------------------------------------------------------------------------

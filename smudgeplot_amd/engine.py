@@ -59,7 +59,7 @@ class Stats(C.Structure):
 
 EXPORTS = [
     "smg_hetmers_run", "smg_hetmers_run_source", "smg_device_count", "smg_engine_create", "smg_engine_destroy",
-    "smg_engine_decode", "smg_engine_bind", "smg_engine_condition", "smg_engine_run", "smg_engine_pass1",
+    "smg_engine_decode", "smg_engine_bind", "smg_engine_set_prefix_index", "smg_engine_condition", "smg_engine_run", "smg_engine_pass1",
     "smg_engine_nreq", "smg_engine_record_words", "smg_engine_route", "smg_engine_route_device", "smg_engine_apply",
     "smg_engine_apply_own", "smg_engine_blockmap", "smg_engine_blockmap_copy", "smg_engine_filter",
     "smg_engine_presort", "smg_engine_merge_maps", "smg_engine_set_blockmap_bits",
@@ -116,6 +116,7 @@ def load_library():
     lib.smg_engine_destroy.argtypes = [vp]
     lib.smg_engine_decode.argtypes = [vp, i32, i32, i64, vp, vp, *err]
     lib.smg_engine_bind.argtypes = [vp, i32, i64, vp, vp, *err]
+    lib.smg_engine_set_prefix_index.argtypes = [vp, vp, i32, i64, *err]
     lib.smg_engine_condition.argtypes = [vp, i32, i32, i32, C.POINTER(i64), *err]
     lib.smg_engine_run.argtypes = [vp, i32, vp, C.POINTER(Stats), *err]
     lib.smg_engine_pass1.argtypes = [vp, i32, *err]
@@ -275,6 +276,10 @@ class Engine:
 
     def bind(self, k: int, nels: int, keys_ptr: int, counts_ptr: int):
         _check(self.lib.smg_engine_bind(self.h, k, nels, keys_ptr, counts_ptr, self._buf, 512), self._buf)
+
+    def set_prefix_index(self, index_ptr: int, ibyte: int = 3, first_entry: int = 0):
+        """the FastK prefix index of the bound table (int64[2^(8 ibyte)] on the device): the engine's look-up directory"""
+        _check(self.lib.smg_engine_set_prefix_index(self.h, index_ptr, ibyte, first_entry, self._buf, 512), self._buf)
 
     def decode(self, k: int, ibyte: int, nels: int, records_ptr: int, index_ptr: int):
         _check(self.lib.smg_engine_decode(self.h, k, ibyte, nels, records_ptr, index_ptr, self._buf, 512),

@@ -52,10 +52,15 @@ class TorchEngine:
         stream = torch.cuda.current_stream(device).cuda_stream
         self.e = _engine.Engine(index, stream)
 
-    def bind(self, k, keys, counts):
+    def bind(self, k, keys, counts, index=None, first_entry=0):
+        """index: the table's FastK prefix index (int64[2^24] on the device, entries up to every 3-byte prefix of the WHOLE
+        table; first_entry = number of this shard's first entry in it) -- what a .ktab stub carries, libfastk.c:841"""
         self._keep = (keys, counts)
         self.words = (k + 31) // 32
         self.e.bind(k, counts.numel(), keys.data_ptr(), counts.data_ptr())
+        if index is not None:
+            self.e.set_prefix_index(index.data_ptr(), 3, first_entry)
+            torch.cuda.current_stream(self.device).synchronize()      # (the index may go away after this call)
 
     def pass1(self, symcheck, exchange=True, world=1):
         # nobody to exchange block maps with: the finest map (32 id bits) costs nothing but its memset.  Exchanged maps:
@@ -270,7 +275,8 @@ def condition_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, ethresh:
 
 
 def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: str = "hash",
-                    engine_factory=TorchEngine, group=None, eng=None, fallback: bool = True, splitters=None):
+                    engine_factory=TorchEngine, group=None, eng=None, fallback: bool = True, splitters=None,
+                    prebound: bool = False):
     """Run hetmers on this rank's shard; returns (plot int64[1001*501] on the shard's device,
     summed over all ranks, and a stats dict).  Collective: every rank must call it.
 
@@ -281,6 +287,8 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
     fallback: a table that fails the symmetry proof is collected on rank 0 and run through the general path
              (False: raise NotSymmetric instead)
     keys = counts = None with `eng` and `splitters` from condition_sharded: the engine owns the shard already
+    prebound: `eng` is bound to exactly these tensors already (eng.bind, possibly with the table's prefix index): the
+             table is not bound again, so what the engine knows about it (index directory, first / last k-mer) stays
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -300,7 +308,9 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
         n = counts.numel()
         if eng is None:
             eng = engine_factory(dev)
-        eng.bind(k, keys, counts)
+            prebound = False
+        if not prebound:
+            eng.bind(k, keys, counts)
 
     # splitters = first k-mer of ranks 1..world-1 (an empty shard inherits its successor's).  They depend
     # on the table only: an engine that is reused on the same shard (bench.py) keeps them.
