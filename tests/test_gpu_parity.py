@@ -1148,3 +1148,33 @@ def test_hexaploid_k51_table_of_1e8_entries_vs_reference_binary(tmp_path):
     k, L = 51, 5
     tk, tc = synth_device.polyploid_table_wide(30_000_000, ploidy=6, cov_hap=10.0, k=k, L=L, seed=5, device=torch.device("cuda:0"))
     _polyploid_vs_reference(tmp_path, k, tk, tc, L, 100_000_000, 6, min_rows=300)
+
+
+@pytest.mark.parametrize("k,G,rep", [(31, 3_000_000, 0.0), (31, 3_000_000, 0.05), (27, 1_000_000, 0.0), (51, 1_500_000, 0.0), (12, 400_000, 0.0)])
+def test_the_tables_prefix_index_as_lookup_directory_changes_nothing(k, G, rep):
+    """smg_engine_set_prefix_index: the FastK prefix index (entries up to every 3-byte prefix, libfastk.c:841) handed
+    over with a bound table replaces the directory pass 1 used to build -- same plot, same requests, and the reference
+    numpy oracle agrees on the small case"""
+    import torch
+    from smudgeplot_amd import sharded, synth_device
+    dev = torch.device("cuda:0")
+    if k <= 31:
+        tk, tc = synth_device.diploid_table(G, k=k, het=0.01, cov=50.0, L=10, seed=9, device=dev, repeats=rep)
+    else:
+        tk, tc = synth_device.diploid_table_wide(G, k=k, het=0.01, cov=50.0, L=10, seed=9, device=dev)
+    kw0 = tk if tk.dim() == 1 else tk[:, 0]
+    index = torch.cumsum(torch.bincount((kw0 >> 40) & 0xFFFFFF, minlength=1 << 24), 0)
+    flat = tk.reshape(-1)
+    plots, reqs = [], []
+    for use in (False, True):
+        eng = sharded.TorchEngine(dev)
+        eng.bind(k, flat, tc, index=index if use else None)
+        for _ in range(2):                                   # (twice: the engine keeps what it knows about a bound table)
+            plot, st = sharded.hetmers_sharded(k, flat, tc, symcheck="hash", eng=eng, prebound=True)
+            assert st["path"] == 1
+            plots.append(plot.cpu().numpy().copy()); reqs.append(st["nrequests"])
+    assert all(np.array_equal(plots[0], p) for p in plots[1:])
+    assert len(set(reqs)) == 1 and plots[0].sum() > 0
+    if k == 12:
+        keys = tk.cpu().numpy().view(np.uint64)
+        assert np.array_equal(plots[0].reshape(1001, 501), brute.hetmers_plot(ktab.u64_to_packed(keys, k), tc.cpu().numpy().view(np.uint16), k))
