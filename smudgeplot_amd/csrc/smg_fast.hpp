@@ -62,7 +62,12 @@ struct FastArgs
   uint32_t       *bmap;          // candidate block map (or NULL): bit (hi32(kmer) >> bmsh) is set when a window block
   int             bmsh;          //   (coarsened to <= 32 leading bits) holds an entry with exactly one suffix-side pair
   int             bm2;           // two-bit map (below): 64-bit map words
+  int             flip;          // single shard, fused look-ups: the CANDIDATES send (a third of the records), the owners of a
+                                 //   pair at p > k-1-p mark the map, and a look-up reads the complement's code byte (smg_lookup.hpp)
 };
+
+// code byte (P flag masked off) -> "owns a pair at p > k-1-p": several pairs, or one that is not self-mirrored
+SMG_DEV bool code_hi(unsigned c) { return c - 63u < 65u; }                    // 63 .. 127
 
 // Two-bit candidate map (one GPU, 32 id bits, one-word k-mers of >= 24 bases).  The map word of 32 block ids is 64 bits
 // wide: the low half holds the usual bit (id & 31), the high half a SECOND bit at a position hashed from the 32 k-mer
@@ -1204,12 +1209,12 @@ kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, const unsigned *__re
               const unsigned code = make_code(s_all, partner - i, w2);
               A.code[i] = (uint8_t) code;
               if ((code & 63) == CODE_FAR) farp[r] = (uint32_t) partner;
-              if (W <= 2 && A.bmap && s_all == 1)             // a candidate: mark its block for the request filter
+              if (W <= 2 && A.bmap && (A.flip ? s_hi > 0 : s_all == 1))   // a candidate (flip: an owner of a pair at p > k-1-p): mark its block
                 { const uint32_t id = (uint32_t) (A.keys[i * W] >> 32) >> A.bmsh;
                   if (A.bm2) atomicOr(reinterpret_cast<u64 *>(A.bmap) + (id >> 5), bm2_bits(id, (uint32_t) A.keys[i * W]));
                   else atomicOr(&A.bmap[id >> 5], 1u << (id & 31));
                 }
-              if (s_hi > 0) slist[atomicAdd(&s_nl, 1u)] = (uint32_t) i;
+              if (A.flip ? s_all == 1 : s_hi > 0) slist[atomicAdd(&s_nl, 1u)] = (uint32_t) i;
             }
         }
       __syncthreads();

@@ -615,6 +615,7 @@ struct smg_engine
   bool         lookup_pending; // look-ups of received requests were queued without a host wait (their time is read later)
   bool         use_sig;    // pass 1 writes the 2-byte look-up signatures (not worth their 5 GB when the filter leaves 1 request in 115)
   int          bm2;        //   the map is a two-bit map (smg_fast.hpp): 64-bit words, private to this engine
+  int          flip;       //   FastArgs.flip: the last pass 1 let the candidates send (one shard, fused look-ups)
   int          bm_cap;     //   id bits of the block map: 32 on one GPU, 30 when the maps of several shards are exchanged
   int          bm_want;    //   ... as asked for by smg_engine_set_blockmap_bits (0: default)
   P1Cold      *p1cold;     // rarely used arguments of kf_pass1_d (device copy)
@@ -1090,6 +1091,7 @@ static FastArgs make_fast(smg_engine *e)
   a.bmap = e->bm_bits ? e->bmap : NULL;
   a.bmsh = 32 - e->bm_bits;
   a.bm2 = e->bm2;
+  a.flip = e->flip;
   return a;
 }
 
@@ -1114,7 +1116,7 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
   if ((rc = dir_geometry(e, (emit_all || e->W > 1) ? 8 : 64, errbuf, errlen, !emit_all && e->W <= 2))) return rc;
   // request filter: the candidate block map (an empty shard has one too -- all zero -- so that every rank of a
   // sharded run reports the same geometry and takes part in the exchange of the maps)
-  e->bm_bits = 0; e->bm2 = 0;
+  e->bm_bits = 0; e->bm2 = 0; e->flip = 0;
   e->filtered = false; e->presorted = 0;
   e->lg.nb = 0;
   if (filter_ok(e) && !emit_all && !getenv("SMG_NO_FILTER"))
@@ -1129,6 +1131,10 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
       HIPCHK(hipMemsetAsync(e->bmap, 0, (size_t) bytes, e->stream));
       e->bm_bits = nbits;
       if (chain) e->lg = lookup_geo(nbits);
+      // One shard whose requests stay at home (the 32-bit map is private: smg_engine_run, TorchEngine without exchange) turns
+      // the question round: the candidates ask (5.7 % of the entries instead of the 17.5 % that own a pair at p > k-1-p),
+      // the owners mark the map, the fused look-up answers from the complement's code byte (smg_lookup.hpp, lookup_one)
+      e->flip = (chain && e->bm_cap >= 32 && !getenv("SMG_LOOKUP_SPLIT") && !getenv("SMG_NO_FLIP")) ? 1 : 0;
       // Signatures (2 bytes per entry written by pass 1, so that a look-up bisects 2-byte instead of 8-byte words)
       // pay when most requests are looked up.  With the 32-bit two-bit map of a single-GPU run 1 request in 115
       // survives the filter: 3.9e6 look-ups at 2.5e9 entries, which can afford the k-mer lines of their bucket, while
@@ -1228,7 +1234,7 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
           P1Hot hot;
           hot.keys = a.keys; hot.cnt = a.cnt; hot.n = a.n; hot.code = a.code; hot.sig = a.sig; hot.bstart = e->dir_preset ? (uint32_t *) NULL : e->bstart;
           hot.bmap = a.bmap; hot.b0 = e->dir.b0; hot.nb = e->dir.nb; hot.shifts = (unsigned) e->dir.dsh | ((unsigned) a.sigsh << 6) | (((unsigned) a.bmsh & 31u) << 12)
-                       | ((emit_all ? 1u : 0u) << 18) | ((want_fp ? 1u : 0u) << 19) | ((unsigned) e->lg.nb << 20) | ((unsigned) e->bm2 << 24);
+                       | ((emit_all ? 1u : 0u) << 18) | ((want_fp ? 1u : 0u) << 19) | ((unsigned) e->lg.nb << 20) | ((unsigned) e->bm2 << 24) | ((unsigned) e->flip << 25);
           hot.G = gr; hot.ntiles = ntiles;
           e->h_p1cold->req = e->req; e->h_p1cold->chunk_fill = e->chunk_fill; e->h_p1cold->dbits = e->dbits;
           e->dbits_dirty = true;                                               // until kf_bigfix has cleared the bits again
@@ -1740,6 +1746,7 @@ extern "C" int smg_engine_apply(smg_engine *e, const uint64_t *d_recv, int64_t n
   if (!e->prepared) return fail(errbuf, errlen, SMG_EINVAL, "apply before pass1%s");
   HIPCHK(hipSetDevice(e->device));
   if (!e->fast) return counted_phase_apply(e, (const u64 *) d_recv, nrecv, missing, errbuf, errlen);
+  if (e->flip) return fail(errbuf, errlen, SMG_EINVAL, "pass 1 ran for a single shard (private 32-bit map: its requests are the candidates' questions and stay at home); set the block-map bits for an exchange before pass 1%s");
   return fast_apply(e, (const u64 *) d_recv, nrecv, 1, missing, errbuf, errlen);
 }
 
@@ -1839,6 +1846,7 @@ extern "C" int smg_engine_filter(smg_engine *e, const uint32_t *d_map, int64_t *
   if (!e->prepared) return fail(errbuf, errlen, SMG_EINVAL, "filter before pass1%s");
   if (!filter_ok(e)) return fail(errbuf, errlen, SMG_EINVAL, "the request filter covers the hash proof at k <= 85%s");
   if (!d_map && !e->bm_bits) return fail(errbuf, errlen, SMG_EINVAL, "no block map to filter with%s");
+  if (e->fast && e->flip) return fail(errbuf, errlen, SMG_EINVAL, "pass 1 ran for a single shard (private 32-bit map: its requests are the candidates' questions and stay at home); set the block-map bits for an exchange before pass 1%s");
   HIPCHK(hipSetDevice(e->device));
   int rc = e->filtered ? SMG_OK : fast_filter(e, d_map, errbuf, errlen);
   if (kept) *kept = e->st.nrequests;
@@ -1897,6 +1905,7 @@ extern "C" int smg_engine_route(smg_engine *e, const uint64_t *splitters, int nr
   if (!counts || nranks < 1 || nranks > 16)
     return fail(errbuf, errlen, SMG_EINVAL, "bad route arguments (1..16 ranks)%s");
   if (!e->prepared) return fail(errbuf, errlen, SMG_EINVAL, "route before pass1%s");
+  if (e->fast && e->flip) return fail(errbuf, errlen, SMG_EINVAL, "pass 1 ran for a single shard (private 32-bit map: its requests are the candidates' questions and stay at home); set the block-map bits for an exchange before pass 1%s");
   HIPCHK(hipSetDevice(e->device));
   if (e->st.nrequests > capacity) return fail(errbuf, errlen, SMG_EINVAL, "send buffer too small%s");
   return route_records(e, e->req, e->chunk_fill, e->n_chunks, e->rw, splitters, nranks, d_send, counts, errbuf, errlen);
@@ -1908,6 +1917,7 @@ extern "C" int smg_engine_route_device(smg_engine *e, const uint64_t *splitters,
   if (!d_counts || nranks < 1 || nranks > 16)
     return fail(errbuf, errlen, SMG_EINVAL, "bad route arguments (1..16 ranks)%s");
   if (!e->prepared) return fail(errbuf, errlen, SMG_EINVAL, "route before pass1%s");
+  if (e->fast && e->flip) return fail(errbuf, errlen, SMG_EINVAL, "pass 1 ran for a single shard (private 32-bit map: its requests are the candidates' questions and stay at home); set the block-map bits for an exchange before pass 1%s");
   HIPCHK(hipSetDevice(e->device));
   if (e->st.nrequests > capacity) return fail(errbuf, errlen, SMG_EINVAL, "send buffer too small%s");
   return route_records(e, e->req, e->chunk_fill, e->n_chunks, e->rw, splitters, nranks, d_send, NULL, errbuf, errlen, d_counts);

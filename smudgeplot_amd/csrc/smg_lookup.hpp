@@ -47,6 +47,21 @@ static inline LookupGeo lookup_geo(int fb)
   return g;
 }
 
+// One survivor of the filter.  Round 3: the record is rc(x) of an entry x that owns a pair at p > k-1-p, and the entry it names
+// gets its P flag.  FastArgs.flip (one shard, fused look-ups): the record is rc(y) of a CANDIDATE y -- 5.7 % of the entries
+// send instead of 17.5 % -- and the look-up reads the answer from the complement's own code byte ("do you own a pair at
+// p > k-1-p?", final once kf_bigfix has run); only a yes costs the second look-up, of y itself, whose P flag is set.
+// Either way a record whose k-mer is not in the table refutes the symmetry of the table.
+template <int W> SMG_DEV void lookup_one(const FastArgs &A, const Key<W> &y, FastCtl *__restrict__ ctl)
+{ const int64_t i = sig_find<W>(A, y, false);
+  if (i < 0) { if (ctl->missing == 0) ctl->missing = 1; return; }
+  if (!A.flip) { SET_P(A, i); return; }
+  if (!code_hi((unsigned) A.code[i] & 0x7Fu)) return;
+  const int64_t j = sig_find<W>(A, revcomp<W>(y, A.g.k), false);
+  if (j < 0) { if (ctl->missing == 0) ctl->missing = 1; return; }
+  SET_P(A, j);
+}
+
 // ---- bucket offsets: exclusive scan of <= 1024 counts ----------------------------------------------------------
 __global__ void __launch_bounds__(L_BK)
 kl_scan(const unsigned *__restrict__ ghist, int nbk, u64 *__restrict__ boff /* [nbk + 1] */, u64 *__restrict__ bcur /* [nbk] */,
@@ -300,11 +315,7 @@ kl_probe(FastArgs A, const u64 *__restrict__ recs, const u64 *__restrict__ boff,
         y.w[0] = v.x; y.w[1] = v.y;
       }
     if (!LIST)
-      { if ((unsigned) lane < take)
-          { const int64_t j = sig_find<RW>(A, y, false);
-            if (j < 0) { if (ctl->missing == 0) ctl->missing = 1; }
-            else SET_P(A, j);
-          }
+      { if ((unsigned) lane < take) lookup_one<RW>(A, y, ctl);
       }
     else
       { if (chunk == F_NOCHUNK || used + take > F_CH)
@@ -432,11 +443,7 @@ kl_probe_x(FastArgs A, const u64 *__restrict__ recs, const u64 *__restrict__ bof
       { const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(recs + (size_t) yv * 2);
         y.w[0] = v.x; y.w[1] = v.y;
       }
-    if ((unsigned) lane < take)
-      { const int64_t j = sig_find<RW>(A, y, false);
-        if (j < 0) { if (ctl->missing == 0) ctl->missing = 1; }
-        else SET_P(A, j);
-      }
+    if ((unsigned) lane < take) lookup_one<RW>(A, y, ctl);
     qn -= take; kept += take;
   };
   // The buckets of this workgroup's own XCD first, then -- once those are handed out -- the other classes' in turn: the

@@ -79,6 +79,12 @@
 #define D_BMDENSE 1                        // request filter: candidates are queued (one u16 slot, with the long-block entries) and
 #endif                                     //   marked in the tile's map window by the dense pass behind the tile, a lane each --
                                            //   not by every thread for each of its four entries (0: the round-3 per-entry sequence)
+#ifndef D_ROT
+#define D_ROT    1                         // the dense pass behind a tile (<= ~100 items: one or two waves' worth) starts at another wave
+#endif                                     //   every tile: wave w of every workgroup sits on SIMD w, and the pass always landed on SIMD 0
+#ifndef D_AGG
+#define D_AGG    0                         // 1: a test's result is added to the two entries' accumulators (pairs seen << 16 | delta code)
+#endif                                     //    under the hit mask as EXEC (one v_add per side) instead of by four selects and two adds
 #define D_Q_TAIL 1024u                     // queue word: slot | D_Q_TAIL (detect a pair beyond distance 3) | D_Q_CAND (mark the map)
 #define D_Q_CAND 2048u
 #define D_RD     3                         // distances tested register-to-register; the deferred tail starts at D_RD + 1 (a fourth
@@ -200,7 +206,7 @@ struct P1Hot                              // kernel argument: what every tile to
   uint32_t       *bstart;        // bucket directory: bucket(x) = (hi32(x) >> dsh) - b0
   uint32_t       *bmap;          // candidate block map (or NULL): bit (hi32(x) >> bmsh)
   uint32_t        b0, nb;
-  unsigned        shifts;        // dsh | sigsh << 6 | bmsh << 12 | emit_all << 18 | want_fp << 19 | hbits << 20 | two << 24  (one register)
+  unsigned        shifts;        // dsh | sigsh << 6 | bmsh << 12 | emit_all << 18 | want_fp << 19 | hbits << 20 | two << 24 | flip << 25  (one register)
   GeoR            G;
   int64_t         ntiles;
   SMG_DEV int dsh() const { return (int) (shifts & 63u); }
@@ -210,6 +216,7 @@ struct P1Hot                              // kernel argument: what every tile to
   SMG_DEV bool want_fp() const { return (shifts >> 19 & 1u) != 0; }
   SMG_DEV int hbits() const { return (int) ((shifts >> 20) & 15u); }    // request histogram on the leading hbits bits (0: none)
   SMG_DEV bool two() const { return (shifts >> 24 & 1u) != 0; }         // two-bit block map (BM2_* in smg_fast.hpp)
+  SMG_DEV bool flip() const { return (shifts >> 25 & 1u) != 0; }        // FastArgs.flip: candidates send, owners of a hi pair mark
 };
 
 struct P1Cold                             // in device memory: what only a flush touches (kept out of the register file)
@@ -234,13 +241,51 @@ struct DShared                            // the workgroup's LDS arrays (pointer
   unsigned *hist;                        // requests of this workgroup per bucket (D_HB bins), for the look-up chain's partition
 };
 
+// One one-away test: entry A of the thread against entry A + D (B >= 4: entry B - 4 of the right neighbour lane).
+// D_AGG: the hit is added to both entries' accumulators (pairs seen << 16 | delta code of the pair) by ONE v_add each,
+// executed under the hit mask as EXEC -- instead of four selects and two adds.  (The tests are straight-line code under a
+// full EXEC mask, which is restored to all ones; the increments are literals of the instruction.)
+template <unsigned KA, unsigned KB> SMG_DEV void d_agg_add(unsigned &xa, unsigned &xb, u64 h, u64 hb)
+{ asm volatile("s_mov_b64 exec, %2\n\tv_add_u32 %0, %4, %0\n\ts_mov_b64 exec, %3\n\tv_add_u32 %1, %5, %1\n\ts_mov_b64 exec, -1"
+               : "+v"(xa), "+v"(xb) : "s"(h), "s"(hb), "n"(KA), "n"(KB));
+}
+
+template <typename WT, bool ODD, bool CHECK, int A, int D> SMG_DEV void
+d_one_test(const WT (&sx)[4 + D_RD], const unsigned (&cx)[8], const u64 (&Sm)[4 + D_RD], WT TOPB,
+           unsigned (&code)[4], unsigned (&npair)[4], u64 (&midM)[4])
+{ constexpr int a = A, d = D, b = A + D, eb = b & 3;
+  const WT AA = (WT) 0xAAAAAAAAAAAAAAAAull;
+  const WT dd = sx[a] ^ sx[b];
+  const WT tt = ((dd << 1) | dd) & AA;
+  u64 h = __ballot(d_popc(tt) == 1);
+  h &= Sm[a];
+  if (d >= 2) h &= Sm[a + 1];
+  if (d >= 3) h &= Sm[a + 2];
+  if (CHECK) h &= __ballot(cx[a] + cx[b] <= SMG_SMAX);
+  const u64 hb = b < 4 ? h : h << 1;
+  constexpr unsigned w2c = ODD ? 0u : (unsigned) CODE_W2;
+#if D_AGG
+  d_agg_add<0x10000u | (unsigned) (31 + d) | w2c, 0x10000u | (unsigned) (31 - d) | w2c>(npair[a], npair[eb], h, hb);
+#else
+  npair[a] += d_lane(h) ? 1u : 0u;
+  npair[eb] += d_lane(hb) ? 1u : 0u;
+  code[a] = d_lane(h) ? ((unsigned) (31 + d) | w2c) : code[a];
+  code[eb] = d_lane(hb) ? ((unsigned) (31 - d) | w2c) : code[eb];
+#endif
+  if (ODD)
+    { const u64 hm = h & __ballot(tt >= TOPB);
+      midM[a] |= hm;
+      midM[eb] |= b < 4 ? hm : hm << 1;
+    }
+  D_FENCE_T();
+}
+
 // The 12 one-away tests of a thread (distances 1..3; entries 4..6 are the right neighbour's 0..2), aggregated on the
 // fly.  Straight-line code: every test is a handful of instructions whose result mask dies at once.
 template <typename WT, bool ODD, bool CHECK> SMG_DEV void
 d_tests(const WT (&sx)[4 + D_RD], const unsigned (&cn)[4], const u64 (&Sm)[4 + D_RD], const GeoR &G,
         unsigned (&code)[4], unsigned (&npair)[4], u64 (&midM)[4])
-{ const WT AA = (WT) 0xAAAAAAAAAAAAAAAAull;
-  unsigned cx[8] = { cn[0], cn[1], cn[2], cn[3], 0, 0, 0, 0 };
+{ unsigned cx[8] = { cn[0], cn[1], cn[2], cn[3], 0, 0, 0, 0 };
   if (CHECK)
     {
 #pragma unroll
@@ -250,33 +295,11 @@ d_tests(const WT (&sx)[4 + D_RD], const unsigned (&cn)[4], const u64 (&Sm)[4 + D
   // top one: tt >= TOPB (one more compare per test; keeping "top bases of e and e+1 differ" masks instead costs
   // twelve more scalar registers than the kernel has)
   const WT TOPB = (WT) 2 << (ODD ? G.mshift : 0);
-#pragma unroll
-  for (int a = 3; a >= 0; a--)               // descending: the neighbour's masks (indices 4..6) die first
-    {
-#pragma unroll
-      for (int d = 1; d <= D_RD; d++)
-        { const int b = a + d, eb = b & 3;
-          const WT dd = sx[a] ^ sx[b];
-          const WT tt = ((dd << 1) | dd) & AA;
-          u64 h = __ballot(d_popc(tt) == 1);
-          h &= Sm[a];
-          if (d >= 2) h &= Sm[a + 1];
-          if (d >= 3) h &= Sm[a + 2];
-          if (CHECK) h &= __ballot(cx[a] + cx[b] <= SMG_SMAX);
-          const u64 hb = b < 4 ? h : h << 1;
-          npair[a] += d_lane(h) ? 1u : 0u;
-          npair[eb] += d_lane(hb) ? 1u : 0u;
-          if (ODD)
-            { const u64 hm = h & __ballot(tt >= TOPB);
-              midM[a] |= hm;
-              midM[eb] |= b < 4 ? hm : hm << 1;
-            }
-          const unsigned w2c = ODD ? 0u : (unsigned) CODE_W2;
-          code[a] = d_lane(h) ? ((unsigned) (31 + d) | w2c) : code[a];
-          code[eb] = d_lane(hb) ? ((unsigned) (31 - d) | w2c) : code[eb];
-          D_FENCE_T();
-        }
-    }
+  static_assert(D_RD == 3, "the tests are written out for three register distances");
+  // descending a: the neighbour's masks (indices 4..6) die first
+#define D_T(A_, D_) d_one_test<WT, ODD, CHECK, A_, D_>(sx, cx, Sm, TOPB, code, npair, midM);
+  D_T(3, 1) D_T(3, 2) D_T(3, 3) D_T(2, 1) D_T(2, 2) D_T(2, 3) D_T(1, 1) D_T(1, 2) D_T(1, 3) D_T(0, 1) D_T(0, 2) D_T(0, 3)
+#undef D_T
 }
 
 // queue slots for the requests of a wave: E[e] = lanes whose entry e sends; one LDS atomic per wave
@@ -301,7 +324,7 @@ d_emit(const DShared &S, const u64 (&E)[4], const Key<W> (&rc)[4], const unsigne
 
 // code byte -> "owns a pair at p > k-1-p" (several pairs, or one that is not self-mirrored) / "exactly one pair";
 // CODE_DEFER (0xFF) is neither
-SMG_DEV bool d_code_hi(unsigned c) { return c - 63u < 65u; }                    // 63 .. 127
+SMG_DEV bool d_code_hi(unsigned c) { return code_hi(c); }
 SMG_DEV bool d_code_uq(unsigned c) { return ((c & 63u) - 1u) < 62u && c < 128u; }
 
 // One tile.  INNER tiles lie completely inside the table: vector loads, no bounds checks, no table-end cases.
@@ -497,7 +520,12 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
   u64 uniqM[4], hiM[4];
 #pragma unroll
   for (int e = 0; e < 4; e++)
-    { const u64 mulM = __ballot(npair[e] >= 2u);
+    {
+#if D_AGG
+      code[e] = npair[e] & 0xFFFFu;                 // (the one delta code of a unique entry; CODE_NONE = 0 when there was none)
+      npair[e] >>= 16;
+#endif
+      const u64 mulM = __ballot(npair[e] >= 2u);
       code[e] = d_lane(mulM) ? (unsigned) CODE_MULTI : code[e];
       uniqM[e] = __ballot(npair[e] == 1u);
       if (ODD)
@@ -519,7 +547,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
 #pragma unroll
       for (int e = 0; e < 4; e++)
         { Al[e] = (D_ABL & 32) ? 0ull : Sm[e] & Sm[e + 1] & Sm[e + 2] & Sm[e + 3] & ownM;
-          Cm[e] = wantmap ? uniqM[e] & ownM : 0ull;
+          Cm[e] = wantmap ? (A.flip() ? hiM[e] : uniqM[e]) & ownM : 0ull;
           if (!INNER) Cm[e] &= V[e];
           Qm[e] = Al[e] | Cm[e];
         }
@@ -559,7 +587,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
           u64 *gm64 = reinterpret_cast<u64 *>(A.bmap);
 #pragma unroll
           for (int e = 0; e < 4; e++)
-            { u64 cm = uniqM[e] & ownM;
+            { u64 cm = (A.flip() ? hiM[e] : uniqM[e]) & ownM;
               if (!INNER) cm &= V[e];
               if (cm)
                 { const uint32_t id = (uint32_t) (kw[e] >> 32) >> bmsh;
@@ -576,7 +604,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
         {
 #pragma unroll
           for (int e = 0; e < 4; e++)
-            { u64 cm = uniqM[e] & ownM;
+            { u64 cm = (A.flip() ? hiM[e] : uniqM[e]) & ownM;
               if (!INNER) cm &= V[e];
               if (cm)
                 { const uint32_t id = (uint32_t) (kw[e] >> 32) >> bmsh;
@@ -603,7 +631,9 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
       u64 E0 = 0, E1 = 0, E2 = 0, E3 = 0;
       if (!(D_ABL & 16))
         { const u64 all = A.emit_all() ? ~0ull : 0ull;
-          E0 = (hiM[0] | all) & ownM; E1 = (hiM[1] | all) & ownM; E2 = (hiM[2] | all) & ownM; E3 = (hiM[3] | all) & ownM;
+          const bool fl = A.flip();           // (flip: the candidates send -- a third of the records)
+          E0 = ((fl ? uniqM[0] : hiM[0]) | all) & ownM; E1 = ((fl ? uniqM[1] : hiM[1]) | all) & ownM;
+          E2 = ((fl ? uniqM[2] : hiM[2]) | all) & ownM; E3 = ((fl ? uniqM[3] : hiM[3]) | all) & ownM;
           if (!INNER) { E0 &= V[0]; E1 &= V[1]; E2 &= V[2]; E3 &= V[3]; }
         }
       const unsigned cnt_w = (unsigned) (__popcll(E0) + __popcll(E1) + __popcll(E2) + __popcll(E3));
@@ -796,6 +826,7 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
   DPrefetch<W, d_anch<W, RW>()> pf;
   pf.valid = false;
   int par = 0;
+  unsigned rot = blockIdx.x;                // (which wave starts the dense pass of the next tile)
   const unsigned cls = blockIdx.x % D_NCLS;
   unsigned ticket = (unsigned) __builtin_amdgcn_readfirstlane((int) s_tk0);      // ticket r stands for tile grid + D_NCLS r + cls
   int64_t tnext = (int64_t) gridDim.x + (int64_t) ticket * D_NCLS + cls, tnext2 = tnext + D_NCLS;
@@ -853,7 +884,9 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
       // entry and of its partners in the deferred-entry map (one bit per table entry, so an entry named twice is redone once).
       // D_Q_CAND: a candidate marks its block id in the tile's window of the map (LDS; ids beyond the window -- a sparse
       // table -- straight in the global map).
-      for (unsigned q = t; q < tn && !(D_ABL & 512); q += D_TPB)
+      const unsigned trot = D_ROT ? (unsigned) (t + 64 * (int) (rot & 3u)) & (D_TPB - 1u) : (unsigned) t;
+      rot++;
+      for (unsigned q = trot; q < tn && !(D_ABL & 512); q += D_TPB)
         { const unsigned qw = tailq[q];
           const int sa = (int) (DENSE ? qw & 1023u : qw);
           if (DENSE && (qw & D_Q_CAND))
