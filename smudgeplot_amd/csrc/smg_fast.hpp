@@ -62,8 +62,6 @@ struct FastArgs
   uint32_t       *bmap;          // candidate block map (or NULL): bit (hi32(kmer) >> bmsh) is set when a window block
   int             bmsh;          //   (coarsened to <= 32 leading bits) holds an entry with exactly one suffix-side pair
   int             bm2;           // two-bit map (below): 64-bit map words
-  int             flip;          // single shard, fused look-ups: the CANDIDATES send (a third of the records), the owners of a
-                                 //   pair at p > k-1-p mark the map, and a look-up reads the complement's code byte (smg_lookup.hpp)
 };
 
 // code byte (P flag masked off) -> "owns a pair at p > k-1-p": several pairs, or one that is not self-mirrored
@@ -1209,12 +1207,12 @@ kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, const unsigned *__re
               const unsigned code = make_code(s_all, partner - i, w2);
               A.code[i] = (uint8_t) code;
               if ((code & 63) == CODE_FAR) farp[r] = (uint32_t) partner;
-              if (W <= 2 && A.bmap && (A.flip ? s_hi > 0 : s_all == 1))   // a candidate (flip: an owner of a pair at p > k-1-p): mark its block
+              if (W <= 2 && A.bmap && s_all == 1)             // a candidate: mark its block for the request filter
                 { const uint32_t id = (uint32_t) (A.keys[i * W] >> 32) >> A.bmsh;
                   if (A.bm2) atomicOr(reinterpret_cast<u64 *>(A.bmap) + (id >> 5), bm2_bits(id, (uint32_t) A.keys[i * W]));
                   else atomicOr(&A.bmap[id >> 5], 1u << (id & 31));
                 }
-              if (A.flip ? s_all == 1 : s_hi > 0) slist[atomicAdd(&s_nl, 1u)] = (uint32_t) i;
+              if (s_hi > 0) slist[atomicAdd(&s_nl, 1u)] = (uint32_t) i;
             }
         }
       __syncthreads();

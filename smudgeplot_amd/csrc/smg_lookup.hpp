@@ -47,19 +47,15 @@ static inline LookupGeo lookup_geo(int fb)
   return g;
 }
 
-// One survivor of the filter.  Round 3: the record is rc(x) of an entry x that owns a pair at p > k-1-p, and the entry it names
-// gets its P flag.  FastArgs.flip (one shard, fused look-ups): the record is rc(y) of a CANDIDATE y -- 5.7 % of the entries
-// send instead of 17.5 % -- and the look-up reads the answer from the complement's own code byte ("do you own a pair at
-// p > k-1-p?", final once kf_bigfix has run); only a yes costs the second look-up, of y itself, whose P flag is set.
-// Either way a record whose k-mer is not in the table refutes the symmetry of the table.
+// One survivor of the filter: the record is rc(x) of an entry x that owns a pair at p > k-1-p, the entry it names gets its P
+// flag; a record whose k-mer is not in the table refutes the symmetry of the table.
+// (Tried in round 4: turning the question round on a single shard -- the CANDIDATES send, the owners of a pair at p > k-1-p
+//  mark the map, the look-up reads the answer from the complement's code byte.  Correct, and no gain: on the bench table
+//  18.7 % of the entries are candidates, 17.5 % own such a pair -- the two streams are the same size.)
 template <int W> SMG_DEV void lookup_one(const FastArgs &A, const Key<W> &y, FastCtl *__restrict__ ctl)
 { const int64_t i = sig_find<W>(A, y, false);
   if (i < 0) { if (ctl->missing == 0) ctl->missing = 1; return; }
-  if (!A.flip) { SET_P(A, i); return; }
-  if (!code_hi((unsigned) A.code[i] & 0x7Fu)) return;
-  const int64_t j = sig_find<W>(A, revcomp<W>(y, A.g.k), false);
-  if (j < 0) { if (ctl->missing == 0) ctl->missing = 1; return; }
-  SET_P(A, j);
+  SET_P(A, i);
 }
 
 // ---- bucket offsets: exclusive scan of <= 1024 counts ----------------------------------------------------------

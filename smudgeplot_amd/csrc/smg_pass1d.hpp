@@ -76,9 +76,20 @@
 #define D_TAILB  8                         // tail: distances 4 .. D_TAILB + 3 come in batches of four LDS reads
 #endif
 #ifndef D_BMDENSE
-#define D_BMDENSE 1                        // request filter: candidates are queued (one u16 slot, with the long-block entries) and
+#define D_BMDENSE 0                        // request filter: candidates are queued (one u16 slot, with the long-block entries) and
 #endif                                     //   marked in the tile's map window by the dense pass behind the tile, a lane each --
                                            //   not by every thread for each of its four entries (0: the round-3 per-entry sequence)
+#ifndef D_BMCOMB
+#define D_BMCOMB 0                         // request filter: the map bits of a thread's four entries (consecutive k-mers: one map word, or two
+#endif                                     //   neighbouring ones) are put together in registers and ORed into the tile's window with one or
+                                           //   two LDS atomics per thread, not with one per entry under four wave-level branches
+#ifndef D_DETPAR
+#define D_DETPAR 1                         // the detection behind a tile runs on a lane per (queued entry, distance 4..11) -- all four waves,
+#endif                                     //   one test each -- instead of a lane per queued entry that walks its block (one wave, ~250
+                                           //   instructions while the other three wait at the barrier: 2.6 of the kernel's 11.9 ms)
+#ifndef D_DETW
+#define D_DETW   8                         // distances per queued entry handled that way (a block that goes on beyond is left to kf_bigfix)
+#endif
 #ifndef D_ROT
 #define D_ROT    1                         // the dense pass behind a tile (<= ~100 items: one or two waves' worth) starts at another wave
 #endif                                     //   every tile: wave w of every workgroup sits on SIMD w, and the pass always landed on SIMD 0
@@ -206,7 +217,7 @@ struct P1Hot                              // kernel argument: what every tile to
   uint32_t       *bstart;        // bucket directory: bucket(x) = (hi32(x) >> dsh) - b0
   uint32_t       *bmap;          // candidate block map (or NULL): bit (hi32(x) >> bmsh)
   uint32_t        b0, nb;
-  unsigned        shifts;        // dsh | sigsh << 6 | bmsh << 12 | emit_all << 18 | want_fp << 19 | hbits << 20 | two << 24 | flip << 25  (one register)
+  unsigned        shifts;        // dsh | sigsh << 6 | bmsh << 12 | emit_all << 18 | want_fp << 19 | hbits << 20 | two << 24  (one register)
   GeoR            G;
   int64_t         ntiles;
   SMG_DEV int dsh() const { return (int) (shifts & 63u); }
@@ -216,7 +227,6 @@ struct P1Hot                              // kernel argument: what every tile to
   SMG_DEV bool want_fp() const { return (shifts >> 19 & 1u) != 0; }
   SMG_DEV int hbits() const { return (int) ((shifts >> 20) & 15u); }    // request histogram on the leading hbits bits (0: none)
   SMG_DEV bool two() const { return (shifts >> 24 & 1u) != 0; }         // two-bit block map (BM2_* in smg_fast.hpp)
-  SMG_DEV bool flip() const { return (shifts >> 25 & 1u) != 0; }        // FastArgs.flip: candidates send, owners of a hi pair mark
 };
 
 struct P1Cold                             // in device memory: what only a flush touches (kept out of the register file)
@@ -547,7 +557,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
 #pragma unroll
       for (int e = 0; e < 4; e++)
         { Al[e] = (D_ABL & 32) ? 0ull : Sm[e] & Sm[e + 1] & Sm[e + 2] & Sm[e + 3] & ownM;
-          Cm[e] = wantmap ? (A.flip() ? hiM[e] : uniqM[e]) & ownM : 0ull;
+          Cm[e] = wantmap ? uniqM[e] & ownM : 0ull;
           if (!INNER) Cm[e] &= V[e];
           Qm[e] = Al[e] | Cm[e];
         }
@@ -582,12 +592,62 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
 #pragma unroll
           for (int e = 0; e < 4; e++) kw[e] = S.ent[(slot0 + e) * W];
         }
-      if (A.two())
+      if (D_BMCOMB)
+        { // ids ascend with the entries: the thread's marks fall into the map word of its first entry (`lo`) or into a later
+          // one, which for all but sparse tables is the next word (`hi`).  A lane whose entries span more than that, or
+          // reach past the tile's LDS window, marks in global memory entry by entry (the wave only goes there if one has to).
+          const bool two = A.two();
+          uint32_t id[4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) id[e] = (uint32_t) (kw[e] >> 32) >> bmsh;
+          const uint32_t w0 = id[0] >> 5;
+          const bool ok = (id[3] >> 5) - w0 <= 1u && id[3] - bmbase < (uint32_t) D_BMF && id[0] >= bmbase;
+          uint32_t lo0 = 0, lo1 = 0, hi0 = 0, hi1 = 0;      // (lo0, lo1) = the two halves of the first word's 64 bits (one-bit map: lo0 only)
+          bool any = false;
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+            { u64 cm = uniqM[e] & ownM;
+              if (!INNER) cm &= V[e];
+              const bool c = d_lane(cm);
+              any = any || c;
+              const uint32_t b0 = 1u << (id[e] & 31u), b1 = two ? 1u << bm2_pos((uint32_t) kw[e]) : 0u;
+              const bool first = (id[e] >> 5) == w0;
+              lo0 |= (c && first) ? b0 : 0u;  lo1 |= (c && first) ? b1 : 0u;
+              hi0 |= (c && !first) ? b0 : 0u; hi1 |= (c && !first) ? b1 : 0u;
+            }
+          const uint32_t rw = w0 - (bmbase >> 5);            // word of the tile's window
+          if (ok)
+            { if (two)
+                { u64 *bm64 = reinterpret_cast<u64 *>(S.bm);
+                  if (lo0) atomicOr(&bm64[rw], (u64) lo0 | ((u64) lo1 << 32));
+                  if (hi0) atomicOr(&bm64[rw + 1], (u64) hi0 | ((u64) hi1 << 32));
+                }
+              else
+                { if (lo0) atomicOr(&S.bm[rw], lo0);
+                  if (hi0) atomicOr(&S.bm[rw + 1], hi0);
+                }
+            }
+          if (__ballot(!ok && any))
+            { if (!ok)
+                {
+#pragma unroll
+                  for (int e = 0; e < 4; e++)
+                    { u64 cm = uniqM[e] & ownM;
+                      if (!INNER) cm &= V[e];
+                      if (d_lane(cm))
+                        { if (two) atomicOr(&reinterpret_cast<u64 *>(A.bmap)[id[e] >> 5], bm2_bits(id[e], (uint32_t) kw[e]));
+                          else     atomicOr(&A.bmap[id[e] >> 5], 1u << (id[e] & 31u));
+                        }
+                    }
+                }
+            }
+        }
+      else if (A.two())
         { u64 *bm64 = reinterpret_cast<u64 *>(S.bm);
           u64 *gm64 = reinterpret_cast<u64 *>(A.bmap);
 #pragma unroll
           for (int e = 0; e < 4; e++)
-            { u64 cm = (A.flip() ? hiM[e] : uniqM[e]) & ownM;
+            { u64 cm = uniqM[e] & ownM;
               if (!INNER) cm &= V[e];
               if (cm)
                 { const uint32_t id = (uint32_t) (kw[e] >> 32) >> bmsh;
@@ -604,7 +664,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
         {
 #pragma unroll
           for (int e = 0; e < 4; e++)
-            { u64 cm = (A.flip() ? hiM[e] : uniqM[e]) & ownM;
+            { u64 cm = uniqM[e] & ownM;
               if (!INNER) cm &= V[e];
               if (cm)
                 { const uint32_t id = (uint32_t) (kw[e] >> 32) >> bmsh;
@@ -631,9 +691,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
       u64 E0 = 0, E1 = 0, E2 = 0, E3 = 0;
       if (!(D_ABL & 16))
         { const u64 all = A.emit_all() ? ~0ull : 0ull;
-          const bool fl = A.flip();           // (flip: the candidates send -- a third of the records)
-          E0 = ((fl ? uniqM[0] : hiM[0]) | all) & ownM; E1 = ((fl ? uniqM[1] : hiM[1]) | all) & ownM;
-          E2 = ((fl ? uniqM[2] : hiM[2]) | all) & ownM; E3 = ((fl ? uniqM[3] : hiM[3]) | all) & ownM;
+          E0 = (hiM[0] | all) & ownM; E1 = (hiM[1] | all) & ownM; E2 = (hiM[2] | all) & ownM; E3 = (hiM[3] | all) & ownM;
           if (!INNER) { E0 &= V[0]; E1 &= V[1]; E2 &= V[2]; E3 &= V[3]; }
         }
       const unsigned cnt_w = (unsigned) (__popcll(E0) + __popcll(E1) + __popcll(E2) + __popcll(E3));
@@ -757,6 +815,48 @@ d_detect(const P1Hot &A, const u64 *ent, const uint16_t *lcn, int64_t g0, int sa
       const WT dd = sfa ^ sfb;
       const WT tt = ((dd << 1) | dd) & (WT) 0xAAAAAAAAAAAAAAAAull;
       if (d_popc(tt) == 1 && ca + cb <= SMG_SMAX) hm |= 1u << (d - D0);
+    }
+}
+
+// ---- the same question, one distance per lane (D_DETPAR) ---------------------------------------------------------------
+// Lane (q, j) tests the queued entry in slot sa = tailq[q] against the entry d = D_RD + 1 + j slots on: same window block
+// (the table is sorted: equal prefixes at both ends mean equal prefixes in between) and one base apart -> both get their
+// bit in the deferred-entry map.  A block that goes on past the last distance (more than twelve entries: one entry in 1e5
+// on the bench table) is left to kf_bigfix altogether: the lane of the last distance marks its entry and the one a slot
+// further -- every member of a pair that far apart is in one of these two roles.
+template <int W, bool ODD, bool KF> SMG_DEV void
+d_detect_one(const P1Hot &A, const u64 *ent, const uint16_t *lcn, int64_t g0, int sa, int j, const P1Cold *__restrict__ cold)
+{ typedef typename DWord<W>::type WT;
+  const GeoR &G = A.G;
+  const int64_t n = A.n;
+  WT pa, sfa;
+  d_unpack<W, KF>(lds_key<W>(ent, sa), G, pa, sfa);
+  const int64_t it = g0 + sa;
+  const int d = D_RD + 1 + j;
+  int sb = sa + d;
+  if (g0 + sb >= n) return;
+  WT pb, sfb; unsigned cb;
+  if (sb < D_SLOTS) { d_unpack<W, KF>(lds_key<W>(ent, sb), G, pb, sfb); cb = lcn[sb]; }
+  else              { d_unpack<W, KF>(load_key<W>(A.keys, g0 + sb), G, pb, sfb); cb = A.cnt[g0 + sb]; }
+  if (pb != pa) return;
+  const WT dd = sfa ^ sfb;
+  const WT tt = ((dd << 1) | dd) & (WT) 0xAAAAAAAAAAAAAAAAull;
+  if (d_popc(tt) == 1 && (unsigned) lcn[sa] + cb <= SMG_SMAX)
+    { const int64_t jb = g0 + sb;
+      uint32_t *db = cold->dbits;
+      atomicOr(&db[it >> 5], 1u << (it & 31));
+      atomicOr(&db[jb >> 5], 1u << (jb & 31));
+    }
+  if (j == D_DETW - 1 && g0 + sb + 1 < n)            // does the block go on past the last distance?
+    { sb++;
+      if (sb < D_SLOTS) d_unpack<W, KF>(lds_key<W>(ent, sb), G, pb, sfb);
+      else              d_unpack<W, KF>(load_key<W>(A.keys, g0 + sb), G, pb, sfb);
+      if (pb == pa)
+        { const int64_t jb = g0 + sb;
+          uint32_t *db = cold->dbits;
+          atomicOr(&db[it >> 5], 1u << (it & 31));
+          atomicOr(&db[jb >> 5], 1u << (jb & 31));
+        }
     }
 }
 
@@ -886,6 +986,11 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
       // table -- straight in the global map).
       const unsigned trot = D_ROT ? (unsigned) (t + 64 * (int) (rot & 3u)) & (D_TPB - 1u) : (unsigned) t;
       rot++;
+      if (D_DETPAR && !DENSE)
+        { for (unsigned it = (unsigned) t; it < tn * D_DETW && !(D_ABL & 512); it += D_TPB)
+            d_detect_one<W, ODD, KF>(A, ent, lcn, g0, (int) tailq[it / D_DETW], (int) (it % D_DETW), cold);
+        }
+      else
       for (unsigned q = trot; q < tn && !(D_ABL & 512); q += D_TPB)
         { const unsigned qw = tailq[q];
           const int sa = (int) (DENSE ? qw & 1023u : qw);

@@ -106,6 +106,12 @@ class TorchEngine:
     def merge_maps(self, parts, width, wlo, wlen, full):
         self.e.merge_maps(parts.data_ptr(), width, wlo, wlen, full.data_ptr())
 
+    def run_single(self, plot, symcheck):
+        """the whole computation on this one shard in ONE call of the C ABI (smg_engine_run): pass 1, look-ups, symmetry
+        proof, pass 2 -- and, when the proof fails, the general all-positions path.  On a table the engine has run before
+        nothing is read back between the launches (one host wait per run)."""
+        return self.e.run(plot.data_ptr(), symcheck)
+
     def run_general(self, k, keys, counts, plot):
         """the assumption-free all-positions path on a whole table (what one GPU does when the proof fails)"""
         self.e.bind(k, counts.numel(), keys.data_ptr(), counts.data_ptr())
@@ -207,6 +213,17 @@ def _general_on_rank0(k, keys, counts, sizes, eng, plot, group, rank, world, wor
         plot.zero_()
     if world > 1:
         dist.broadcast(plot, src=0, group=group)
+
+
+def _scratch(eng, name: str, nwords: int, dev) -> torch.Tensor:
+    """an int64 device buffer of at least `nwords` words that belongs to the engine object and is reused by every step"""
+    pool = getattr(eng, "_scratch_pool", None)
+    if pool is None:
+        pool = eng._scratch_pool = {}
+    t = pool.get(name)
+    if t is None or t.numel() < nwords or t.device != dev:
+        t = pool[name] = torch.empty(int(nwords * 1.25) + 16, dtype=torch.int64, device=dev)
+    return t[:nwords]
 
 
 def symm_splitters(hist: np.ndarray, bits: int, world: int, words: int) -> np.ndarray:
@@ -346,6 +363,19 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
     else:
         splitters, sizes = np.zeros(0, np.uint64), [n]
 
+    if not exchange and hasattr(eng, "run_single"):
+        # one shard, nobody to talk to: the engine runs the table in one call (and takes the general path by itself when
+        # the symmetry proof fails -- the reference answers for any sorted table)
+        plot = torch.empty(PLOT_CELLS, dtype=torch.int64, device=dev)
+        st = eng.run_single(plot, symcheck)
+        if st["path"] != 1 and not fallback:
+            raise NotSymmetric("table is not closed under reverse complement with equal counts; "
+                               "run the single-GPU engine (general path) or condition the table")
+        if st["path"] != 1:
+            eng._splitter_cache = None
+        st.update(rank=rank, world=world, shard_nels=n, sent=0, received=st.get("nemitted", 0), engine=eng)
+        return plot, st
+
     eng.pass1(symcheck, exchange, world)
     rw = eng.record_words()
     nreq = eng.nreq()
@@ -372,17 +402,18 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
             # ranges of neighbours share their boundary word: the merge ORs them (one launch)
             eng.merge_maps(parts, width, wlo, wlen, full)
             nreq = eng.filter(full)
-        send = torch.empty(max(nreq, 1) * rw, dtype=torch.int64, device=dev)
+        # (the exchange buffers live as long as the engine and only ever grow: a step allocates nothing)
+        send = _scratch(eng, "send", max(nreq, 1) * rw, dev)
         # grouped on the device; the per-destination totals go from the router into the count exchange without a host
         # round trip, and the host reads what it sends and what it receives in ONE copy
-        both = torch.empty(2 * world, dtype=torch.int64, device=dev)
+        both = _scratch(eng, "both", 2 * world, dev)
         sc, rcnt = both[:world], both[world:]
         eng.route(splitters, world, send, counts_out=sc)
         dist.all_to_all_single(rcnt, sc, group=group)
         hb = both.cpu().tolist()
         send_counts, recv_counts = [int(v) for v in hb[:world]], [int(v) for v in hb[world:]]
         nrecv = sum(recv_counts)
-        recv = torch.empty(max(nrecv, 1) * rw, dtype=torch.int64, device=dev)
+        recv = _scratch(eng, "recv", max(nrecv, 1) * rw, dev)
         dist.all_to_all_single(recv[: nrecv * rw], send[: nreq * rw],
                                output_split_sizes=[c * rw for c in recv_counts],
                                input_split_sizes=[c * rw for c in send_counts], group=group)
@@ -397,14 +428,15 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
     # a SUM all_reduce cannot combine -- so every rank writes its 128-bit residue into ITS OWN two words (zeros
     # elsewhere), the sum hands every rank all residues, and the XOR over the ranks is taken on the host.
     nslot = world if exchange else 1
-    buf = torch.zeros(PLOT_CELLS + 1 + 2 * nslot, dtype=torch.int64, device=dev)
+    buf = _scratch(eng, "plot", PLOT_CELLS + 1 + 2 * nslot, dev)     # (pass 2 clears the plot itself; the proof words below)
+    buf[PLOT_CELLS:].zero_()
     plot = buf[:PLOT_CELLS]
     eng.pass2(plot)
     me = rank if exchange else 0
     if missing is None:
         # the engine writes (missing, residue word 0, residue word 1) on the device, in stream order: no host round
         # trip between the look-ups and the all_reduce.  Rank r's words go to [0] (summed) and to ITS slot.
-        tmp = torch.zeros(3, dtype=torch.int64, device=dev)
+        tmp = _scratch(eng, "proof", 3, dev)
         eng.proof_into(tmp)
         buf[PLOT_CELLS] = tmp[0]
         buf[PLOT_CELLS + 1 + 2 * me: PLOT_CELLS + 3 + 2 * me] = tmp[1:3]
@@ -431,4 +463,4 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
     st.update(rank=rank, world=world, shard_nels=n, sent=nreq if exchange else 0, received=nrecv, engine=eng)
     if not symmetric:
         st["path"] = 2
-    return plot, st
+    return plot.clone(), st           # (the reduction buffer belongs to the engine: the caller gets its own 4 MB)

@@ -293,10 +293,7 @@ def test_request_filter_changes_nothing_but_the_request_count(k, m, seed, monkey
     packed, cnt = synth.adversarial_table(k, m, 4, seed, low_complexity=40, dense=1)
     want = brute.hetmers_plot(packed, cnt, k) if m * k <= 400000 else None
     tab = table_from(packed, cnt, k)
-    plot_d, st_d = engine.hetmers_run(tab, symcheck="hash")      # the default: one shard lets the candidates send (k <= 64)
-    monkeypatch.setenv("SMG_NO_FLIP", "1")                 # the counts below compare like with like: the owners of a hi pair send
     plot_f, st_f = engine.hetmers_run(tab, symcheck="hash")
-    assert np.array_equal(plot_d, plot_f) and st_d["path"] == st_f["path"] == 1
     monkeypatch.setenv("SMG_FILTER_SORT_MIN", "1")         # long lists are bucketed on their leading 8 bits first
     plot_s, st_s = engine.hetmers_run(tab, symcheck="hash")
     assert np.array_equal(plot_f, plot_s) and st_s["nrequests"] == st_f["nrequests"]
@@ -1074,8 +1071,7 @@ def _brute_cached(k, m, seed, packed, cnt):
                                  {"SMG_BM_BITS": "24", "SMG_ONE_BIT_MAP": "1"}, {"SMG_DIR_PER": "8"}, {"SMG_DIR_PER": "200"},
                                  {"SMG_NO_FILTER": "1"}, {"SMG_PROBE_X": "1"}, {"SMG_PROBE_X": "1", "SMG_ONE_BIT_MAP": "1"},
                                  {"SMG_PROBE_X": "1", "SMG_PX_PART": "512", "SMG_PX_WGS": "8"}, {"SMG_PROBE_X": "0"},
-                                 {"SMG_PROBE_X": "1", "SMG_PX_ONE_XCC": "1"}, {"SMG_NO_FLIP": "1"}, {"SMG_NO_FLIP": "1", "SMG_PROBE_X": "1"},
-                                 {"SMG_NO_FLIP": "1", "SMG_BM_BITS": "30", "SMG_SIG": "1"}, {"SMG_NO_INDEX_DIR": "1"}])
+                                 {"SMG_PROBE_X": "1", "SMG_PX_ONE_XCC": "1"}, {"SMG_NO_INDEX_DIR": "1"}])
 @pytest.mark.parametrize("k,m,seed", [(31, 60000, 21), (27, 40000, 22), (24, 30000, 23)])
 def test_every_variant_of_the_lookup_chain_gives_the_same_plot(k, m, seed, env, monkeypatch):
     """the A/B switches of the look-up chain: two-bit / one-bit map, round-1 chain, survivor list
@@ -1088,11 +1084,7 @@ def test_every_variant_of_the_lookup_chain_gives_the_same_plot(k, m, seed, env, 
         monkeypatch.setenv(name, val)
     plot, st = engine.hetmers_run(tab, symcheck="hash")
     assert np.array_equal(plot, base), env
-    assert st["path"] == st0["path"] == 1
-    # (one shard by default lets the CANDIDATES send; the switches that take the fused look-ups away, and SMG_NO_FLIP, put
-    #  the owners of a pair at p > k-1-p back in that role: another number of records, the same plot)
-    if not any(v in env for v in ("SMG_NO_FLIP", "SMG_OLD_LOOKUP", "SMG_LOOKUP_SPLIT", "SMG_NO_FILTER")):
-        assert st["nemitted"] == st0["nemitted"]
+    assert st["path"] == st0["path"] == 1 and st["nemitted"] == st0["nemitted"]
     if "SMG_NO_FILTER" in env:
         assert st["nrequests"] == st["nemitted"]
     elif env == {"SMG_ONE_BIT_MAP": "1"}:

@@ -68,7 +68,7 @@ def _run(world, k, keys, cnt, cuts, symcheck, drop=None, fallback=True, own_spli
 
 
 @pytest.mark.parametrize("world,symcheck,k", [(2, "hash", 31), (2, "exact", 31), (3, "hash", 24), (2, "hash", 12),
-                                                (3, "hash", 13)])
+                                                (3, "hash", 13), (8, "hash", 31), (8, "hash", 16)])
 def test_prefix_sharded_matches_oracle(world, symcheck, k):
     keys, cnt = synth.diploid_table_u64(4000, k=k, seed=40 + world, het_frac=0.4, cov=30, L=5)
     want = brute.hetmers_plot(ktab.u64_to_packed(keys, k), cnt, k)
