@@ -578,6 +578,7 @@ struct smg_engine
   bool         have_ixdir;                   //   ... handed over with the current table (smg_engine_set_prefix_index); gone when the table changes
   bool         dir_preset;                   //   the current run looks up through ixdir: pass 1 writes no directory
   bool         have_ends;  u64 end_first, end_last;     // leading words of the first and the last entry of the bound table (read once)
+  bool         fused_last;   // the look-ups of the last run were the fused ones (kl_part -> kl_probe on the engine's own map)
   bool         spec_ok;      // the last smg_engine_run on this bound table went through the hash-proof chain: its counts size the next one
   int64_t      spec_nreq, spec_nbig;   //   requests pass 1 (+ kf_bigfix) emitted, entries deferred to kf_bigfix (functions of the table)
   u64         *req;    int64_t req_cap;      // bytes
@@ -1633,10 +1634,12 @@ static int compact_chunks(smg_engine *e, int64_t nreq, char *errbuf, size_t errl
 static int fast_apply(smg_engine *e, const u64 *flat, int64_t nflat, int check_count, int64_t *missing,
                       char *errbuf, size_t errlen, bool spec = false)
 { int rc = SMG_OK;
+  e->fused_last = false;
   if (!flat && e->lg.nb && e->bm_bits && !e->filtered && !getenv("SMG_LOOKUP_SPLIT"))
     { // own requests, own map: partition, then filter and look-ups in one kernel (no survivor list, no sort)
       if (e->n_chunks == 0 || e->st.nrequests == 0) { if (missing) *missing = 0; return SMG_OK; }
       if (!e->presorted && (rc = filter_presort(e, errbuf, errlen))) return rc;
+      e->fused_last = true;
       hipEvent_t mid = e->ev[10];
       hipEventRecord(mid, e->stream);
       if ((rc = lookup_probe(e, e->bmap, false, 0u, errbuf, errlen))) return rc;
@@ -1966,7 +1969,7 @@ static int run_speculative(smg_engine *e, int64_t *d_plot, char *errbuf, size_t 
   if ((rc = fast_pass1(e, 0, 0, 1, errbuf, errlen, true))) return rc;
   const unsigned grid = e->p1grid;
   if ((rc = fast_apply(e, NULL, 0, 0, NULL, errbuf, errlen, true))) return rc;
-  if (!e->filtered) return SMG_ERETRY;                       // (not the fused chain after all)
+  if (!e->fused_last) return SMG_ERETRY;                     // (not the fused chain after all: nothing to take for granted)
   if ((rc = fast_pass2(e, d_plot, false, errbuf, errlen))) return rc;
   HIPCHK(hipMemsetAsync(&e->ctrl->plot_sum, 0, sizeof(u64), e->stream));
   hipLaunchKernelGGL(kf_plot_sum, dim3(64), dim3(1024), 0, e->stream, (const u64 *) d_plot, &e->ctrl->plot_sum);
@@ -2034,7 +2037,7 @@ extern "C" int smg_engine_run(smg_engine *e, int symcheck, int64_t *d_plot, smg_
         symmetric = e->fp[0] == e->fp[2] && e->fp[1] == e->fp[3];
       if (symmetric && (rc = fast_pass2(e, d_plot, true, errbuf, errlen))) return rc;
       // what the next run on this table may take for granted (hash proof through the fused look-up chain only)
-      if (symmetric && !exact && e->lg.nb && e->filtered && e->W <= 2 && !e->h_p1cold->times)
+      if (symmetric && !exact && e->lg.nb && e->fused_last && e->W <= 2 && !e->h_p1cold->times)
         { e->spec_ok = true; e->spec_nreq = e->st.nemitted; e->spec_nbig = e->st.nbig; }
     }
   else if (symcheck != SMG_SYM_NONE)

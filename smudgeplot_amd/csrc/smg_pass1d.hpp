@@ -75,29 +75,6 @@
 #ifndef D_TAILB
 #define D_TAILB  8                         // tail: distances 4 .. D_TAILB + 3 come in batches of four LDS reads
 #endif
-#ifndef D_BMDENSE
-#define D_BMDENSE 0                        // request filter: candidates are queued (one u16 slot, with the long-block entries) and
-#endif                                     //   marked in the tile's map window by the dense pass behind the tile, a lane each --
-                                           //   not by every thread for each of its four entries (0: the round-3 per-entry sequence)
-#ifndef D_BMCOMB
-#define D_BMCOMB 0                         // request filter: the map bits of a thread's four entries (consecutive k-mers: one map word, or two
-#endif                                     //   neighbouring ones) are put together in registers and ORed into the tile's window with one or
-                                           //   two LDS atomics per thread, not with one per entry under four wave-level branches
-#ifndef D_DETPAR
-#define D_DETPAR 1                         // the detection behind a tile runs on a lane per (queued entry, distance 4..11) -- all four waves,
-#endif                                     //   one test each -- instead of a lane per queued entry that walks its block (one wave, ~250
-                                           //   instructions while the other three wait at the barrier: 2.6 of the kernel's 11.9 ms)
-#ifndef D_DETW
-#define D_DETW   8                         // distances per queued entry handled that way (a block that goes on beyond is left to kf_bigfix)
-#endif
-#ifndef D_ROT
-#define D_ROT    1                         // the dense pass behind a tile (<= ~100 items: one or two waves' worth) starts at another wave
-#endif                                     //   every tile: wave w of every workgroup sits on SIMD w, and the pass always landed on SIMD 0
-#ifndef D_AGG
-#define D_AGG    0                         // 1: a test's result is added to the two entries' accumulators (pairs seen << 16 | delta code)
-#endif                                     //    under the hit mask as EXEC (one v_add per side) instead of by four selects and two adds
-#define D_Q_TAIL 1024u                     // queue word: slot | D_Q_TAIL (detect a pair beyond distance 3) | D_Q_CAND (mark the map)
-#define D_Q_CAND 2048u
 #define D_RD     3                         // distances tested register-to-register; the deferred tail starts at D_RD + 1 (a fourth
                                            //   distance in registers: ten vector registers spill, 16.4 instead of 14.7 ms)
 #ifndef D_ABL
@@ -129,7 +106,7 @@ SMG_DEV bool d_lane(u64 mask) { return __builtin_amdgcn_inverse_ballot_w64(mask)
 // One lane of a wave adds to an LDS counter and the wave takes the old value.  Written out: for `if (lane == 0) atomicAdd(..)`
 // the compiler's atomic optimiser cannot see that one lane is active and builds its general sequence around the atomic
 // (two mbcnt, a compare, a saveexec, a scalar population count and multiply, a multiply-add to hand every lane its share:
-// ~12 instructions for each of the three wave-aggregated atomics of a tile).  LDS operations return in order and the wait
+// ~12 instructions for each of the two wave-aggregated atomics of a tile).  LDS operations return in order and the wait
 // is for all of them, so the compiler's own counting stays valid.
 SMG_DEV unsigned d_wave_add(unsigned *ctr, unsigned v, int lane)
 { unsigned old = 0;
@@ -177,11 +154,11 @@ template <int W> SMG_DEV void mix_hash(const Key<W> &x, unsigned cnt, u64 &ha, u
 }
 
 // the 4 entries of a thread, loaded one tile ahead
-template <int W, bool ANCH> struct DPrefetch
+template <int W> struct DPrefetch
 { Key<W> k[4]; ushort4 c; bool valid;
   uint32_t anchor;               // leading 32 bits of the tile's first owned entry (the base of the tile's block-map window)
   SMG_DEV void load(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, int64_t i0, int64_t ianchor)
-  { anchor = ANCH ? (uint32_t) (keys[ianchor * W] >> 32) : 0u;
+  { anchor = (uint32_t) (keys[ianchor * W] >> 32);
     if constexpr (W == 1)
       { const ulonglong2 v0 = *reinterpret_cast<const ulonglong2 *>(keys + i0);
         const ulonglong2 v1 = *reinterpret_cast<const ulonglong2 *>(keys + i0 + 2);
@@ -202,8 +179,7 @@ template <int W, bool ANCH> struct DPrefetch
 #pragma unroll
       for (int w = 0; w < W; w++) asm volatile("" : "+v"(k[e].w[w]));
     unsigned c01 = (unsigned) c.x | ((unsigned) c.y << 16), c23 = (unsigned) c.z | ((unsigned) c.w << 16);
-    if (ANCH) asm volatile("" : "+v"(c01), "+v"(c23), "+v"(anchor));
-    else      asm volatile("" : "+v"(c01), "+v"(c23));
+    asm volatile("" : "+v"(c01), "+v"(c23), "+v"(anchor));
     c.x = (unsigned short) c01; c.y = (unsigned short) (c01 >> 16); c.z = (unsigned short) c23; c.w = (unsigned short) (c23 >> 16);
   }
 };
@@ -214,7 +190,7 @@ struct P1Hot                              // kernel argument: what every tile to
   int64_t         n;
   uint8_t        *code;
   uint16_t       *sig;           // sig[i] = (uint16_t) (keys[i] >> sigsh): the 16 k-mer bits below the directory's bucket bits
-  uint32_t       *bstart;        // bucket directory: bucket(x) = (hi32(x) >> dsh) - b0
+  uint32_t       *bstart;        // bucket directory: bucket(x) = (hi32(x) >> dsh) - b0; NULL: the table came with its prefix index, none is built
   uint32_t       *bmap;          // candidate block map (or NULL): bit (hi32(x) >> bmsh)
   uint32_t        b0, nb;
   unsigned        shifts;        // dsh | sigsh << 6 | bmsh << 12 | emit_all << 18 | want_fp << 19 | hbits << 20 | two << 24  (one register)
@@ -251,51 +227,13 @@ struct DShared                            // the workgroup's LDS arrays (pointer
   unsigned *hist;                        // requests of this workgroup per bucket (D_HB bins), for the look-up chain's partition
 };
 
-// One one-away test: entry A of the thread against entry A + D (B >= 4: entry B - 4 of the right neighbour lane).
-// D_AGG: the hit is added to both entries' accumulators (pairs seen << 16 | delta code of the pair) by ONE v_add each,
-// executed under the hit mask as EXEC -- instead of four selects and two adds.  (The tests are straight-line code under a
-// full EXEC mask, which is restored to all ones; the increments are literals of the instruction.)
-template <unsigned KA, unsigned KB> SMG_DEV void d_agg_add(unsigned &xa, unsigned &xb, u64 h, u64 hb)
-{ asm volatile("s_mov_b64 exec, %2\n\tv_add_u32 %0, %4, %0\n\ts_mov_b64 exec, %3\n\tv_add_u32 %1, %5, %1\n\ts_mov_b64 exec, -1"
-               : "+v"(xa), "+v"(xb) : "s"(h), "s"(hb), "n"(KA), "n"(KB));
-}
-
-template <typename WT, bool ODD, bool CHECK, int A, int D> SMG_DEV void
-d_one_test(const WT (&sx)[4 + D_RD], const unsigned (&cx)[8], const u64 (&Sm)[4 + D_RD], WT TOPB,
-           unsigned (&code)[4], unsigned (&npair)[4], u64 (&midM)[4])
-{ constexpr int a = A, d = D, b = A + D, eb = b & 3;
-  const WT AA = (WT) 0xAAAAAAAAAAAAAAAAull;
-  const WT dd = sx[a] ^ sx[b];
-  const WT tt = ((dd << 1) | dd) & AA;
-  u64 h = __ballot(d_popc(tt) == 1);
-  h &= Sm[a];
-  if (d >= 2) h &= Sm[a + 1];
-  if (d >= 3) h &= Sm[a + 2];
-  if (CHECK) h &= __ballot(cx[a] + cx[b] <= SMG_SMAX);
-  const u64 hb = b < 4 ? h : h << 1;
-  constexpr unsigned w2c = ODD ? 0u : (unsigned) CODE_W2;
-#if D_AGG
-  d_agg_add<0x10000u | (unsigned) (31 + d) | w2c, 0x10000u | (unsigned) (31 - d) | w2c>(npair[a], npair[eb], h, hb);
-#else
-  npair[a] += d_lane(h) ? 1u : 0u;
-  npair[eb] += d_lane(hb) ? 1u : 0u;
-  code[a] = d_lane(h) ? ((unsigned) (31 + d) | w2c) : code[a];
-  code[eb] = d_lane(hb) ? ((unsigned) (31 - d) | w2c) : code[eb];
-#endif
-  if (ODD)
-    { const u64 hm = h & __ballot(tt >= TOPB);
-      midM[a] |= hm;
-      midM[eb] |= b < 4 ? hm : hm << 1;
-    }
-  D_FENCE_T();
-}
-
 // The 12 one-away tests of a thread (distances 1..3; entries 4..6 are the right neighbour's 0..2), aggregated on the
 // fly.  Straight-line code: every test is a handful of instructions whose result mask dies at once.
 template <typename WT, bool ODD, bool CHECK> SMG_DEV void
 d_tests(const WT (&sx)[4 + D_RD], const unsigned (&cn)[4], const u64 (&Sm)[4 + D_RD], const GeoR &G,
         unsigned (&code)[4], unsigned (&npair)[4], u64 (&midM)[4])
-{ unsigned cx[8] = { cn[0], cn[1], cn[2], cn[3], 0, 0, 0, 0 };
+{ const WT AA = (WT) 0xAAAAAAAAAAAAAAAAull;
+  unsigned cx[8] = { cn[0], cn[1], cn[2], cn[3], 0, 0, 0, 0 };
   if (CHECK)
     {
 #pragma unroll
@@ -305,11 +243,33 @@ d_tests(const WT (&sx)[4 + D_RD], const unsigned (&cn)[4], const u64 (&Sm)[4 + D
   // top one: tt >= TOPB (one more compare per test; keeping "top bases of e and e+1 differ" masks instead costs
   // twelve more scalar registers than the kernel has)
   const WT TOPB = (WT) 2 << (ODD ? G.mshift : 0);
-  static_assert(D_RD == 3, "the tests are written out for three register distances");
-  // descending a: the neighbour's masks (indices 4..6) die first
-#define D_T(A_, D_) d_one_test<WT, ODD, CHECK, A_, D_>(sx, cx, Sm, TOPB, code, npair, midM);
-  D_T(3, 1) D_T(3, 2) D_T(3, 3) D_T(2, 1) D_T(2, 2) D_T(2, 3) D_T(1, 1) D_T(1, 2) D_T(1, 3) D_T(0, 1) D_T(0, 2) D_T(0, 3)
-#undef D_T
+#pragma unroll
+  for (int a = 3; a >= 0; a--)               // descending: the neighbour's masks (indices 4..6) die first
+    {
+#pragma unroll
+      for (int d = 1; d <= D_RD; d++)
+        { const int b = a + d, eb = b & 3;
+          const WT dd = sx[a] ^ sx[b];
+          const WT tt = ((dd << 1) | dd) & AA;
+          u64 h = __ballot(d_popc(tt) == 1);
+          h &= Sm[a];
+          if (d >= 2) h &= Sm[a + 1];
+          if (d >= 3) h &= Sm[a + 2];
+          if (CHECK) h &= __ballot(cx[a] + cx[b] <= SMG_SMAX);
+          const u64 hb = b < 4 ? h : h << 1;
+          npair[a] += d_lane(h) ? 1u : 0u;
+          npair[eb] += d_lane(hb) ? 1u : 0u;
+          if (ODD)
+            { const u64 hm = h & __ballot(tt >= TOPB);
+              midM[a] |= hm;
+              midM[eb] |= b < 4 ? hm : hm << 1;
+            }
+          const unsigned w2c = ODD ? 0u : (unsigned) CODE_W2;
+          code[a] = d_lane(h) ? ((unsigned) (31 + d) | w2c) : code[a];
+          code[eb] = d_lane(hb) ? ((unsigned) (31 - d) | w2c) : code[eb];
+          D_FENCE_T();
+        }
+    }
 }
 
 // queue slots for the requests of a wave: E[e] = lanes whose entry e sends; one LDS atomic per wave
@@ -334,16 +294,13 @@ d_emit(const DShared &S, const u64 (&E)[4], const Key<W> (&rc)[4], const unsigne
 
 // code byte -> "owns a pair at p > k-1-p" (several pairs, or one that is not self-mirrored) / "exactly one pair";
 // CODE_DEFER (0xFF) is neither
-SMG_DEV bool d_code_hi(unsigned c) { return code_hi(c); }
+SMG_DEV bool d_code_hi(unsigned c) { return c - 63u < 65u; }                    // 63 .. 127
 SMG_DEV bool d_code_uq(unsigned c) { return ((c & 63u) - 1u) < 62u && c < 128u; }
 
 // One tile.  INNER tiles lie completely inside the table: vector loads, no bounds checks, no table-end cases.
 // RW = 64-bit words per request record: W (the complement k-mer) or W + 1 (+ count | has-hi-pair << 16).
-// does the tile need the leading word of its first owned entry ahead of time? (the per-entry map marking of round 3 does)
-template <int W, int RW> constexpr bool d_anch() { return ((W == 1 && RW == 1) || (W == 2 && RW != 1)) && !D_BMDENSE; }
-
 template <int W, int RW, bool ODD, bool KF, bool INNER> SMG_DEV void
-d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64 &fa, u64 &fb, DPrefetch<W, d_anch<W, RW>()> &pf)
+d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64 &fa, u64 &fb, DPrefetch<W> &pf)
 { typedef typename DWord<W>::type WT;
   constexpr bool D_BM = (W == 1 && RW == 1) || (W == 2 && RW != 1);     // variants that feed the request filter
   const GeoR &G = A.G;
@@ -490,9 +447,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
   for (int e = 0; e < D_RD; e++) Sm[4 + e] = Sm[e] >> 1;
 
   // entries whose block continues past distance 3: deferred (their owner queues their slot)
-  constexpr bool D_BM0 = (W == 1 && RW == 1) || (W == 2 && RW != 1);
-  constexpr bool DENSE = D_BMDENSE && D_BM0;              // (queued behind the tests, together with the candidates)
-  if (!(D_ABL & 32) && !DENSE)
+  if (!(D_ABL & 32))
     { u64 Al[4];
 #pragma unroll
       for (int e = 0; e < 4; e++) Al[e] = Sm[e] & Sm[e + 1] & Sm[e + 2] & Sm[e + 3] & ownM;
@@ -530,12 +485,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
   u64 uniqM[4], hiM[4];
 #pragma unroll
   for (int e = 0; e < 4; e++)
-    {
-#if D_AGG
-      code[e] = npair[e] & 0xFFFFu;                 // (the one delta code of a unique entry; CODE_NONE = 0 when there was none)
-      npair[e] >>= 16;
-#endif
-      const u64 mulM = __ballot(npair[e] >= 2u);
+    { const u64 mulM = __ballot(npair[e] >= 2u);
       code[e] = d_lane(mulM) ? (unsigned) CODE_MULTI : code[e];
       uniqM[e] = __ballot(npair[e] == 1u);
       if (ODD)
@@ -549,36 +499,10 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
   // ---- request filter: a CANDIDATE (exactly one suffix-side pair) sets the bit of its block id -------------------
   //@mark D_BMAP
   D_FENCE_P();
-  if (DENSE)
-    { // one queue for both kinds of work the dense pass behind the tile does: an entry whose block goes on past distance 3
-      // (D_Q_TAIL) and a candidate (D_Q_CAND: its block id gets its map bits there) -- at most one word per owned entry
-      u64 Al[4], Cm[4], Qm[4];
-      const bool wantmap = A.bmap != nullptr && !(D_ABL & 8);
-#pragma unroll
-      for (int e = 0; e < 4; e++)
-        { Al[e] = (D_ABL & 32) ? 0ull : Sm[e] & Sm[e + 1] & Sm[e + 2] & Sm[e + 3] & ownM;
-          Cm[e] = wantmap ? uniqM[e] & ownM : 0ull;
-          if (!INNER) Cm[e] &= V[e];
-          Qm[e] = Al[e] | Cm[e];
-        }
-      const unsigned nq = (unsigned) (__popcll(Qm[0]) + __popcll(Qm[1]) + __popcll(Qm[2]) + __popcll(Qm[3]));
-      if (nq)
-        { unsigned base = 0;
-          base = d_wave_add(S.s_tn, nq, lane);
-#pragma unroll
-          for (int e = 0; e < 4; e++)
-            { if (d_lane(Qm[e]))
-                { const unsigned q = __builtin_amdgcn_mbcnt_hi((unsigned) (Qm[e] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) Qm[e], base));
-                  S.tailq[q] = (uint16_t) ((unsigned) (slot0 + e) | (d_lane(Al[e]) ? D_Q_TAIL : 0u) | (d_lane(Cm[e]) ? D_Q_CAND : 0u));
-                }
-              base += (unsigned) __popcll(Qm[e]);
-            }
-        }
-    }
   // word 0 of the tile's LDS bit map = the map word of the tile's first owned entry (a uniform, scalar load)
   // (inner tiles: loaded one tile ahead with the entries -- as a load of its own it was waited for on the spot)
-  const uint32_t bmbase = (D_BM && !DENSE) ? (((INNER ? pf_anchor : (uint32_t) (A.keys[(g0 + D_LEAD) * W] >> 32)) >> bmsh) & ~31u) : 0u;
-  if (D_BM && !DENSE && A.bmap && !(D_ABL & 8))
+  const uint32_t bmbase = D_BM ? (((INNER ? pf_anchor : (uint32_t) (A.keys[(g0 + D_LEAD) * W] >> 32)) >> bmsh) & ~31u) : 0u;
+  if (D_BM && A.bmap && !(D_ABL & 8))
     { // leading word of the thread's own entries, back from the staged copy (cheaper than four registers kept alive
       // across the tests)
       u64 kw[4];
@@ -592,57 +516,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
 #pragma unroll
           for (int e = 0; e < 4; e++) kw[e] = S.ent[(slot0 + e) * W];
         }
-      if (D_BMCOMB)
-        { // ids ascend with the entries: the thread's marks fall into the map word of its first entry (`lo`) or into a later
-          // one, which for all but sparse tables is the next word (`hi`).  A lane whose entries span more than that, or
-          // reach past the tile's LDS window, marks in global memory entry by entry (the wave only goes there if one has to).
-          const bool two = A.two();
-          uint32_t id[4];
-#pragma unroll
-          for (int e = 0; e < 4; e++) id[e] = (uint32_t) (kw[e] >> 32) >> bmsh;
-          const uint32_t w0 = id[0] >> 5;
-          const bool ok = (id[3] >> 5) - w0 <= 1u && id[3] - bmbase < (uint32_t) D_BMF && id[0] >= bmbase;
-          uint32_t lo0 = 0, lo1 = 0, hi0 = 0, hi1 = 0;      // (lo0, lo1) = the two halves of the first word's 64 bits (one-bit map: lo0 only)
-          bool any = false;
-#pragma unroll
-          for (int e = 0; e < 4; e++)
-            { u64 cm = uniqM[e] & ownM;
-              if (!INNER) cm &= V[e];
-              const bool c = d_lane(cm);
-              any = any || c;
-              const uint32_t b0 = 1u << (id[e] & 31u), b1 = two ? 1u << bm2_pos((uint32_t) kw[e]) : 0u;
-              const bool first = (id[e] >> 5) == w0;
-              lo0 |= (c && first) ? b0 : 0u;  lo1 |= (c && first) ? b1 : 0u;
-              hi0 |= (c && !first) ? b0 : 0u; hi1 |= (c && !first) ? b1 : 0u;
-            }
-          const uint32_t rw = w0 - (bmbase >> 5);            // word of the tile's window
-          if (ok)
-            { if (two)
-                { u64 *bm64 = reinterpret_cast<u64 *>(S.bm);
-                  if (lo0) atomicOr(&bm64[rw], (u64) lo0 | ((u64) lo1 << 32));
-                  if (hi0) atomicOr(&bm64[rw + 1], (u64) hi0 | ((u64) hi1 << 32));
-                }
-              else
-                { if (lo0) atomicOr(&S.bm[rw], lo0);
-                  if (hi0) atomicOr(&S.bm[rw + 1], hi0);
-                }
-            }
-          if (__ballot(!ok && any))
-            { if (!ok)
-                {
-#pragma unroll
-                  for (int e = 0; e < 4; e++)
-                    { u64 cm = uniqM[e] & ownM;
-                      if (!INNER) cm &= V[e];
-                      if (d_lane(cm))
-                        { if (two) atomicOr(&reinterpret_cast<u64 *>(A.bmap)[id[e] >> 5], bm2_bits(id[e], (uint32_t) kw[e]));
-                          else     atomicOr(&A.bmap[id[e] >> 5], 1u << (id[e] & 31u));
-                        }
-                    }
-                }
-            }
-        }
-      else if (A.two())
+      if (A.two())
         { u64 *bm64 = reinterpret_cast<u64 *>(S.bm);
           u64 *gm64 = reinterpret_cast<u64 *>(A.bmap);
 #pragma unroll
@@ -818,48 +692,6 @@ d_detect(const P1Hot &A, const u64 *ent, const uint16_t *lcn, int64_t g0, int sa
     }
 }
 
-// ---- the same question, one distance per lane (D_DETPAR) ---------------------------------------------------------------
-// Lane (q, j) tests the queued entry in slot sa = tailq[q] against the entry d = D_RD + 1 + j slots on: same window block
-// (the table is sorted: equal prefixes at both ends mean equal prefixes in between) and one base apart -> both get their
-// bit in the deferred-entry map.  A block that goes on past the last distance (more than twelve entries: one entry in 1e5
-// on the bench table) is left to kf_bigfix altogether: the lane of the last distance marks its entry and the one a slot
-// further -- every member of a pair that far apart is in one of these two roles.
-template <int W, bool ODD, bool KF> SMG_DEV void
-d_detect_one(const P1Hot &A, const u64 *ent, const uint16_t *lcn, int64_t g0, int sa, int j, const P1Cold *__restrict__ cold)
-{ typedef typename DWord<W>::type WT;
-  const GeoR &G = A.G;
-  const int64_t n = A.n;
-  WT pa, sfa;
-  d_unpack<W, KF>(lds_key<W>(ent, sa), G, pa, sfa);
-  const int64_t it = g0 + sa;
-  const int d = D_RD + 1 + j;
-  int sb = sa + d;
-  if (g0 + sb >= n) return;
-  WT pb, sfb; unsigned cb;
-  if (sb < D_SLOTS) { d_unpack<W, KF>(lds_key<W>(ent, sb), G, pb, sfb); cb = lcn[sb]; }
-  else              { d_unpack<W, KF>(load_key<W>(A.keys, g0 + sb), G, pb, sfb); cb = A.cnt[g0 + sb]; }
-  if (pb != pa) return;
-  const WT dd = sfa ^ sfb;
-  const WT tt = ((dd << 1) | dd) & (WT) 0xAAAAAAAAAAAAAAAAull;
-  if (d_popc(tt) == 1 && (unsigned) lcn[sa] + cb <= SMG_SMAX)
-    { const int64_t jb = g0 + sb;
-      uint32_t *db = cold->dbits;
-      atomicOr(&db[it >> 5], 1u << (it & 31));
-      atomicOr(&db[jb >> 5], 1u << (jb & 31));
-    }
-  if (j == D_DETW - 1 && g0 + sb + 1 < n)            // does the block go on past the last distance?
-    { sb++;
-      if (sb < D_SLOTS) d_unpack<W, KF>(lds_key<W>(ent, sb), G, pb, sfb);
-      else              d_unpack<W, KF>(load_key<W>(A.keys, g0 + sb), G, pb, sfb);
-      if (pb == pa)
-        { const int64_t jb = g0 + sb;
-          uint32_t *db = cold->dbits;
-          atomicOr(&db[it >> 5], 1u << (it & 31));
-          atomicOr(&db[jb >> 5], 1u << (jb & 31));
-        }
-    }
-}
-
 #ifndef D_WAVES_W2
 #define D_WAVES_W2 3                       // two-word k-mers with a count word in the request (exact proof): waves per SIMD
 #endif                                     //   (the 23 KB request queue of that variant allows three workgroups per CU)
@@ -923,10 +755,9 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
       cold->times[3 * (size_t) blockIdx.x] = wall_clock64(); cold->times[3 * (size_t) blockIdx.x + 2] = hw;
     }
 
-  DPrefetch<W, d_anch<W, RW>()> pf;
+  DPrefetch<W> pf;
   pf.valid = false;
   int par = 0;
-  unsigned rot = blockIdx.x;                // (which wave starts the dense pass of the next tile)
   const unsigned cls = blockIdx.x % D_NCLS;
   unsigned ticket = (unsigned) __builtin_amdgcn_readfirstlane((int) s_tk0);      // ticket r stands for tile grid + D_NCLS r + cls
   int64_t tnext = (int64_t) gridDim.x + (int64_t) ticket * D_NCLS + cls, tnext2 = tnext + D_NCLS;
@@ -964,51 +795,22 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
       const bool last = tnext >= A.ntiles;
       const unsigned tn = s_tn[par];               // (zeroed again behind the barrier at the end of this iteration: the
       const unsigned qn = s_qn;                    //  next tile counts in the other one)
-      constexpr bool DENSE = D_BMDENSE && D_BM;
-      // word of the global map that word 0 of the tile's LDS window stands for (the window starts at the map word of the
-      // tile's first owned entry)
-      const uint32_t bmw0 = D_BM ? (uint32_t) __builtin_amdgcn_readfirstlane((int) (((uint32_t) (ent[D_LEAD * W] >> 32) >> A.bmsh()) >> 5)) : 0u;
-      if (D_BM && !DENSE && A.bmap)                 // candidate-block bits of this tile -> global map
+      if (D_BM && A.bmap)                           // candidate-block bits of this tile -> global map
         { const int two = A.two() ? 1 : 0;          // (two-bit map: twice the words, at twice the word offset)
           for (int w = t; w < (D_BMW << two); w += D_TPB)
             { const unsigned v = bm[w];
               if (v)
-                { atomicOr(&A.bmap[((size_t) bmw0 << two) + w], v);
+                { atomicOr(&A.bmap[(((size_t) (((uint32_t) (ent[D_LEAD * W] >> 32) >> A.bmsh()) >> 5)) << two) + w], v);
                   bm[w] = 0;
                 }
             }
         }
 
-      // ---- the dense pass over this tile's queued entries (a lane each) ------------------------------------------------
-      // D_Q_TAIL: does the entry own a pair at distance 4..30, or does its block go on past 30?  A hit sets the bits of the
-      // entry and of its partners in the deferred-entry map (one bit per table entry, so an entry named twice is redone once).
-      // D_Q_CAND: a candidate marks its block id in the tile's window of the map (LDS; ids beyond the window -- a sparse
-      // table -- straight in the global map).
-      const unsigned trot = D_ROT ? (unsigned) (t + 64 * (int) (rot & 3u)) & (D_TPB - 1u) : (unsigned) t;
-      rot++;
-      if (D_DETPAR && !DENSE)
-        { for (unsigned it = (unsigned) t; it < tn * D_DETW && !(D_ABL & 512); it += D_TPB)
-            d_detect_one<W, ODD, KF>(A, ent, lcn, g0, (int) tailq[it / D_DETW], (int) (it % D_DETW), cold);
-        }
-      else
-      for (unsigned q = trot; q < tn && !(D_ABL & 512); q += D_TPB)
-        { const unsigned qw = tailq[q];
-          const int sa = (int) (DENSE ? qw & 1023u : qw);
-          if (DENSE && (qw & D_Q_CAND))
-            { const u64 kw = ent[sa * W];
-              const uint32_t id = (uint32_t) (kw >> 32) >> A.bmsh();
-              const uint32_t rel = id - (bmw0 << 5);
-              if (A.two())
-                { const u64 v = bm2_bits(id, (uint32_t) kw);
-                  if (rel < D_BMF) atomicOr(&reinterpret_cast<u64 *>(bm)[rel >> 5], v);
-                  else             atomicOr(&reinterpret_cast<u64 *>(A.bmap)[id >> 5], v);
-                }
-              else
-                { if (rel < D_BMF) atomicOr(&bm[rel >> 5], 1u << (rel & 31));
-                  else             atomicOr(&A.bmap[id >> 5], 1u << (id & 31));
-                }
-            }
-          if (DENSE && !(qw & D_Q_TAIL)) continue;
+      // ---- deferred tail: one dense detection pass over this tile's queued entries (a lane each) ---------------------
+      // A hit sets the bits of the entry and of its partners in the deferred-entry map (one bit per table entry, so an
+      // entry named twice is redone once).
+      for (unsigned q = t; q < tn && !(D_ABL & 512); q += D_TPB)
+        { const int sa = (int) tailq[q];
           unsigned hm; bool big;
           d_detect<W, ODD, KF>(A, ent, lcn, g0, sa, hm, big);
           if (hm | (unsigned) big)                           // rare: mark the entry and its partners for kf_bigfix
@@ -1066,16 +868,6 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
         }
       if (!(D_ABL & 8192)) lds_barrier();
       if (t == 0) s_tn[par] = 0;
-      if (DENSE && A.bmap)                          // the tile's window is complete behind the barrier: -> global map.  (The
-        { const int two = A.two() ? 1 : 0;          //  next marks fall behind the next tile's barrier: no third one is needed.)
-          for (int w = t; w < (D_BMW << two); w += D_TPB)
-            { const unsigned v = bm[w];
-              if (v)
-                { atomicOr(&A.bmap[((size_t) bmw0 << two) + w], v);
-                  bm[w] = 0;
-                }
-            }
-        }
       tile = tnext; tnext = tnext2;
       tnext2 = (int64_t) gridDim.x + (int64_t) (unsigned) __builtin_amdgcn_readfirstlane((int) s_tk[par]) * D_NCLS + cls;
     }

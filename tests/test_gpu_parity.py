@@ -1178,3 +1178,40 @@ def test_the_tables_prefix_index_as_lookup_directory_changes_nothing(k, G, rep):
     if k == 12:
         keys = tk.cpu().numpy().view(np.uint64)
         assert np.array_equal(plots[0].reshape(1001, 501), brute.hetmers_plot(ktab.u64_to_packed(keys, k), tc.cpu().numpy().view(np.uint16), k))
+
+
+def test_a_rerun_on_the_same_engine_takes_nothing_for_granted_that_it_does_not_check():
+    """smg_engine_run on a table the engine has run before queues the whole run without reading anything back in between and
+    sizes it from the last run's counts; every count is checked at the end.  A table that changed in place between two
+    runs (equal size, equal pointers) must still get the right answer: here (i) the counts of one k-mer and its complement
+    move so that their pairs disappear (closed table, other request count), (ii) one count moves alone (the table is no
+    longer closed: general path)."""
+    import torch
+    from smudgeplot_amd import sharded
+    k = 31
+    keys, cnt = synth.diploid_table_u64(30000, k=k, seed=91, het_frac=0.4, cov=30, L=5)
+    dev = torch.device("cuda:0")
+    tk = torch.from_numpy(keys.view(np.int64).copy()).to(dev)
+    tc = torch.from_numpy(cnt.view(np.int16).copy()).to(dev)
+    eng = sharded.TorchEngine(dev)
+    eng.bind(k, tk, tc)
+    want = brute.hetmers_plot(ktab.u64_to_packed(keys, k), cnt, k)
+    for _ in range(3):                                        # the second and third run are the speculative ones
+        plot, st = sharded.hetmers_sharded(k, tk, tc, symcheck="hash", eng=eng, prebound=True)
+        assert st["path"] == 1 and np.array_equal(plot.cpu().numpy().reshape(1001, 501), want)
+    rc = ktab.revcomp_u64(keys, k)
+    pos = {int(v): i for i, v in enumerate(keys)}
+    # an entry that has a pair, and its complement: counts up to 900 -> no sum stays <= 1000 next to them
+    j = int(np.nonzero(rc != keys)[0][len(keys) // 3])
+    cnt2 = cnt.copy(); cnt2[j] = 900; cnt2[pos[int(rc[j])]] = 900
+    tc.copy_(torch.from_numpy(cnt2.view(np.int16).copy()))
+    plot, st = sharded.hetmers_sharded(k, tk, tc, symcheck="hash", eng=eng, prebound=True)
+    assert st["path"] == 1 and np.array_equal(plot.cpu().numpy().reshape(1001, 501), brute.hetmers_plot(ktab.u64_to_packed(keys, k), cnt2, k))
+    cnt3 = cnt2.copy(); cnt3[j] = 17                           # ... and now the table is not closed any more
+    tc.copy_(torch.from_numpy(cnt3.view(np.int16).copy()))
+    plot, st = sharded.hetmers_sharded(k, tk, tc, symcheck="hash", eng=eng, prebound=True)
+    assert st["path"] == 2 and np.array_equal(plot.cpu().numpy().reshape(1001, 501), brute.hetmers_plot(ktab.u64_to_packed(keys, k), cnt3, k))
+    tc.copy_(torch.from_numpy(cnt.view(np.int16).copy()))    # back to the first table: the plain path, then speculative again
+    for _ in range(2):
+        plot, st = sharded.hetmers_sharded(k, tk, tc, symcheck="hash", eng=eng, prebound=True)
+        assert st["path"] == 1 and np.array_equal(plot.cpu().numpy().reshape(1001, 501), want)
