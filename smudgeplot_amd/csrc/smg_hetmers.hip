@@ -578,6 +578,7 @@ struct smg_engine
   bool         have_ixdir;                   //   ... handed over with the current table (smg_engine_set_prefix_index); gone when the table changes
   bool         dir_preset;                   //   the current run looks up through ixdir: pass 1 writes no directory
   bool         have_ends;  u64 end_first, end_last;     // leading words of the first and the last entry of the bound table (read once)
+  bool         no_filter;    // pass 1 builds no candidate map and nothing is filtered (out-of-core shards: smg_multi.hpp, host_run_sequential)
   bool         fused_last;   // the look-ups of the last run were the fused ones (kl_part -> kl_probe on the engine's own map)
   bool         spec_ok;      // the last smg_engine_run on this bound table went through the hash-proof chain: its counts size the next one
   int64_t      spec_nreq, spec_nbig;   //   requests pass 1 (+ kf_bigfix) emitted, entries deferred to kf_bigfix (functions of the table)
@@ -1125,7 +1126,7 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
   e->bm_bits = 0; e->bm2 = 0;
   e->filtered = false; e->presorted = 0;
   e->lg.nb = 0;
-  if (filter_ok(e) && !emit_all && !getenv("SMG_NO_FILTER"))
+  if (filter_ok(e) && !emit_all && !e->no_filter && !getenv("SMG_NO_FILTER"))
     { const int nbits = bm_id_bits(e->kmer, e->bm_cap);
       // the look-up chain of smg_lookup.hpp: one-word k-mers, key-only records, a map of >= 12 id bits
       const bool chain = nbits >= 12 && e->W <= 2 && e->rw == e->W && !getenv("SMG_OLD_LOOKUP");
@@ -1726,6 +1727,40 @@ static int fast_pass2(smg_engine *e, int64_t *d_plot, bool with_sum, char *errbu
   if (rc) return rc;
   float ms = 0; hipEventElapsedTime(&ms, e->ev[6], e->ev[7]);
   e->st.ms_pass2 = ms;
+  return SMG_OK;
+}
+
+// ---- out-of-core shards: take a shard up again after its keys were dropped (smg_multi.hpp, host_run_sequential) ------------
+// The shard's k-mers and counts are back in the engine (decoded again from the table), `d_codes` are the code bytes its
+// pass 1 left.  What the look-ups of the received requests and pass 2 need besides is the directory: the table's prefix
+// index if it was handed over, else one pass of k_directory.  No candidate map, no signatures, no list of deferred entries
+// (pass 2 finds the far partners by scanning the code bytes, as it does for three-word k-mers).
+static int fast_resume(smg_engine *e, const uint8_t *d_codes, int with_meta, char *errbuf, size_t errlen)
+{ int rc;
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipMemsetAsync(e->ctrl, 0, sizeof(Ctrl), e->stream));
+  set_geo(e);
+  e->fast = true; e->counted_done = false; e->lookup_pending = false;
+  if ((rc = grow(&e->deg, &e->deg_cap, ((e->n + 15) & ~15ll) + 32, errbuf, errlen))) return rc;
+  if (e->n > 0) HIPCHK(hipMemcpyAsync(e->deg, d_codes, (size_t) e->n, hipMemcpyDeviceToDevice, e->stream));
+  e->rw = e->W + ((with_meta || e->W > 2) ? 1 : 0);
+  e->use_sig = false; e->bm_bits = 0; e->bm2 = 0; e->lg.nb = 0;
+  e->filtered = false; e->presorted = 0; e->n_chunks = 0; e->far_listed = false;
+  e->st.nrequests = 0; e->st.ms_rclookup = 0;
+  memset(e->fp, 0, sizeof(e->fp));
+  if ((rc = dir_geometry(e, 8, errbuf, errlen, true))) return rc;
+  if (!e->dir_preset)
+    { HIPCHK(hipMemsetAsync(e->bstart, e->n > 0 ? 0xFF : 0, sizeof(uint32_t) * ((size_t) e->dir.nb + 2), e->stream));
+      if (e->n > 0)
+        { Tab t = make_tab(e);
+          const unsigned nblk = (unsigned) ((e->n + 1 + TPB - 1) / TPB);
+#define CALL(WW) hipLaunchKernelGGL(k_directory<WW>, dim3(nblk), dim3(TPB), 0, e->stream, t, e->bstart, e->ctrl)
+          DISPATCH_W(e, CALL)
+#undef CALL
+          HIPCHK(hipGetLastError());
+        }
+    }
+  e->prepared = true;
   return SMG_OK;
 }
 
@@ -2619,6 +2654,39 @@ static int host_run(const smg_table_source *tv, const smg_opts *opts, int64_t *p
                                want_symm ? " before the table is symmetrised" : "", ng);
         }
     }
+    // Out of core (smg_multi.hpp, host_run_sequential): a table whose shards do not fit the device TOGETHER -- keys, counts and
+    // the lists of a run take ~8 W + 12 bytes per entry -- is run shard after shard, the table read twice; what stays between
+    // the two rounds is a code byte per entry and the requests.  SMG_HBM_LIMIT=<bytes> (tests) stands in for the free device
+    // memory, SMG_SEQUENTIAL_SHARDS=<n> forces the mode.
+    if (ng <= 1 || virt)
+      { const int W = (tv->kmer + 31) / 32;
+        int seq = 0;
+        { const char *sv = getenv("SMG_SEQUENTIAL_SHARDS"); if (sv && atoi(sv) > 1) seq = atoi(sv); }
+        if (!seq && tv->kmer <= FAST_MAX_K)
+          { size_t fr = 0, tot = 0;
+            double limit = 0;
+            { const char *hl = getenv("SMG_HBM_LIMIT"); if (hl && atof(hl) > 0) limit = atof(hl); }
+            if (limit <= 0 && hipSetDevice(device) == hipSuccess && hipMemGetInfo(&fr, &tot) == hipSuccess) limit = 0.9 * (double) fr;
+            const double all = (double) tv->nels * (8.0 * W + 12.0);
+            if (limit > 0 && all > limit)
+              { const double keep = (double) tv->nels * (1.0 + 2.4 * W);             // code bytes + requests of every shard
+                for (int q = 2; q <= SMG_MAXGPU && !seq; q++)
+                  if (keep + (double) tv->nels / q * (8.0 * W + 14.0) <= limit && tv->nels / q < 0xFFFFFFF0ll - 16) seq = q;
+                if (!seq)
+                  return fail(errbuf, errlen, SMG_ENOMEM, "the table does not fit the device even shard by shard (16 shards, a code byte and "
+                              "the requests of every entry resident): use SMUDGEPLOT_GPUS%s");
+              }
+          }
+        if (seq)
+          { if (labels)
+              return fail(errbuf, errlen, SMG_EINVAL, "extract on a table that does not fit the device is not supported (run hetmers, or use SMUDGEPLOT_GPUS)%s");
+            if (verbose) fprintf(stderr, "  [smg] %lld entries do not fit the device together: %d prefix shards one after the other\n",
+                                 (long long) tv->nels, seq);
+            smg_opts o; memset(&o, 0, sizeof(o));
+            if (opts) o = *opts; else o.symcheck = SMG_SYM_HASH;
+            return host_run_sequential(tv, &o, seq, plot, stats, errbuf, errlen);
+          }
+      }
     // SMG_FORCE_MULTI=1 (tests): take the multi-GPU code path even with one GPU -- a one-rank RCCL
     // communicator, send/recv to self, all-reduce: checks the dlopen'ed RCCL entry points on a 1-GPU box
     if (ng <= 1 && getenv("SMG_FORCE_MULTI") && !v) ng = -1;

@@ -439,6 +439,142 @@ static void multi_cuts(const smg_table_source *tv, int n, int64_t *cut)
     }
 }
 
+// ---- out of core: prefix shards ONE AFTER THE OTHER on one device ---------------------------------------------------------
+// The reference streams a table of any size from disk (small_recursion loads a subtree into its cache when it fits and
+// falls back to the streaming twins when it does not, PloidyPlot.c:931-1038); the virtual shards above must all be
+// resident together.  Here a table whose shards do not fit together is slow instead of an error: what has to outlive a
+// shard between its two passes is its code bytes (1 byte per entry) and its requests (8 bytes for ~17 % of the entries,
+// grouped by destination shard) -- not its k-mers.
+//   round 1, shard by shard: read + decode, pass 1 (no candidate map: the filter would need the maps of the shards that have
+//            not been read yet), requests grouped by destination, code bytes and requests kept, k-mers dropped;
+//   round 2, shard by shard: read + decode again (the reference reads its table ~2 (BLEVEL + 1) times), code bytes back, look-ups
+//            of all requests that name this shard, pass 2 into the one histogram.
+// Symmetry proof as everywhere: XOR of the shards' fingerprints, no look-up may miss.  A table that fails it, a table that
+// still has to be conditioned and k > 85 are refused with a precise message (condition the table with smg_condition first).
+static int host_run_sequential(const smg_table_source *tv, const smg_opts *opts, int nshards, int64_t *plot, smg_stats *stats,
+                               char *errbuf, size_t errlen)
+{ const int W = (tv->kmer + 31) / 32, kbyte = (tv->kmer + 3) >> 2, pbyte = kbyte + 2 - tv->ibyte;
+  if (tv->kmer > FAST_MAX_K)
+    return fail(errbuf, errlen, SMG_EINVAL, "a table of k > 85 that does not fit the device is not supported (its degrees need all shards at once)%s");
+  if (opts->condition)
+    return fail(errbuf, errlen, SMG_EINVAL, "a raw table that does not fit the device: condition it first (smg_condition), then run hetmers%s");
+  if (nshards < 2) nshards = 2;
+  if (nshards > SMG_MAXGPU) nshards = SMG_MAXGPU;            // (the router groups by at most 16 destinations)
+  const int symcheck = opts->symcheck == SMG_SYM_NONE ? SMG_SYM_HASH : opts->symcheck;
+  const int n = nshards;
+  std::vector<int64_t> cut((size_t) n + 1), counts((size_t) n * n, 0), nreq((size_t) n, 0);
+  std::vector<uint8_t *> codes((size_t) n, (uint8_t *) NULL);
+  std::vector<uint64_t *> send((size_t) n, (uint64_t *) NULL);
+  std::vector<u64> splitters((size_t) (n > 1 ? n - 1 : 1) * W, 0);
+  multi_cuts(tv, n, cut.data());
+  { // a splitter = the prefix bucket a shard starts with (cuts are bucket boundaries): everything in front is smaller
+    const int64_t ixlen = 1ll << (8 * tv->ibyte);
+    for (int sh = 1; sh < n; sh++)
+      { int64_t lo = 0, hi = ixlen;                            // smallest bucket b with index[b] > cut[sh]
+        while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (tv->prefix_index[m] > cut[sh]) hi = m; else lo = m + 1; }
+        splitters[(size_t) (sh - 1) * W] = lo >= ixlen ? ~0ull : (u64) lo << (64 - 8 * tv->ibyte);
+        if (lo >= ixlen) for (int w = 1; w < W; w++) splitters[(size_t) (sh - 1) * W + w] = ~0ull;
+      }
+  }
+  smg_engine *e = smg_engine_create(opts->device, NULL, errbuf, errlen);
+  if (!e) return SMG_ENODEV;
+  e->no_filter = true;
+  int rc = SMG_OK, rw = W;
+  int64_t *d_index = NULL, *d_plot = NULL, *h_plot = NULL;
+  uint64_t *recv = NULL;
+  int64_t missing = 0, nels = 0, nemit = 0;
+  u64 fp[4] = { 0, 0, 0, 0 };
+  float ms_p1 = 0, ms_look = 0, ms_p2 = 0;
+  const size_t ixbytes = sizeof(int64_t) << (8 * tv->ibyte);
+  struct timespec w0, w1;
+  clock_gettime(CLOCK_MONOTONIC, &w0);
+#define SBAIL(code, msg) { rc = fail(errbuf, errlen, code, msg "%s"); goto done; }
+  if (hipMalloc(&d_index, ixbytes) != hipSuccess || hipMalloc(&d_plot, sizeof(int64_t) * SMG_PLOT_CELLS) != hipSuccess)
+    SBAIL(SMG_ENOMEM, "out of device memory for the table index")
+  if (hipMemcpy(d_index, tv->prefix_index, ixbytes, hipMemcpyHostToDevice) != hipSuccess) SBAIL(SMG_ENODEV, "host to device copy failed")
+  h_plot = (int64_t *) malloc(sizeof(int64_t) * SMG_PLOT_CELLS);
+  if (!h_plot) SBAIL(SMG_ENOMEM, "out of host memory")
+  memset(plot, 0, sizeof(int64_t) * SMG_PLOT_CELLS);
+  for (int round = 1; round <= 2 && rc == SMG_OK; round++)
+    for (int sh = 0; sh < n && rc == SMG_OK; sh++)
+      { const int64_t lo = cut[sh], hi = cut[sh + 1], ns = hi - lo;
+        if ((rc = decode_begin(e, tv->kmer, tv->ibyte, ns, errbuf, errlen))) break;
+        { DecodeHook hk; hk.e = e; hk.d_index = d_index; hk.ibyte = tv->ibyte; hk.ibase = lo;
+          if ((rc = ingest_records(tv, pbyte, lo, hi, NULL, opts->device, tv->host_threads, NULL, errbuf, errlen, decode_hook, &hk))) break;
+        }
+        if ((rc = smg_engine_set_prefix_index(e, d_index, tv->ibyte, lo, errbuf, errlen))) break;
+        if (hipStreamSynchronize(e->stream) != hipSuccess) SBAIL(SMG_ENODEV, "decode failed")
+        if (round == 1)
+          { e->bm_want = 32;
+            if ((rc = smg_engine_pass1(e, symcheck, errbuf, errlen))) break;
+            rw = smg_engine_record_words(e);
+            nreq[sh] = smg_engine_nreq(e);
+            if (hipMalloc(&send[sh], sizeof(uint64_t) * (size_t) (nreq[sh] > 0 ? nreq[sh] : 1) * rw) != hipSuccess
+                || hipMalloc(&codes[sh], (size_t) (ns > 0 ? ns : 1)) != hipSuccess)
+              SBAIL(SMG_ENOMEM, "out of device memory for what a shard leaves behind (1 byte per entry and its requests)")
+            if ((rc = smg_engine_route(e, (const uint64_t *) splitters.data(), n, send[sh], nreq[sh], &counts[(size_t) sh * n], errbuf, errlen))) break;
+            if (ns > 0 && hipMemcpy(codes[sh], e->deg, (size_t) ns, hipMemcpyDeviceToDevice) != hipSuccess) SBAIL(SMG_ENODEV, "device copy failed")
+            for (int q = 0; q < 4; q++) fp[q] ^= e->fp[q];
+            ms_p1 += e->st.ms_pass1; nels += ns; nemit += e->st.nemitted;
+          }
+        else
+          { if ((rc = fast_resume(e, codes[sh], symcheck == SMG_SYM_EXACT, errbuf, errlen))) break;
+            int64_t nrecv = 0;
+            for (int t = 0; t < n; t++) nrecv += counts[(size_t) t * n + sh];
+            if (hipMalloc(&recv, sizeof(uint64_t) * (size_t) (nrecv > 0 ? nrecv : 1) * rw) != hipSuccess)
+              SBAIL(SMG_ENOMEM, "out of device memory for a shard's requests")
+            int64_t roff = 0;
+            for (int t = 0; t < n; t++)
+              { int64_t soff = 0;
+                for (int d = 0; d < sh; d++) soff += counts[(size_t) t * n + d];
+                const int64_t c = counts[(size_t) t * n + sh];
+                if (c && hipMemcpy(recv + roff * rw, send[t] + soff * rw, sizeof(uint64_t) * (size_t) c * rw, hipMemcpyDeviceToDevice) != hipSuccess)
+                  SBAIL(SMG_ENODEV, "device copy failed")
+                roff += c;
+              }
+            int64_t miss = 0;
+            if ((rc = smg_engine_apply(e, recv, nrecv, &miss, errbuf, errlen))) break;
+            missing += miss;
+            hipFree(recv); recv = NULL;
+            hipFree(codes[sh]); codes[sh] = NULL;
+            if ((rc = smg_engine_pass2(e, d_plot, errbuf, errlen))) break;
+            if (hipMemcpy(h_plot, d_plot, sizeof(int64_t) * SMG_PLOT_CELLS, hipMemcpyDeviceToHost) != hipSuccess) SBAIL(SMG_ENODEV, "device to host copy failed")
+            for (int cell = 0; cell < SMG_PLOT_CELLS; cell++) plot[cell] += h_plot[cell];
+            smg_stats st2; smg_engine_stats(e, &st2);
+            ms_look += st2.ms_rclookup; ms_p2 += st2.ms_pass2 > 0 ? st2.ms_pass2 : 0;
+          }
+      }
+  if (rc == SMG_OK)
+    { bool symmetric = missing == 0;
+      if (symcheck == SMG_SYM_HASH) symmetric = symmetric && fp[0] == fp[2] && fp[1] == fp[3];
+      if (!symmetric)
+        rc = fail(errbuf, errlen, SMG_ENOTSYM, "the table is not closed under reverse complement with equal counts, and it does not fit the "
+                  "device in one piece: condition it first (smg_condition)%s");
+    }
+  if (rc == SMG_OK)
+    { clock_gettime(CLOCK_MONOTONIC, &w1);
+      smg_stats st; memset(&st, 0, sizeof(st));
+      st.path = 1; st.key_words = W; st.nels = nels; st.nemitted = nemit; st.nrequests = nemit;
+      st.ms_pass1 = ms_p1; st.ms_rclookup = ms_look; st.ms_pass2 = ms_p2;
+      st.ms_total = (float) (((double) (w1.tv_sec - w0.tv_sec) + 1e-9 * (double) (w1.tv_nsec - w0.tv_nsec)) * 1e3);
+      for (int cell = 0; cell < SMG_PLOT_CELLS; cell++) st.npairs += plot[cell];
+      if (stats) *stats = st;
+      if (opts->verbose)
+        fprintf(stderr, "  [smg] n=%lld k=%d out of core: %d prefix shards one after the other, the table read twice; pass1 %.2f ms, "
+                "rc-lookup %.2f, pass2 %.2f (sums over the shards), wall incl. both reads %.2f ms\n",
+                (long long) nels, tv->kmer, n, ms_p1, ms_look, ms_p2, st.ms_total);
+    }
+done:
+#undef SBAIL
+  for (int sh = 0; sh < n; sh++) { if (codes[sh]) hipFree(codes[sh]); if (send[sh]) hipFree(send[sh]); }
+  if (recv) hipFree(recv);
+  if (d_index) hipFree(d_index);
+  if (d_plot) hipFree(d_plot);
+  free(h_plot);
+  smg_engine_destroy(e);
+  return rc;
+}
+
 static int host_run_multi(const smg_table_source *tv, const smg_opts *opts, int ngpus, bool force_virtual, int64_t *plot,
                           smg_stats *stats, char *errbuf, size_t errlen, const uint16_t *labels = NULL,
                           uint64_t **records = NULL, int64_t *nrec = NULL, int *rec_words = NULL)

@@ -1113,13 +1113,16 @@ def _polyploid_vs_reference(tmp_path, k, tk, tc, L, min_entries, shards, min_row
     want = (tmp_path / "ref.smu").read_text()
     assert want.count("\n") > min_rows
     assert eng_smu == want
-    for gpus, out in ((1, "g1"), (shards, "gs")):
-        env = dict(os.environ, SMUDGEPLOT_GPUS=str(gpus))
+    for gpus, out in ((1, "g1"), (shards, "gs"), (-3, "g3seq")):
+        env = dict(os.environ, SMUDGEPLOT_GPUS=str(max(gpus, 1)))
         if gpus > 1:
             env["SMG_VIRTUAL_SHARDS"] = str(gpus)
+        if gpus < 0:                                     # out of core: three shards one after the other, the table read twice
+            env["SMG_SEQUENTIAL_SHARDS"] = str(-gpus)
         q = subprocess.run([HETMERS_BIN, f"-e{L}", "-T8", "-v", f"-o{out}", "t.ktab"], cwd=tmp_path, capture_output=True,
                            text=True, env=env)
         assert q.returncode == 0, q.stderr
+        assert (gpus >= 0) or "out of core" in q.stderr
         assert (tmp_path / f"{out}.smu").read_text() == want, gpus
     return want
 
@@ -1215,3 +1218,43 @@ def test_a_rerun_on_the_same_engine_takes_nothing_for_granted_that_it_does_not_c
     for _ in range(2):
         plot, st = sharded.hetmers_sharded(k, tk, tc, symcheck="hash", eng=eng, prebound=True)
         assert st["path"] == 1 and np.array_equal(plot.cpu().numpy().reshape(1001, 501), want)
+
+
+@pytest.mark.parametrize("nshards", [2, 5, 13])
+@pytest.mark.parametrize("name", ["k31_i1", "k31_i3_p4", "k21_i2_p2", "k51_i1_p3", "k32_i1_p2", "k65_i1", "k17_i1"])
+@pytest.mark.parametrize("mode", ["hash", "exact"])
+def test_out_of_core_shards_one_after_the_other(name, nshards, mode, monkeypatch):
+    """a table whose shards do not fit the device together is run shard after shard, the table read twice (the reference
+    streams what its cache does not hold, PloidyPlot.c:931-1038): only a code byte per entry and the requests stay between
+    the two rounds.  SMG_SEQUENTIAL_SHARDS forces the mode on the reference's golden vectors."""
+    g = load_golden(name)
+    monkeypatch.setenv("SMG_SEQUENTIAL_SHARDS", str(nshards))
+    plot, st = engine.hetmers_run(make_table(g), symcheck=mode)
+    assert engine.smu_text(plot) == g["smu"]
+    assert st["nels"] == len(g["counts"]) and st["path"] == 1
+
+
+def test_out_of_core_mode_is_chosen_from_the_free_memory_and_says_what_it_cannot_do(monkeypatch, tmp_path):
+    """SMG_HBM_LIMIT (bytes) stands in for the free device memory: the executable picks the number of shards itself and says
+    so; a raw table, k > 85, a table that is not closed and an extract run get a precise refusal instead of a wrong answer"""
+    g = load_golden("k31_i3_p4")
+    n = len(g["counts"])
+    ktab.write_ktab(str(tmp_path / "t"), g["k"], g["packed"], g["counts"], ibyte=g["ibyte"], nparts=g["nparts"])
+    # all together: n * 20 bytes; a code byte + requests of every entry (3.4 bytes) + a third of the table must fit
+    env = dict(os.environ, SMG_HBM_LIMIT=str(int(n * 3.4 + n / 3 * 22 + 1000)))
+    r = subprocess.run([HETMERS_BIN, "-oout", f"-e{g['L']}", "-T4", "-v", "t.ktab"], cwd=tmp_path, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "prefix shards one after the other" in r.stderr and "out of core" in r.stderr
+    assert (tmp_path / "out.smu").read_text() == g["smu"]
+    r = subprocess.run([HETMERS_BIN, "-oout2", f"-e{g['L']}", "-T4", "t.ktab"], cwd=tmp_path, capture_output=True, text=True,
+                       env=dict(os.environ, SMG_HBM_LIMIT=str(int(n * 3.0))))
+    assert r.returncode == 1 and "does not fit the device even shard by shard" in r.stderr
+    monkeypatch.setenv("SMG_SEQUENTIAL_SHARDS", "3")
+    with pytest.raises(engine.EngineError, match="k > 85"):
+        engine.hetmers_run(make_table(load_golden("k100_i1")), symcheck="hash")
+    packed, cnt = synth.adversarial_table(31, 3000, 4, seed=5, low_complexity=40, dense=1)
+    keep = np.ones(len(cnt), bool); keep[len(cnt) // 2] = False
+    with pytest.raises(engine.EngineError, match="not closed under reverse complement"):
+        engine.hetmers_run(table_from(packed[keep], cnt[keep], 31), symcheck="hash")
+    with pytest.raises(engine.EngineError, match="condition it first"):
+        engine.hetmers_run(table_from(packed, cnt, 31), symcheck="hash", condition=engine.COND_TRIM if hasattr(engine, "COND_TRIM") else 1, ethresh=6)
