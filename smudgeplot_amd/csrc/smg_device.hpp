@@ -173,21 +173,9 @@ template <int W> SMG_DEV int64_t find_key(const u64 *__restrict__ keys, const Di
   if (lo == (int64_t) DIR_UNSET) return -1;
   int64_t hi = d.bstart[++b];
   while (hi == (int64_t) DIR_UNSET) hi = d.bstart[++b];       // bstart[nb] is always set
-  // The k-mers of a bucket share their leading 32 - dsh bits and are spread evenly over the rest (a random genome; a skewed
-  // bucket only costs the two probes below): the 32 bits below the bucket bits say where in the bucket the target sits, to
-  // within a few entries -- the bisection then stays inside one or two 128-byte lines instead of walking down from the
-  // middle of a bucket of 64-300 k-mers (five or six lines, every one a miss: the look-ups of a polyploid table, where one
-  // request in eight survives the filter, were most of its step).
-  if (hi - lo > 16)
-    { const uint32_t rem = (uint32_t) ((t.w[0] << (32 - d.dsh)) >> 32);
-      const int64_t pos = lo + (int64_t) (((u64) rem * (u64) (hi - lo)) >> 32);
-      const int64_t a = pos - 8, b2 = pos + 8;
-      if (a > lo && !key_lt<W>(load_key<W>(keys, a), t)) hi = a + 1;             // at a, or left of it
-      else
-        { if (a > lo) lo = a + 1;
-          if (b2 < hi) { if (key_lt<W>(load_key<W>(keys, b2), t)) lo = b2 + 1; else hi = b2 + 1; }
-        }
-    }
+  // (Round 4 tried to start the bisection from an interpolated position -- the k-mers of a bucket are spread evenly below
+  //  its leading bits -- to keep it inside one or two lines: no gain, 4.74 vs 4.68 ms for the look-ups of the octoploid
+  //  table, whose fused probe kernel is bound by the volume of its random map and directory loads, not by their depth.)
   lo = lower_bound_key<W>(keys, lo, hi, t);
   if (lo < hi && key_eq<W>(load_key<W>(keys, lo), t)) return lo;
   return -1;

@@ -655,7 +655,7 @@ static int fail(char *errbuf, size_t errlen, int code, const char *fmt, const ch
 #define DISPATCH_W3(e, CALL)                                                                  \
   switch ((e)->W) { case 1: CALL(1); break; case 2: CALL(2); break; default: CALL(3); break; }
 
-extern "C" const char *smg_version(void) { return "smudgeplot_amd 0.3 (hetmers engine, gfx950)"; }
+extern "C" const char *smg_version(void) { return "smudgeplot_amd 0.4 (hetmers engine, gfx950)"; }
 
 extern "C" int smg_device_count(void)
 { int n = 0;

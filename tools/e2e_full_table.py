@@ -68,6 +68,20 @@ with tempfile.TemporaryDirectory(prefix="smg_full", dir=tmp) as d:
     out["mi355x_hetmers_end_to_end_T4"] = {"wall_s": round(best[0], 3), "kmers_per_s": n / best[0],
                                            "engine_line": [l.strip() for l in best[1].splitlines() if "[smg]" in l]}
     gpu_smu = open(os.path.join(d, "gpu.smu")).read()
+    vs = int(os.environ.get("E2E_VSHARDS", "0"))
+    if vs > 1:       # the N > 1 protocol on this one device: vs prefix shards, device-to-device "exchange" (smg_multi.hpp)
+        t0 = time.time()
+        r = subprocess.run([ours, f"-e{L}", "-T4", "-v", "-ovs", "t.ktab"], cwd=d, capture_output=True, text=True,
+                           env=dict(os.environ, SMG_VIRTUAL_SHARDS=str(vs)))
+        assert r.returncode == 0, r.stderr
+        out[f"virtual_shards_{vs}"] = {"wall_s": round(time.time() - t0, 3), "same_smu": open(os.path.join(d, "vs.smu")).read() == gpu_smu,
+                                       "engine_line": [l.strip() for l in r.stderr.splitlines() if "[smg]" in l]}
+        t0 = time.time()
+        r = subprocess.run([ours, f"-e{L}", "-T4", "-v", "-oseq", "t.ktab"], cwd=d, capture_output=True, text=True,
+                           env=dict(os.environ, SMG_SEQUENTIAL_SHARDS="4"))
+        assert r.returncode == 0, r.stderr
+        out["out_of_core_4_shards"] = {"wall_s": round(time.time() - t0, 3), "same_smu": open(os.path.join(d, "seq.smu")).read() == gpu_smu,
+                                       "engine_line": [l.strip() for l in r.stderr.splitlines() if "[smg]" in l]}
     out["smu_bytes"] = len(gpu_smu)
     out["smu_rows"] = gpu_smu.count("\n")
     out["engine_on_resident_table_equals_executable_on_files"] = eng_smu == gpu_smu
