@@ -1515,7 +1515,9 @@ static int lookup_probe(smg_engine *e, const uint32_t *map, bool list, unsigned 
   // share of deferred entries that pass 1 reported tells the two kinds of table apart (0.13 % / 0.39 % in the two
   // bench workloads); SMG_PROBE_X=0/1 overrides.
   { const char *px = getenv("SMG_PROBE_X");
-    const bool auto_x = e->st.nbig > 0 && e->st.nbig * 400 > e->n;
+    // ... and so does the share of entries that sent a request: 17.5 % on the diploid tables, a third on the polyploid ones, where
+    // one request in seven survives the filter (2.5e7 look-ups at 6.4e8 entries) and kl_probe_x is 7-8 % ahead as well
+    const bool auto_x = (e->st.nbig > 0 && e->st.nbig * 400 > e->n) || e->st.nemitted * 100 > e->n * 28;
     if (!list && e->lg.nb >= 3 && (px ? atoi(px) != 0 : auto_x))
       { int rc2;
         if ((rc2 = grow(&e->xtick, &e->xtick_cap, (int64_t) PX_NXCD * PX_TICKW * 4, errbuf, errlen))) return rc2;
