@@ -81,10 +81,10 @@ def make_table(workload: str, G: int, k: int, dev, seed: int = 1):
 
 
 def lib_hash() -> str:
-    """identity of the engine build: profiles/hbm_traffic.json carries the one its counters were read on"""
-    import hashlib
-    with open(os.path.join(ROOT, "smudgeplot_amd", "libsmg_hetmers.so"), "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()[:16]
+    """identity of the engine's device code (sha256 of the gfx950 code object inside the library):
+    profiles/hbm_traffic.json carries the one its counters were read on"""
+    from smudgeplot_amd import codeobj
+    return codeobj.code_object_hash()
 
 
 def cpu_baseline(workload: str, sample_genome: int, k: int, dev):
@@ -244,12 +244,12 @@ def main():
         if dom in t.get("bytes_per_entry", {}):
             # counters are read in separate rocprofv3 passes (tools/r04_measure.sh), so the figure belongs to the build it
             # was read on: another build of the engine gets no traffic figure instead of a stale one
-            if t.get("lib_sha256_16") == lib_hash():
+            if t.get("code_object_sha256_16") == lib_hash():
                 traffic = t["bytes_per_entry"][dom] * n_local
                 traffic_src = t.get("source")
             else:
-                traffic_src = "stale: profiles/hbm_traffic.json was measured on engine build %s, this is %s" % (
-                    t.get("lib_sha256_16"), lib_hash())
+                traffic_src = "stale: profiles/hbm_traffic.json was measured on code object %s, this library carries %s" % (
+                    t.get("code_object_sha256_16"), lib_hash())
 
     if rank == 0:
         # the CPU baseline is timed on rank 0 of the single-GPU run only (it takes ~25 s of host time)

@@ -2619,6 +2619,8 @@ static int host_run(const smg_table_source *tv, const smg_opts *opts, int64_t *p
                     const uint16_t *labels, uint64_t **records, int64_t *nrec, int *rec_words,
                     char *errbuf, size_t errlen)
 { if (!tv || !plot || !tv->read) return fail(errbuf, errlen, SMG_EINVAL, "null argument%s");
+  struct timespec w0, w1, w2;
+  clock_gettime(CLOCK_MONOTONIC, &w0);       // (the first HIP call of the process -- the free-memory query below -- starts the runtime)
   const int device = opts ? opts->device : 0;
   const int symcheck = opts ? opts->symcheck : SMG_SYM_EXACT;
   const int verbose = opts ? opts->verbose : 0;
@@ -2707,8 +2709,6 @@ static int host_run(const smg_table_source *tv, const smg_opts *opts, int64_t *p
       }
   }
 
-  struct timespec w0, w1, w2;
-  clock_gettime(CLOCK_MONOTONIC, &w0);
   smg_engine *e = smg_engine_create(device, NULL, errbuf, errlen);
   if (!e) return SMG_ENODEV;
   clock_gettime(CLOCK_MONOTONIC, &w1);       // (the first HIP call of the process: runtime start-up + code object load)
