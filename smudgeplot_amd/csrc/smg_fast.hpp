@@ -1125,7 +1125,10 @@ block_scan(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, int64
 }
 
 // marked entries of the bit map -> list[0 .. *count) (entries beyond `cap` are counted, not stored, and keep their
-// bits: the host grows the list and runs another round); a thread takes four map words (128 table entries) per round
+// bits: the host grows the list and runs another round); a thread takes BC_Q x four map words (512 table entries) per
+// round -- independent 16-byte loads in flight together: a round costs two barriers and one returning global atomic,
+// and with one quad per thread the 38 rounds of the 2.5e9-entry table were 0.24 ms of latency for 317 MB
+#define BC_Q 4
 __global__ void __launch_bounds__(BF_TPB)
 kf_collect(uint32_t *__restrict__ dbits, int64_t nwords, uint32_t *__restrict__ list, unsigned cap, unsigned *__restrict__ count)
 { __shared__ unsigned s_n[2], s_base[2];
@@ -1133,19 +1136,26 @@ kf_collect(uint32_t *__restrict__ dbits, int64_t nwords, uint32_t *__restrict__ 
   if (t < 2) s_n[t] = 0;
   __syncthreads();
   const int64_t nquads = nwords >> 2;
-  const int64_t rounds = (nquads + (int64_t) gridDim.x * BF_TPB - 1) / ((int64_t) gridDim.x * BF_TPB);
+  const int64_t per_round = (int64_t) gridDim.x * BF_TPB * BC_Q;
+  const int64_t rounds = (nquads + per_round - 1) / per_round;
   for (int64_t rd = 0; rd < rounds; rd++)
     { const int par = (int) (rd & 1);
-      const int64_t wi = (rd * gridDim.x + blockIdx.x) * (int64_t) BF_TPB + t;
-      uint4 w4 = make_uint4(0, 0, 0, 0);
-      if (wi < nquads) w4 = reinterpret_cast<const uint4 *>(dbits)[wi];
-      const uint32_t w[4] = { w4.x, w4.y, w4.z, w4.w };
-      const unsigned c = (unsigned) (__popc(w[0]) + __popc(w[1]) + __popc(w[2]) + __popc(w[3]));
+      const int64_t w0 = (rd * gridDim.x + blockIdx.x) * (int64_t) (BF_TPB * BC_Q) + t;
+      uint4 w4[BC_Q];
+      unsigned c = 0;
+#pragma unroll
+      for (int q = 0; q < BC_Q; q++)
+        { const int64_t wi = w0 + (int64_t) q * BF_TPB;
+          w4[q] = make_uint4(0, 0, 0, 0);
+          if (wi < nquads) w4[q] = reinterpret_cast<const uint4 *>(dbits)[wi];
+        }
+#pragma unroll
+      for (int q = 0; q < BC_Q; q++) c += (unsigned) (__popc(w4[q].x) + __popc(w4[q].y) + __popc(w4[q].z) + __popc(w4[q].w));
       unsigned pos = 0;
       if (c) pos = atomicAdd(&s_n[par], c);
       __syncthreads();
       const unsigned tot = s_n[par];
-      if (tot == 0) continue;                           // (nothing marked in these 131072 entries)
+      if (tot == 0) continue;                           // (nothing marked in these entries)
       if (t == 0) s_base[par] = atomicAdd(count, tot);
       __syncthreads();
       const unsigned base = s_base[par];
@@ -1153,13 +1163,25 @@ kf_collect(uint32_t *__restrict__ dbits, int64_t nwords, uint32_t *__restrict__ 
       if (c && base + pos + c <= cap)
         { unsigned o = base + pos;
 #pragma unroll
-          for (int j = 0; j < 4; j++)
-            for (uint32_t m = w[j]; m; m &= m - 1) list[o++] = (uint32_t) ((wi * 4 + j) * 32 + __ffs(m) - 1);
-          reinterpret_cast<uint4 *>(dbits)[wi] = make_uint4(0, 0, 0, 0);
+          for (int q = 0; q < BC_Q; q++)
+            { const int64_t wi = w0 + (int64_t) q * BF_TPB;
+              const uint32_t w[4] = { w4[q].x, w4[q].y, w4[q].z, w4[q].w };
+              if (w[0] | w[1] | w[2] | w[3])
+                {
+#pragma unroll
+                  for (int j = 0; j < 4; j++)
+                    for (uint32_t m = w[j]; m; m &= m - 1) list[o++] = (uint32_t) ((wi * 4 + j) * 32 + __ffs(m) - 1);
+                  reinterpret_cast<uint4 *>(dbits)[wi] = make_uint4(0, 0, 0, 0);
+                }
+            }
         }
     }
 }
 
+// (Round 4 tried to solve the listed entries of one long window block together: the wave finds the block's bounds with four
+//  rounds of probes, stages up to 512 k-mers in its corner of LDS and every member looks its 3 (k - p0) flips up there.
+//  Correct -- 255 GPU tests -- and slower: 4.07 instead of 3.39 ms for the 9.4e6 deferred entries of the repeats table
+//  (commit history has bf_group_solve); the per-entry prefix narrowing below stays.)
 // Work is dealt out twice: a workgroup takes a SLAB of BF_SLAB listed entries at a time (global counter: the entries of
 // a repeat region sit next to each other in the list), its waves take 64 of them at a time (LDS counter) and run without
 // a barrier until the slab is done -- a walk through a block of a thousand entries holds up its own wave, not the other
