@@ -1181,7 +1181,8 @@ kf_collect(uint32_t *__restrict__ dbits, int64_t nwords, uint32_t *__restrict__ 
 // (Round 4 tried to solve the listed entries of one long window block together: the wave finds the block's bounds with four
 //  rounds of probes, stages up to 512 k-mers in its corner of LDS and every member looks its 3 (k - p0) flips up there.
 //  Correct -- 255 GPU tests -- and slower: 4.07 instead of 3.39 ms for the 9.4e6 deferred entries of the repeats table
-//  (commit history has bf_group_solve); the per-entry prefix narrowing below stays.)
+//  -- the group search runs for every batch, most long blocks of that table outgrow the stage, and a solved group still pays
+//  4300 vector instructions; the per-entry prefix narrowing below stays.)
 // Work is dealt out twice: a workgroup takes a SLAB of BF_SLAB listed entries at a time (global counter: the entries of
 // a repeat region sit next to each other in the list), its waves take 64 of them at a time (LDS counter) and run without
 // a barrier until the slab is done -- a walk through a block of a thousand entries holds up its own wave, not the other
