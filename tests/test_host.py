@@ -211,3 +211,22 @@ def test_hostile_stub_is_refused_before_any_record_is_touched(tmp_path):
     (tmp_path / ".ovf.ktab.1").write_bytes(bytes(part[:4]) + struct.pack("<q", -5) + bytes(part[12:]))
     r = run(["-e4", "-oneg", "ovf"], tmp_path)
     assert r.returncode == 1 and "truncated or not a FastK table" in r.stderr
+
+
+def test_code_object_hash_and_traffic_file():
+    """bench.py quotes `roofline.traffic` only for the gfx950 code object the PMC passes were read on
+    (smudgeplot_amd/codeobj.py, profiles/hbm_traffic.json): the hash must be computable without a GPU, and every entry of
+    the traffic file must say which code object it belongs to"""
+    import json
+    import warnings
+    from smudgeplot_amd import codeobj
+    h = codeobj.code_object_hash()
+    assert len(h) == 16 and int(h, 16) >= 0
+    assert h == codeobj.code_object_hash()                       # deterministic
+    with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+        doc = json.load(f)
+    assert {"k31", "k51", "k31_repeats", "k31_octoploid", "k51_hexaploid"} <= set(doc)
+    for key, ent in doc.items():
+        assert len(ent["code_object_sha256_16"]) == 16 and ent["bytes_per_entry"]["ms_pass1"] > 0, key
+        if ent["code_object_sha256_16"] != h:
+            warnings.warn(f"profiles/hbm_traffic.json[{key}] was measured on another code object: bench.py will report traffic = null")
