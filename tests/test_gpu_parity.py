@@ -985,7 +985,7 @@ def test_table_source_with_the_reference_binary_as_judge(tmp_path):
 def test_a_table_of_more_than_2_to_the_32_entries():
     """4.4e9 entries (synthetic diploid 1.75 Gbp, k=31): more than a shard can index.  The records live in a device
     tensor and reach the engine through the table-source callback, so the host holds nothing.  Checked: the automatic
-    2-shard run equals a 3-shard run (shard invariance); the pair count is 1.75x the 1 Gbp table's within 2 %; and the
+    2-shard run equals a 3-shard run (shard invariance) and the out-of-core run in four sequential shards; the pair count is 1.75x the 1 Gbp table's within 2 %; and the
     SHAPE of the plot is that of its 1/50 twin (the 35 Mbp table of the same generator, which the test above runs
     through the reference binary): every well filled cell holds 50x the twin's count within 5 sigma of the twin's
     counting noise."""
@@ -1011,6 +1011,15 @@ def test_a_table_of_more_than_2_to_the_32_entries():
     p3, st3 = _run_source_from_device(rec, index, k, n, limit=n // 3 + 1)
     assert st2["nels"] == n and st2["path"] == 1
     assert np.array_equal(p2, p3)
+    # ... and equals the OUT-OF-CORE run of the same table: four shards one after the other, the records pulled twice, no
+    # candidate map, every request looked up from a sorted list -- another protocol and other kernels for the second half
+    # of the computation, the same histogram cell for cell
+    os.environ["SMG_SEQUENTIAL_SHARDS"] = "4"
+    try:
+        p4, st4 = _run_source_from_device(rec, index, k, n)
+    finally:
+        del os.environ["SMG_SEQUENTIAL_SHARDS"]
+    assert st4["nels"] == n and np.array_equal(p2, p4)
     pairs = int(p2.sum())
     assert 0.98 < pairs / (458466309 * 1.75) < 1.02, pairs
     full = twin >= 20000                               # (a cell counts a pair twice: sigma = sqrt(2 c))
