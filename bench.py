@@ -4,10 +4,13 @@
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched under
 torch.distributed.run with one rank per GPU (RCCL).  Rank 0 prints ONE JSON line.
 
-A "step" = one complete hetmers computation (pass 1 -> complement exchange + symmetry proof ->
-pass 2 -> histogram reduction) over the whole device-resident table.  Workload at N=1 is
-BASELINE.json configs[2]: "Synthetic diploid 1 Gbp, 50x cov, k=31" generated on device
-(smudgeplot_amd/synth_device.py); --genome scales it (stated in config.workload).
+A "step" = one complete hetmers computation (pass 1 with the symmetry proof -> complement look-ups /
+exchange -> pass 2 -> histogram reduction) over the whole device-resident table.  The table is handed
+to the engine once, before the timed region, together with its FastK prefix index (what the stub of a
+.ktab file carries; the generator stands in for the file and supplies it: config.directory, --no-index).
+Workload at N=1 is BASELINE.json configs[2]: "Synthetic diploid 1 Gbp, 50x cov, k=31" generated on device
+(smudgeplot_amd/synth_device.py); --genome scales it, --workload picks the repeats / octoploid (configs[3]) /
+hexaploid k=51 (configs[4]) stand-ins (stated in config.workload).
 N>1: STRONG scaling -- the same table, prefix-sharded across the ranks; one all_to_all of the
 complement requests and one all_reduce of the 2-D histogram per step.
 
