@@ -230,3 +230,42 @@ def test_code_object_hash_and_traffic_file():
         assert len(ent["code_object_sha256_16"]) == 16 and ent["bytes_per_entry"]["ms_pass1"] > 0, key
         if ent["code_object_sha256_16"] != h:
             warnings.warn(f"profiles/hbm_traffic.json[{key}] was measured on another code object: bench.py will report traffic = null")
+
+
+@pytest.mark.parametrize("kind", ["octoploid", "hexaploid_k51", "diploid_k51_chunked"])
+def test_polyploid_generators_make_conditioned_tables_the_reference_accepts(kind, tmp_path):
+    """the bench's polyploid stand-ins (synth_device.polyploid_table_graded / polyploid_table_wide), run on the CPU device at
+    toy size: sorted, duplicate free, closed under reverse complement with equal counts -- the REFERENCE binary takes the
+    table as trimmed and symmetric (it would shell out to Logex / Symmex and die otherwise) and its .smu is the numpy oracle's;
+    the device-side FastK writer round-trips through the numpy reader"""
+    import torch
+    import brute
+    from conftest import REF_BIN
+    from smudgeplot_amd import engine, ktab, synth_device
+    if kind == "octoploid":
+        k, L = 31, 8
+        tk, tc = synth_device.polyploid_table_graded(25000, ploidy=8, cov_hap=14.0, k=k, L=L, seed=4, device="cpu")
+    elif kind == "hexaploid_k51":
+        k, L = 51, 5
+        tk, tc = synth_device.polyploid_table_wide(15000, ploidy=6, cov_hap=10.0, k=k, L=L, seed=5, device="cpu", max_chunk=4e4)
+    else:
+        k, L = 51, 10
+        tk, tc = synth_device.polyploid_table_wide(20000, ploidy=2, rates=(0.01,), cov_hap=25.0, k=k, L=L, seed=1, device="cpu", max_chunk=2e4)
+    n = tc.numel()
+    kw = tk.numpy().view(np.uint64).reshape(n, -1)
+    cnt = tc.numpy().view(np.uint16)
+    assert cnt.min() >= L
+    lt = (kw[1:, 0] > kw[:-1, 0])
+    for w in range(1, kw.shape[1]):
+        lt |= (kw[1:, 0] == kw[:-1, 0]) & (kw[1:, w] > kw[:-1, w])
+    assert lt.all()                                               # strictly increasing
+    packed = np.ascontiguousarray(np.ascontiguousarray(kw.astype(">u8")).view(np.uint8).reshape(n, -1)[:, : (k + 3) // 4])
+    synth_device.write_table_from_device(str(tmp_path / "t"), tk, tc, k, nparts=3)
+    T = ktab.read_ktab(str(tmp_path / "t"))
+    assert np.array_equal(T.packed, packed) and np.array_equal(T.counts, cnt)
+    want = engine.smu_text(brute.hetmers_plot(packed, cnt, k))
+    assert want.count("\n") > 20
+    if os.path.exists(REF_BIN):
+        r = subprocess.run([REF_BIN, f"-e{L}", "-T2", "-oref", "t.ktab"], cwd=tmp_path, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert (tmp_path / "ref.smu").read_text() == want
