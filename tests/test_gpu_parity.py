@@ -336,6 +336,19 @@ def test_sharded_driver_on_the_real_backend_one_rank_group(k, symcheck, monkeypa
             plot, st = sharded.hetmers_sharded(k, tk, tc, symcheck=symcheck, eng=st["engine"] if _ else None)
             assert np.array_equal(plot.cpu().numpy().reshape(1001, 501), want)
             assert st["sent"] == st["received"] and st["world"] == 1
+        # the 29-bit map that 8 ranks exchange (TorchEngine.pass1 picks it for world >= 8, which this box cannot be): forced
+        # here, together with the table's prefix index as the shard's look-up directory (what bench.py --gpus N hands over)
+        monkeypatch.setenv("SMG_BM_BITS", "29")
+        eng = sharded.TorchEngine(dev)
+        if k >= 12:
+            kw0 = tk.reshape(len(cnt), -1)[:, 0]
+            index = torch.cumsum(torch.bincount((kw0 >> 40) & 0xFFFFFF, minlength=1 << 24), 0)
+            eng.bind(k, tk, tc, index=index)
+        else:
+            eng.bind(k, tk, tc)
+        for _ in range(2):
+            plot, st = sharded.hetmers_sharded(k, tk, tc, symcheck=symcheck, eng=eng, prebound=True)
+            assert np.array_equal(plot.cpu().numpy().reshape(1001, 501), want)
     finally:
         dist.destroy_process_group()
 
