@@ -1,7 +1,7 @@
 # round-4 measurement set: bench lines, kernel stats, PMC passes (never combined with tracing), traffic entries with the
 # library's hash, forced exchange shares, e2e.  Usage on the GPU box: bash tools/r04_measure.sh [part ...]   (default: all)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04m; mkdir -p $O; cd $R
-PARTS=${@:-"default repeats k51 oct hex k30 shares e2e k51big vshards"}
+PARTS=${@:-"default repeats k51 oct hex k30 shares e2e k51big vshards timeline"}
 J=$O/hbm_traffic.json; cp profiles/hbm_traffic.json $J 2>/dev/null
 line() { grep '^{' $1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); r=d["roofline"]; print(sys.argv[1], "ms/step %.3f" % d["ms_per_step"], {k: round(v,3) for k,v in r["kernel_ms"].items()}, "p1alone %.3f" % r["pass1_kernel_alone_ms"], "frac %.3f" % r["frac"], "traffic", r["traffic"], "cpu", (d.get("cpu_baseline") or {}).get("value"))' $2; }
 prof() {   # prof <tag> <traffic-key> <bench args...>: bench line (with the CPU baseline), kernel stats, PMC passes c + d, traffic entry
@@ -44,6 +44,12 @@ shares)
 e2e)
   ( timeout 900 python tools/e2e_config12.py 4e8 diploid skipT1 ) > $O/e2e_1e9.json 2> $O/e2e_err.txt
   grep -A3 "end_to_end_T\|reference_T\|byte_identical" $O/e2e_1e9.json | grep -v engine_line | cut -c1-200 ;;
+timeline)   # launch-by-launch timeline of one step (start, duration, idle gap in front of each launch)
+  for w in uniform repeats; do
+    ( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/tl_$w -o r04 -- python $R/bench.py --workload $w --steps 4 --warmup 2 --no-cpu > $O/tl_$w.log 2>&1 )
+    python tools/step_timeline.py $O/tl_$w kf_pass1_d > $O/step_timeline_$w.txt 2>&1; rm -rf $O/tl_$w
+    tail -n 2 $O/step_timeline_$w.txt
+  done ;;
 vshards)
   ( E2E_SKIP_REF=1 E2E_VSHARDS=8 timeout 900 python tools/e2e_full_table.py uniform ) > $O/e2e_config3_vshards8.json 2> $O/e2e_vs_err.txt
   grep -v engine_line $O/e2e_config3_vshards8.json | head -40; grep "smg\]" $O/e2e_config3_vshards8.json | cut -c1-400 ;;
