@@ -72,6 +72,62 @@ def test_big_window_blocks():
         assert np.array_equal(plot, want), mode
 
 
+def _long_block_families(k, seed):
+    """families of 120 .. 2600 k-mers that share their first k/2 + 1 bases (one window block each, in buckets of their
+    own): dense ones (a k-mer, all its single mutants behind the shared part, double mutants) and sparse ones (random
+    tails, a few hundred of them with exactly one partner -- often far away in the block), some counts beyond the
+    sum limit, a random background"""
+    rng = np.random.default_rng(seed)
+    share = k // 2 + 1
+    rows = []
+    for f, size in enumerate([120, 400, 1000, 1800, 2600, 150, 700, 1500, 2000, 2300]):
+        base = rng.integers(0, 4, k, dtype=np.uint8)
+        base[0], base[1] = f & 3, f >> 2                       # (a leading 2-mer of its own: never two families in a bucket)
+        fam = np.tile(base, (size, 1))
+        if f < 5:                                              # dense
+            j = 1
+            for p in range(share, k):
+                for d in (1, 2, 3):
+                    if j < size:
+                        fam[j, p] = (base[p] + d) & 3; j += 1
+            while j < size:
+                p, q = rng.integers(share, k, 2)
+                fam[j, p] = (base[p] + rng.integers(1, 4)) & 3
+                fam[j, q] = (base[q] + rng.integers(1, 4)) & 3
+                j += 1
+        else:                                                  # sparse
+            fam[:, share:] = rng.integers(0, 4, (size, k - share), dtype=np.uint8)
+            for j in range(0, min(size - 1, 600), 2):
+                fam[j + 1] = fam[j]
+                p = rng.integers(share, k)
+                fam[j + 1, p] = (fam[j, p] + rng.integers(1, 4)) & 3
+        rows.append(fam)
+    rows.append(rng.integers(0, 4, (3000, k), dtype=np.uint8))
+    packed = ktab.pack_bases(np.concatenate(rows))
+    cnt = rng.integers(5, 60, size=len(packed)).astype(np.uint16)
+    cnt[rng.random(len(cnt)) < 0.04] = 700                     # (pairs of two such counts exceed the sum limit)
+    packed, cnt = ktab.sort_unique_packed(packed, cnt)
+    return ktab.symmetrize(packed, cnt, k)
+
+
+@pytest.mark.parametrize("k", [22, 24, 31, 32, 40, 51, 64])
+def test_long_window_blocks_dense_and_sparse_families(k):
+    """kf_bigfix on window blocks of 120 .. 2600 entries -- dense families (most members own several pairs) and sparse
+    ones (unique partners hundreds of entries away: the far code and kf_pass2_far) -- with the directory pass 1 builds
+    (coarse on a small table) and with the table's 24-bit prefix index as directory (ibyte = 3: one bucket per block at
+    k = 24, finer than the blocks at k = 22), one- and two-word k-mers, counts beyond the sum limit -- against the
+    numpy oracle.  (Written for the round-4 attempt to solve such blocks from an LDS copy of their directory bucket,
+    profiles/r04_pass1_experiments.txt; it holds for any kf_bigfix.)"""
+    packed, cnt = _long_block_families(k, 300 + k)
+    want = brute.hetmers_plot(packed, cnt, k)
+    assert want.sum() > 500
+    for ibyte in (1, 3):
+        for mode in ("hash", "exact"):
+            plot, st = engine.hetmers_run(table_from(packed, cnt, k, ibyte=ibyte), symcheck=mode)
+            assert st["path"] == 1 and st["nbig"] > 5000, st
+            assert np.array_equal(plot, want), (k, ibyte, mode)
+
+
 def test_asymmetric_tables_fall_back_to_the_general_path():
     """tables that are NOT reverse-complement closed (the reference only probes entry #1)"""
     k = 31
