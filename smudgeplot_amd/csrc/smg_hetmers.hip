@@ -1295,6 +1295,21 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
                               grid, grid + BF_MAXGRID, e->lg.nb, e->farp)
           if (e->W == 2 && e->rw == 2) BIGFIX(2, 2); else if (e->W == 2) BIGFIX(2, 3); else if (e->rw == 1) BIGFIX(1, 1); else BIGFIX(1, 2);
 #undef BIGFIX
+#ifdef SMG_BF_INSTR
+          { unsigned long long h[64], z[64] = { 0 };     // tuning builds only: see g_bf_instr
+            hipStreamSynchronize(e->stream);
+            hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bf_instr), sizeof h);
+            hipMemcpyToSymbol(HIP_SYMBOL(g_bf_instr), z, sizeof z);
+            static const char *nm[9] = { "linear", "<128", "<256", "<512", "<1024", "<2048", "<16384", "<131072", "more" };
+            for (int c = 0; c < 9; c++)
+              if (h[c] || h[16 + c])
+                fprintf(stderr, "[bf] block %-8s entries %10llu  batches %8llu  cycles/batch %10.0f\n", nm[c], h[c], h[16 + c],
+                        h[16 + c] ? (double) h[32 + c] / (double) h[16 + c] : 0.0);
+            fprintf(stderr, "[bf] slabs %llu  walk phase %.0f cycles/slab  write-out %.0f cycles/slab  workgroups %llu  %.0f cycles each\n", h[50],
+                    h[50] ? (double) h[48] / (double) h[50] : 0.0, h[50] ? (double) h[49] / (double) h[50] : 0.0, h[52],
+                    h[52] ? (double) h[51] / (double) h[52] : 0.0);
+          }
+#endif
           hipEventRecord(e->ev[3], e->stream);
           HIPCHK(hipGetLastError());
         }
