@@ -1088,6 +1088,54 @@ block_scan(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, int64
   // neighbours are therefore fetched eight at a time, independent loads in flight together -- a walk of one
   // dependent load per step took 0.19 us per entry with every lane of the chip busy.
   const Key<W> x = load_key<W>(keys, i);
+#ifdef SMG_BF_NEAR
+  // Tuning builds only (-DSMG_BF_NEAR): the eight nearest neighbours on either side FIRST, and the two far probes -- two more
+  // 128-byte requests of the entry's ~5.6 -- only for a side whose block is still open behind them (a listed entry's block
+  // reaches at least four entries away, that is why pass 1 deferred it; few reach past eight).
+  { const unsigned c = cnt[i];
+    s_all = 0; s_hi = 0; partner = -1; w2 = 0;
+    bool open[2] = { true, true };
+#pragma unroll 1
+    for (int base = 1; base <= BF_LIN; base += 8)
+      { if (base == 9)
+          { if (!open[0] && !open[1]) return;
+            const int64_t lo = i - BF_LIN - 1, hi = i + BF_LIN + 1;
+            const bool far_lo = open[0] && lo >= 0 && same_block<W>(x, load_key<W>(keys, lo >= 0 ? lo : i), g);
+            const bool far_hi = open[1] && hi < n && same_block<W>(x, load_key<W>(keys, hi < n ? hi : i), g);
+            if (far_lo || far_hi) { big_block_walk<W>(keys, cnt, n, g, i, s_all, s_hi, partner, w2, block_len); return; }
+          }
+#pragma unroll 1
+        for (int side = 0; side < 2; side++)
+          if (open[side])
+            { const int dir = side ? 1 : -1;
+              Key<W> y[8]; unsigned cy[8]; bool in[8];
+#pragma unroll
+              for (int j = 0; j < 8; j++)
+                { const int64_t q = i + (int64_t) dir * (base + j);
+                  in[j] = q >= 0 && q < n;
+                  y[j] = load_key<W>(keys, in[j] ? q : i);
+                  cy[j] = cnt[in[j] ? q : i];
+                }
+              bool op = true;
+#pragma unroll
+              for (int j = 0; j < 8; j++)
+                { op = op && in[j] && same_block<W>(x, y[j], g);
+                  if (op)
+                    { const int p = pair_pos<W>(x, y[j]);
+                      if (p >= 0 && c + cy[j] <= SMG_SMAX)
+                        { const unsigned h = (p != g.k - 1 - p);
+                          if (s_all == 0) { partner = i + (int64_t) dir * (base + j); w2 = h; }
+                          s_all++; s_hi += h;
+                        }
+                    }
+                }
+              open[side] = op;
+            }
+        if (!open[0] && !open[1]) return;
+      }
+    return;
+  }
+#endif
   // a block that reaches past the linear range on either side goes straight to the bisection
   { const int64_t lo = i - BF_LIN - 1, hi = i + BF_LIN + 1;
     const bool far_lo = lo >= 0 && same_block<W>(x, load_key<W>(keys, lo >= 0 ? lo : i), g);
@@ -1196,7 +1244,8 @@ kf_collect(uint32_t *__restrict__ dbits, int64_t nwords, uint32_t *__restrict__ 
 // class is 0 when its block is walked linearly, else 1 + the bin of its block's length (< 128, 256, 512, 1024, 2048, 16384,
 // 131072, more); a 64-entry batch has the class of its longest block.  [c]: entries, [16 + c]: batches, [32 + c]: shader
 // cycles the batches took; [48]: cycles of thread 0 in the slabs' walk phase, [49]: in their request write-out, [50]: slabs,
-// [51] / [52]: cycles of the workgroups from start to end / workgroups.
+// [51] / [52]: cycles of the workgroups from start to end / workgroups; [53..55] / [56]: cycles of the batches in the scan (its
+// loads), in issuing the entry's stores and map atomic, in waiting for those to drain / batches.
 __device__ unsigned long long g_bf_instr[64];
 SMG_DEV unsigned bf_class(int64_t len)
 { if (len <= 0) return 0;
@@ -1252,8 +1301,8 @@ kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, const unsigned *__re
               int64_t blen = 0;
               const long long c0 = clock64();
               block_scan<W>(A.keys, A.cnt, A.n, A.g, i, s_all, s_hi, partner, w2, &blen);
-              { const long long c1 = clock64();
-                const unsigned cls = bf_class(blen);
+              const long long c1 = clock64();
+              { const unsigned cls = bf_class(blen);
                 unsigned mx = cls;
                 for (int o = 32; o; o >>= 1) { const unsigned v = (unsigned) __shfl_xor((int) mx, o); mx = v > mx ? v : mx; }
                 atomicAdd(&s_instr[cls], 1ull);
@@ -1266,12 +1315,24 @@ kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, const unsigned *__re
               const unsigned code = make_code(s_all, partner - i, w2);
               A.code[i] = (uint8_t) code;
               if ((code & 63) == CODE_FAR) farp[r] = (uint32_t) partner;
+#ifndef SMG_BF_NOATOMIC                                       /* (timing experiment: the run's result is wrong without the marks) */
               if (W <= 2 && A.bmap && s_all == 1)             // a candidate: mark its block for the request filter
                 { const uint32_t id = (uint32_t) (A.keys[i * W] >> 32) >> A.bmsh;
                   if (A.bm2) atomicOr(reinterpret_cast<u64 *>(A.bmap) + (id >> 5), bm2_bits(id, (uint32_t) A.keys[i * W]));
                   else atomicOr(&A.bmap[id >> 5], 1u << (id & 31));
                 }
+#endif
               if (s_hi > 0) slist[atomicAdd(&s_nl, 1u)] = (uint32_t) i;
+#ifdef SMG_BF_INSTR
+              { const long long c2 = clock64();                // (the stores and the atomic of this batch drained here, so that the
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   //  next batch's first wait is for its own loads only)
+                const long long c3 = clock64();
+                if (lane == __ffsll((long long) __ballot(1)) - 1)
+                  { atomicAdd(&s_instr[53], (unsigned long long) (c1 - c0)); atomicAdd(&s_instr[54], (unsigned long long) (c2 - c1));
+                    atomicAdd(&s_instr[55], (unsigned long long) (c3 - c2)); atomicAdd(&s_instr[56], 1ull);
+                  }
+              }
+#endif
             }
         }
       __syncthreads();

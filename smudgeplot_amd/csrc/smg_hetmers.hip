@@ -1308,6 +1308,9 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
             fprintf(stderr, "[bf] slabs %llu  walk phase %.0f cycles/slab  write-out %.0f cycles/slab  workgroups %llu  %.0f cycles each\n", h[50],
                     h[50] ? (double) h[48] / (double) h[50] : 0.0, h[50] ? (double) h[49] / (double) h[50] : 0.0, h[52],
                     h[52] ? (double) h[51] / (double) h[52] : 0.0);
+            if (h[56])
+              fprintf(stderr, "[bf] per batch: scan %.0f  issue of stores + map atomic %.0f  their drain %.0f cycles\n", (double) h[53] / (double) h[56],
+                      (double) h[54] / (double) h[56], (double) h[55] / (double) h[56]);
           }
 #endif
           hipEventRecord(e->ev[3], e->stream);
