@@ -1088,54 +1088,6 @@ block_scan(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, int64
   // neighbours are therefore fetched eight at a time, independent loads in flight together -- a walk of one
   // dependent load per step took 0.19 us per entry with every lane of the chip busy.
   const Key<W> x = load_key<W>(keys, i);
-#ifdef SMG_BF_NEAR
-  // Tuning builds only (-DSMG_BF_NEAR): the eight nearest neighbours on either side FIRST, and the two far probes -- two more
-  // 128-byte requests of the entry's ~5.6 -- only for a side whose block is still open behind them (a listed entry's block
-  // reaches at least four entries away, that is why pass 1 deferred it; few reach past eight).
-  { const unsigned c = cnt[i];
-    s_all = 0; s_hi = 0; partner = -1; w2 = 0;
-    bool open[2] = { true, true };
-#pragma unroll 1
-    for (int base = 1; base <= BF_LIN; base += 8)
-      { if (base == 9)
-          { if (!open[0] && !open[1]) return;
-            const int64_t lo = i - BF_LIN - 1, hi = i + BF_LIN + 1;
-            const bool far_lo = open[0] && lo >= 0 && same_block<W>(x, load_key<W>(keys, lo >= 0 ? lo : i), g);
-            const bool far_hi = open[1] && hi < n && same_block<W>(x, load_key<W>(keys, hi < n ? hi : i), g);
-            if (far_lo || far_hi) { big_block_walk<W>(keys, cnt, n, g, i, s_all, s_hi, partner, w2, block_len); return; }
-          }
-#pragma unroll 1
-        for (int side = 0; side < 2; side++)
-          if (open[side])
-            { const int dir = side ? 1 : -1;
-              Key<W> y[8]; unsigned cy[8]; bool in[8];
-#pragma unroll
-              for (int j = 0; j < 8; j++)
-                { const int64_t q = i + (int64_t) dir * (base + j);
-                  in[j] = q >= 0 && q < n;
-                  y[j] = load_key<W>(keys, in[j] ? q : i);
-                  cy[j] = cnt[in[j] ? q : i];
-                }
-              bool op = true;
-#pragma unroll
-              for (int j = 0; j < 8; j++)
-                { op = op && in[j] && same_block<W>(x, y[j], g);
-                  if (op)
-                    { const int p = pair_pos<W>(x, y[j]);
-                      if (p >= 0 && c + cy[j] <= SMG_SMAX)
-                        { const unsigned h = (p != g.k - 1 - p);
-                          if (s_all == 0) { partner = i + (int64_t) dir * (base + j); w2 = h; }
-                          s_all++; s_hi += h;
-                        }
-                    }
-                }
-              open[side] = op;
-            }
-        if (!open[0] && !open[1]) return;
-      }
-    return;
-  }
-#endif
   // a block that reaches past the linear range on either side goes straight to the bisection
   { const int64_t lo = i - BF_LIN - 1, hi = i + BF_LIN + 1;
     const bool far_lo = lo >= 0 && same_block<W>(x, load_key<W>(keys, lo >= 0 ? lo : i), g);
@@ -1315,13 +1267,11 @@ kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, const unsigned *__re
               const unsigned code = make_code(s_all, partner - i, w2);
               A.code[i] = (uint8_t) code;
               if ((code & 63) == CODE_FAR) farp[r] = (uint32_t) partner;
-#ifndef SMG_BF_NOATOMIC                                       /* (timing experiment: the run's result is wrong without the marks) */
               if (W <= 2 && A.bmap && s_all == 1)             // a candidate: mark its block for the request filter
                 { const uint32_t id = (uint32_t) (A.keys[i * W] >> 32) >> A.bmsh;
                   if (A.bm2) atomicOr(reinterpret_cast<u64 *>(A.bmap) + (id >> 5), bm2_bits(id, (uint32_t) A.keys[i * W]));
                   else atomicOr(&A.bmap[id >> 5], 1u << (id & 31));
                 }
-#endif
               if (s_hi > 0) slist[atomicAdd(&s_nl, 1u)] = (uint32_t) i;
 #ifdef SMG_BF_INSTR
               { const long long c2 = clock64();                // (the stores and the atomic of this batch drained here, so that the
