@@ -11,8 +11,10 @@ to the engine once, before the timed region, together with its FastK prefix inde
 Workload at N=1 is BASELINE.json configs[2]: "Synthetic diploid 1 Gbp, 50x cov, k=31" generated on device
 (smudgeplot_amd/synth_device.py); --genome scales it, --workload picks the repeats / octoploid (configs[3]) /
 hexaploid k=51 (configs[4]) stand-ins (stated in config.workload).
-N>1: STRONG scaling -- the same table, prefix-sharded across the ranks; one all_to_all of the
-complement requests and one all_reduce of the 2-D histogram per step.
+N>1: STRONG scaling -- the same table, prefix-sharded across the ranks (every rank generates its own shard, none holds
+the whole table); one all_to_all of the complement requests and one all_reduce of the 2-D histogram per step.
+After the timed loop the plot of the last step is rendered as .smu text and compared with the REFERENCE binary's output
+for this very table (tests/golden/bench_<workload>.smu; "parity" in the JSON line); a mismatch exits non-zero.
 
 value = table entries (k-mers) x steps / wall time, wall = max over ranks between barriers.
 """
@@ -55,32 +57,67 @@ def default_genome(workload: str, k: int = 31) -> int:
     return {"uniform": 10 ** 9, "repeats": 10 ** 9, "octoploid": 2 * 10 ** 8, "hexaploid": 4 * 10 ** 8}[workload]
 
 
-def make_table(workload: str, G: int, k: int, dev, seed: int = 1):
-    """-> (keys, counts, L, description): the conditioned (trimmed, rc-closed) table of a workload, generated on `dev`"""
+def make_table(workload: str, G: int, k: int, dev, seed: int = 1, key_range=None):
+    """-> (keys, counts, L, description): the conditioned (trimmed, rc-closed) table of a workload, generated on `dev`.
+    key_range = synth_device.key_range_of(rank, world): only this rank's prefix shard of that table (N > 1: no rank ever
+    holds the whole table; the shards of all ranks, in rank order, are the table of N = 1 entry for entry)"""
+    kr = {} if key_range is None else {"key_range": key_range}
     if workload in ("uniform", "repeats"):
         L = 10
         rep = 0.05 if workload == "repeats" else 0.0
         if k <= 31:
-            keys, cnt = synth_device.diploid_table(G, k=k, het=0.01, cov=50.0, L=L, seed=seed, device=dev, repeats=rep)
-        elif G <= 5 * 10 ** 8:                 # two-word k-mers (BASELINE configs[4] is k=51); keys is [n, 2]
+            keys, cnt = synth_device.diploid_table(G, k=k, het=0.01, cov=50.0, L=L, seed=seed, device=dev, repeats=rep, **kr)
+        elif G <= 5 * 10 ** 8 and key_range is None:   # two-word k-mers (BASELINE configs[4] is k=51); keys is [n, 2]
             keys, cnt = synth_device.diploid_table_wide(G, k=k, het=0.01, cov=50.0, L=L, seed=seed, device=dev)
         else:                                  # the same model generated chunk by chunk of the key space (1 Gbp fits)
-            keys, cnt = synth_device.polyploid_table_wide(G, ploidy=2, rates=(0.01,), cov_hap=25.0, k=k, L=L, seed=seed, device=dev)
+            keys, cnt = synth_device.polyploid_table_wide(G, ploidy=2, rates=(0.01,), cov_hap=25.0, k=k, L=L, seed=seed, device=dev, **kr)
         desc = f"synthetic diploid {G:.3g} bp, 50x, 1% het, k={k}, L={L}" + \
                (", 5% of the genome repeats (dispersed, tandem, homopolymer)" if rep else "")
     elif workload == "octoploid":
         assert k <= 31
         L = 8
-        keys, cnt = synth_device.polyploid_table_graded(G, ploidy=8, cov_hap=14.0, k=k, L=L, seed=3 + seed, device=dev)
+        keys, cnt = synth_device.polyploid_table_graded(G, ploidy=8, cov_hap=14.0, k=k, L=L, seed=3 + seed, device=dev, **kr)
         desc = (f"synthetic octoploid {G:.3g} bp x 8 haplotypes, graded divergences (variant sets carried by 1, 2, 3 and 4 of 8 "
                 f"haplotypes at 0.1 / 0.15 / 0.1 / 0.2 %), 14x per haplotype, k={k}, L={L}")
     else:
         assert 33 <= k <= 64
         L = 5
-        keys, cnt = synth_device.polyploid_table_wide(G, ploidy=6, cov_hap=10.0, k=k, L=L, seed=4 + seed, device=dev)
+        keys, cnt = synth_device.polyploid_table_wide(G, ploidy=6, cov_hap=10.0, k=k, L=L, seed=4 + seed, device=dev, **kr)
         desc = (f"synthetic hexaploid {G:.3g} bp x 6 haplotypes, graded divergences (variant sets carried by 1, 2 and 3 of 6 "
                 f"haplotypes at 0.1 / 0.15 / 0.2 %), 10x per haplotype, k={k}, L={L}")
     return keys, cnt, L, desc
+
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def parity_against_golden(workload: str, G: int, k: int, n_total: int, hk: int, hc: int, plot) -> dict:
+    """Compare the plot of the last timed step with what the REFERENCE binary (PloidyPlot.c, compiled from the reference's
+    own sources) wrote for this very table: tests/golden/bench_<workload>.smu, made on the GPU box by
+    tools/make_bench_goldens.py together with the table's checksum (tests/golden/bench_tables.json).  The table is
+    identified by synth_device.table_hash (an order-sensitive checksum of every k-mer word and count, summed over the
+    ranks), the result by the bytes of the .smu text (PloidyPlot.c:1603-1617).  ok = None: no golden for this size."""
+    import hashlib
+    th = synth_device.table_hash_text(n_total, hk, hc)
+    out = {"vs": "reference binary golden", "table_hash": th, "ok": None}
+    tj = os.path.join(GOLDEN_DIR, "bench_tables.json")
+    if not os.path.exists(tj):
+        out["reason"] = "tests/golden/bench_tables.json is missing"
+        return out
+    with open(tj) as f:
+        g = json.load(f).get(workload)
+    if not g or int(g["genome"]) != int(G) or int(g["k"]) != int(k):
+        out["reason"] = "no golden for this workload at this size (the goldens are the default sizes)"
+        return out
+    smu = engine.smu_text(plot.cpu().numpy().reshape(engine.PLOT_ROWS, engine.PLOT_COLS))
+    out["smu_sha256"] = hashlib.sha256(smu.encode()).hexdigest()
+    out["golden"] = "tests/golden/" + g["smu_file"]
+    out["same_table"] = g["table_hash"] == th
+    with open(os.path.join(GOLDEN_DIR, g["smu_file"])) as f:
+        out["ok"] = bool(out["same_table"] and f.read() == smu)
+    if not out["same_table"]:
+        out["reason"] = "the generator produced another table than the one the golden was made on (%s)" % g["table_hash"]
+    return out
 
 
 def lib_hash() -> str:
@@ -153,33 +190,45 @@ def main():
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
 
-    # ---- workload: identical table on every rank, then keep this rank's prefix shard ----------
+    # ---- workload: every rank generates ITS prefix shard only (the generators cut the key space; no rank holds the table)
     G = int(args.genome)
-    keys, cnt, L, desc = make_table(args.workload, G, args.k, dev)
-    n_total = cnt.numel()
+    words = (args.k + 31) // 32
+    key_range = synth_device.key_range_of(rank, world) if world > 1 else None
+    keys, cnt, L, desc = make_table(args.workload, G, args.k, dev, key_range=key_range)
+    n_local = cnt.numel()
     kw0 = keys if keys.dim() == 1 else keys[:, 0]          # the word that holds the window-block prefix
+    sizes = [n_local]
+    if world > 1:
+        mine = torch.tensor([n_local], dtype=torch.int64, device=dev)
+        allv = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        sizes = [int(v) for v in torch.cat(allv).cpu().tolist()]
+    n_total = sum(sizes)
+    first_entry = sum(sizes[:rank])
     # A FastK table comes with its prefix index (entries up to every 3-byte prefix: the stub of the .ktab file,
     # libfastk.c:841); the generator stands in for the table file, so it supplies the index too -- the engine takes it
-    # as its look-up directory (the `hetmers` executable hands over the index it read from the stub the same way)
-    index, first_entry = None, 0
+    # as its look-up directory (the `hetmers` executable hands over the index it read from the stub the same way).
+    # The index is the WHOLE table's (every rank's shard starts at entry `first_entry` of it): bucket counts summed over ranks
+    index = None
     if not args.no_index:
-        index = torch.cumsum(torch.bincount((kw0 >> 40) & 0xFFFFFF, minlength=1 << 24), 0)
+        per = torch.bincount((kw0 >> 40) & 0xFFFFFF, minlength=1 << 24)
+        if world > 1:
+            dist.all_reduce(per, op=dist.ReduceOp.SUM)
+        index = torch.cumsum(per, 0)
+        del per
+    # splitters of the sharded run = the cut values the shards were generated by (lower bound of every rank's k-mer range)
+    splitters = None
     if world > 1:
-        cuts = [0]
-        sh = 64 - 2 * min(32, args.k // 2)
-        pref = kw0 >> sh
+        splitters = np.zeros((world - 1, words), dtype=np.uint64)
         for r in range(1, world):
-            c = (n_total * r) // world
-            # move the cut to a window-block boundary (first k//2 bases differ)
-            while c < n_total and int(pref[c]) == int(pref[c - 1]):
-                c += 1
-            cuts.append(c)
-        cuts.append(n_total)
-        lo, hi = cuts[rank], cuts[rank + 1]
-        keys = keys[lo:hi].clone()
-        cnt = cnt[lo:hi].clone()
-        first_entry = lo
-        del pref
+            splitters[r - 1, 0] = np.uint64(synth_device.key_range_of(r, world)[0]) << np.uint64(48)
+        splitters = splitters.reshape(-1)
+    # checksum of the table (summed over the ranks): what the golden .smu of the parity block was made on
+    hk, hc = synth_device.table_hash(keys, cnt, first_entry=first_entry)
+    if world > 1:
+        hv = torch.tensor([hk - (1 << 64) if hk >> 63 else hk, hc - (1 << 64) if hc >> 63 else hc], dtype=torch.int64, device=dev)
+        dist.all_reduce(hv, op=dist.ReduceOp.SUM)
+        hk, hc = [int(v) & 0xFFFFFFFFFFFFFFFF for v in hv.cpu().tolist()]
     del kw0
     keys = keys.reshape(-1)
     torch.cuda.synchronize()
@@ -191,7 +240,8 @@ def main():
     del index
 
     def step():
-        plot, st = sharded.hetmers_sharded(args.k, keys, cnt, symcheck=args.symcheck, eng=eng, prebound=True)
+        plot, st = sharded.hetmers_sharded(args.k, keys, cnt, symcheck=args.symcheck, eng=eng, prebound=True,
+                                           splitters=splitters, sizes=sizes if world > 1 else None)
         st.pop("engine", None)
         eng_stats.append(st)
         return plot
@@ -216,7 +266,6 @@ def main():
 
     # ---- roofline of the dominant kernel, from HIP events recorded by the engine on its stream
     ms = {key: float(np.mean([s[key] for s in eng_stats])) for key in ("ms_pass1", "ms_rclookup", "ms_pass2")}
-    n_local = cnt.numel()
     nreq = float(np.mean([s.get("nemitted", s["nrequests"]) for s in eng_stats]))   # requests pass 1 emitted
     nkept = float(np.mean([s["nrequests"] for s in eng_stats]))                     # ... and the filter kept
     ms_filter = float(np.mean([s.get("ms_filter", 0.0) for s in eng_stats]))
@@ -255,6 +304,7 @@ def main():
                     t.get("code_object_sha256_16"), lib_hash())
 
     if rank == 0:
+        parity = parity_against_golden(args.workload, G, args.k, n_total, hk, hc, plot)
         # the CPU baseline is timed on rank 0 of the single-GPU run only (it takes ~25 s of host time)
         cpu = None
         if not (args.no_cpu or world > 1):
@@ -285,12 +335,17 @@ def main():
                          "whole_job_frac_of_the_B_alg_roofline":
                              (n_total * 2.0 * alg_bytes_per_kmer_pass(args.k) / (dt / args.steps)) / 1e9 / (HBM_PEAK_GBS * world)},
             "cpu_baseline": cpu,
+            # the plot of the last TIMED step against the reference binary's .smu of this very table (outside the timed region)
+            "parity": parity,
             "pairs_in_plot": int(plot.sum().item()),
             "hbm_peak_allocated_by_torch_GB": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),     # (the generator's peak)
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0 and parity["ok"] is False:
+        raise SystemExit("bench.py: the plot of the timed run differs from the reference binary's .smu of this table (%s)"
+                         % parity.get("golden"))
 
 
 if __name__ == "__main__":

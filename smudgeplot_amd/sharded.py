@@ -58,9 +58,28 @@ class TorchEngine:
         self._keep = (keys, counts)
         self.words = (k + 31) // 32
         self.e.bind(k, counts.numel(), keys.data_ptr(), counts.data_ptr())
+        # what the engine is bound to: hetmers_sharded(prebound=True) checks it (a run that failed the symmetry proof
+        # leaves rank 0's engine on the GATHERED table, see _general_on_rank0) and binds again when it does not match
+        self._bound = (keys.data_ptr(), counts.numel())
+        self._index = None
         if index is not None:
+            # the engine reads 2^24 int64 words from this pointer: anything else is an out-of-bounds read on the device
+            if not (index.dtype == torch.int64 and index.numel() == 1 << 24 and index.is_contiguous()
+                    and index.device == keys.device):
+                raise ValueError("prefix index: need a contiguous int64 tensor of 2^24 words on the table's device "
+                                 "(entries up to every 3-byte prefix, libfastk.c:841)")
             self.e.set_prefix_index(index.data_ptr(), 3, first_entry)
-            torch.cuda.current_stream(self.device).synchronize()      # (the index may go away after this call)
+            # (kept: the directory kernel runs on the ENGINE's stream, which need not be torch's current one, and a
+            #  re-bind after a fallback hands the index over again)
+            self._index = (index, first_entry, keys.data_ptr(), counts.numel())
+
+    def rebind(self, k, keys, counts):
+        """bind again, with the prefix index of the last bind if these are the tensors it was given for"""
+        ix = getattr(self, "_index", None)
+        if ix is not None and ix[2:] == (keys.data_ptr(), counts.numel()):
+            self.bind(k, keys, counts, index=ix[0], first_entry=ix[1])
+        else:
+            self.bind(k, keys, counts)
 
     def pass1(self, symcheck, exchange=True, world=1):
         # nobody to exchange block maps with: the finest map (32 id bits) costs nothing but its memset.  Exchanged maps:
@@ -115,6 +134,7 @@ class TorchEngine:
     def run_general(self, k, keys, counts, plot):
         """the assumption-free all-positions path on a whole table (what one GPU does when the proof fails)"""
         self.e.bind(k, counts.numel(), keys.data_ptr(), counts.data_ptr())
+        self._bound = None                    # (not the shard any more: a later prebound=True call binds again)
         return self.e.run(plot.data_ptr(), "none")
 
     def filter(self, full_map=None):
@@ -293,7 +313,7 @@ def condition_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, ethresh:
 
 def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: str = "hash",
                     engine_factory=TorchEngine, group=None, eng=None, fallback: bool = True, splitters=None,
-                    prebound: bool = False):
+                    prebound: bool = False, sizes=None):
     """Run hetmers on this rank's shard; returns (plot int64[1001*501] on the shard's device,
     summed over all ranks, and a stats dict).  Collective: every rank must call it.
 
@@ -305,7 +325,12 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
              (False: raise NotSymmetric instead)
     keys = counts = None with `eng` and `splitters` from condition_sharded: the engine owns the shard already
     prebound: `eng` is bound to exactly these tensors already (eng.bind, possibly with the table's prefix index): the
-             table is not bound again, so what the engine knows about it (index directory, first / last k-mer) stays
+             table is not bound again, so what the engine knows about it (index directory, first / last k-mer) stays.
+             The k-mers must not change while bound (counts may).  If the engine is found bound to something else -- the
+             run before failed the symmetry proof and left rank 0 on the gathered table -- the shard is bound again.
+    splitters: lower bounds of the k-mer ranges of ranks 1..world-1 (W words each), e.g. the cut values a table was
+             generated or cut by; `sizes` (entries per rank) with them saves the all_gather of the shard sizes that the
+             fall-back on rank 0 needs
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -326,7 +351,13 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
         if eng is None:
             eng = engine_factory(dev)
             prebound = False
-        if not prebound:
+        if prebound and getattr(eng, "_bound", (keys.data_ptr(), n)) != (keys.data_ptr(), n):
+            if hasattr(eng, "rebind"):
+                eng.rebind(k, keys, counts)
+            else:
+                eng.bind(k, keys, counts)
+            eng._splitter_cache = None
+        elif not prebound:
             eng.bind(k, keys, counts)
 
     # splitters = first k-mer of ranks 1..world-1 (an empty shard inherits its successor's).  They depend
@@ -334,8 +365,9 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
     tag = (0 if owned else keys.data_ptr(), n, world, rank)
     cached = getattr(eng, "_splitter_cache", None)
     if splitters is not None:
-        splitters, sizes = np.ascontiguousarray(splitters, dtype=np.uint64).reshape(-1), None
-        if not owned and fallback and exchange:
+        splitters = np.ascontiguousarray(splitters, dtype=np.uint64).reshape(-1)
+        sizes = [int(v) for v in sizes] if sizes is not None else None
+        if sizes is None and not owned and fallback and exchange:
             # the caller's splitters come without shard sizes, and the general path on rank 0 needs them: one
             # all_gather, as in the uncached branch (without it rank 0 raised while the others sat in dist.send)
             mine = torch.tensor([n], dtype=torch.int64, device=dev)

@@ -85,13 +85,28 @@ def _plant_repeats(h1: torch.Tensor, frac: float, gen) -> None:
     h1[(starts[:, None] + ar[None, :300]).reshape(-1)] = base[:, None].expand(nrun, 300).reshape(-1)
 
 
+def key_range_of(rank: int, world: int):
+    """[lo, hi) of the LEADING 16 KEY BITS that rank `rank` of `world` owns when a table is generated shard by shard:
+    equal slices of the key space (a uniform random genome fills it evenly), cut on 8-base boundaries -- which are
+    window-block boundaries for every k >= 16, so the shards are the prefix shards of the sharded run and the cut values
+    (lo << 48, left aligned) are its splitters.  The shards of all ranks, in rank order, ARE the table of world = 1."""
+    return (rank * 65536) // world, ((rank + 1) * 65536) // world
+
+
+def _in_range16(lead16: torch.Tensor, key_range) -> torch.Tensor:
+    return (lead16 >= key_range[0]) & (lead16 < key_range[1])
+
+
 def diploid_table(G: int, k: int = 31, het: float = 0.01, cov: float = 50.0, L: int = 10,
-                  seed: int = 1, device="cuda", chunks: int = 1, repeats: float = 0.0):
+                  seed: int = 1, device="cuda", chunks: int = 1, repeats: float = 0.0, key_range=None):
     """-> (keys int64 viewing LEFT-aligned uint64 k-mers, sorted as unsigned; counts int16
     viewing uint16).  k <= 31 so the right-aligned value is non-negative and sorts correctly.
     repeats > 0: that fraction of the genome is repeats (see _plant_repeats) and a k-mer's coverage scales with
-    its copy number."""
+    its copy number.
+    key_range = key_range_of(rank, world): only the entries whose leading 16 key bits lie in that range (one rank's
+    shard of the table: the genome is the same on every rank, the k-mers outside the range are dropped before the sort)."""
     assert k <= 31
+    assert key_range is None or k >= 16
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
     h1 = torch.randint(0, 4, (G,), dtype=torch.uint8, device=device, generator=gen)
@@ -102,8 +117,22 @@ def diploid_table(G: int, k: int = 31, het: float = 0.01, cov: float = 50.0, L: 
     del snp, delta
     km = [_kmers_of(h1, k), _kmers_of(h2, k)]
     del h1, h2
+    if key_range is not None:         # this rank's k-mers of both strands (a complement may fall into the range when its k-mer does not)
+        own = []
+        for a in km:
+            own.append(a[_in_range16(a >> (2 * k - 16), key_range)])
+            r = _revcomp_right(a, k)
+            own.append(r[_in_range16(r >> (2 * k - 16), key_range)])
+            del r
+        del km
+        return _diploid_finish(own, k, cov, L, repeats, device, both_strands=False)
+    return _diploid_finish(km, k, cov, L, repeats, device, both_strands=True)
+
+
+def _diploid_finish(km, k, cov, L, repeats, device, both_strands: bool):
+    """occurrence lists (right-aligned k-mers; both_strands: their complements are added here) -> the sorted, counted table"""
     # torch.unique (rocPRIM) takes < 2^31 elements: split the key space by leading bits
-    total = 4 * km[0].numel()
+    total = 4 * km[0].numel() if both_strands else sum(a.numel() for a in km)
     nchunk = 1
     while total / nchunk > 1.2e9:
         nchunk *= 2
@@ -114,11 +143,14 @@ def diploid_table(G: int, k: int = 31, het: float = 0.01, cov: float = 50.0, L: 
         sel = []
         for a in km:
             sel.append(a[(a >> shift) == c] if cb else a)
-            r = _revcomp_right(a, k)
-            sel.append(r[(r >> shift) == c] if cb else r)
-            del r
+            if both_strands:
+                r = _revcomp_right(a, k)
+                sel.append(r[(r >> shift) == c] if cb else r)
+                del r
         allk = torch.cat(sel)
         del sel
+        if allk.numel() == 0:
+            continue
         keys, mult = torch.unique(allk, sorted=True, return_counts=True)
         del allk
         # multiplicity 2+ => present in both haplotypes (or a genomic repeat): homozygous coverage
@@ -139,8 +171,10 @@ def diploid_table(G: int, k: int = 31, het: float = 0.01, cov: float = 50.0, L: 
         key_parts.append(keys)
         cnt_parts.append(cnt)
     del km
-    keys = torch.cat(key_parts) if nchunk > 1 else key_parts[0]
-    cnt = torch.cat(cnt_parts) if nchunk > 1 else cnt_parts[0]
+    if not key_parts:
+        return torch.zeros(0, dtype=torch.int64, device=device), torch.zeros(0, dtype=torch.int16, device=device)
+    keys = torch.cat(key_parts) if len(key_parts) > 1 else key_parts[0]
+    cnt = torch.cat(cnt_parts) if len(cnt_parts) > 1 else cnt_parts[0]
     del key_parts, cnt_parts
     keys <<= (64 - 2 * k)                      # left align: base 0 in bits 63..62
     return keys, cnt
@@ -303,18 +337,31 @@ def _normal_from_hash(canon: torch.Tensor) -> torch.Tensor:
 
 
 def polyploid_table_graded(G: int, ploidy: int = 8, rates=(0.001, 0.0015, 0.001, 0.002), cov_hap: float = 14.0,
-                           k: int = 31, L: int = 8, seed: int = 4, device="cuda"):
+                           k: int = 31, L: int = 8, seed: int = 4, device="cuda", key_range=None):
     """Octoploid-like table at any size that fits (k <= 31): the haplotypes of `graded_haplotypes`, every k-mer of both
     strands, a k-mer carried by d haplotypes ~ Normal(d * cov_hap) (the deviate hashed from the canonical k-mer),
     entries below L dropped.  The key space is cut by leading bits so that no torch.unique sees more than 1.2e9 elements.
-    -> (keys int64 left aligned, sorted as unsigned; counts int16): trimmed and closed under reverse complement."""
+    -> (keys int64 left aligned, sorted as unsigned; counts int16): trimmed and closed under reverse complement.
+    key_range: one rank's shard of that table (see diploid_table)."""
     assert k <= 31
+    assert key_range is None or k >= 16
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
     haps = graded_haplotypes(G, ploidy, rates, gen, device)
     km = [_kmers_of(h, k) for h in haps]
     del haps
     total = 2 * ploidy * km[0].numel()
+    both_strands = key_range is None
+    if key_range is not None:
+        own = []
+        for a in km:
+            own.append(a[_in_range16(a >> (2 * k - 16), key_range)])
+            r = _revcomp_right(a, k)
+            own.append(r[_in_range16(r >> (2 * k - 16), key_range)])
+            del r
+        km = own
+        del own
+        total = sum(a.numel() for a in km)
     nchunk = 1
     while total / nchunk > 1.0e9:
         nchunk *= 2
@@ -325,11 +372,14 @@ def polyploid_table_graded(G: int, ploidy: int = 8, rates=(0.001, 0.0015, 0.001,
         sel = []
         for a in km:
             sel.append(a[(a >> shift) == c] if cb else a)
-            r = _revcomp_right(a, k)
-            sel.append(r[(r >> shift) == c] if cb else r)
-            del r
+            if both_strands:
+                r = _revcomp_right(a, k)
+                sel.append(r[(r >> shift) == c] if cb else r)
+                del r
         allk = torch.cat(sel)
         del sel
+        if allk.numel() == 0:
+            continue
         keys, mult = torch.unique(allk, sorted=True, return_counts=True)
         del allk
         z = _normal_from_hash(torch.minimum(keys, _revcomp_right(keys, k)))
@@ -340,15 +390,17 @@ def polyploid_table_graded(G: int, ploidy: int = 8, rates=(0.001, 0.0015, 0.001,
         key_parts.append(keys[keep]); cnt_parts.append(cnt[keep])
         del keys, cnt, keep
     del km
-    keys = torch.cat(key_parts) if nchunk > 1 else key_parts[0]
-    cnt = torch.cat(cnt_parts) if nchunk > 1 else cnt_parts[0]
+    if not key_parts:
+        return torch.zeros(0, dtype=torch.int64, device=device), torch.zeros(0, dtype=torch.int16, device=device)
+    keys = torch.cat(key_parts) if len(key_parts) > 1 else key_parts[0]
+    cnt = torch.cat(cnt_parts) if len(cnt_parts) > 1 else cnt_parts[0]
     del key_parts, cnt_parts
     keys <<= (64 - 2 * k)
     return keys, cnt.contiguous()
 
 
 def polyploid_table_wide(G: int, ploidy: int = 6, rates=(0.001, 0.0015, 0.002), cov_hap: float = 10.0, k: int = 51,
-                         L: int = 5, seed: int = 5, device="cuda", max_chunk: float = 6.0e8):
+                         L: int = 5, seed: int = 5, device="cuda", max_chunk: float = 6.0e8, key_range=None):
     """Two-word k-mers (33 <= k <= 64) of `ploidy` graded haplotypes (ploidy = 2, rates = (het,) is the diploid model of
     diploid_table_wide; ploidy = 6 the hexaploid stand-in of BASELINE configs[4]), generated CHUNK BY CHUNK of the
     key space (the leading bases of a k-mer pick its chunk, a chunk is at most `max_chunk` occurrences), so that the
@@ -357,7 +409,10 @@ def polyploid_table_wide(G: int, ploidy: int = 6, rates=(0.001, 0.0015, 0.002), 
     Every occurrence (haplotype, strand, position) carries the normal deviate of its position (mirrored for the
     reverse strand); an entry takes the minimum over its occurrences and Normal(d * cov_hap) with d = occurrences
     (<= ploidy): the occurrence sets of x and rc(x) mirror each other, so both get the same count.  Entries below L are
-    dropped.  -> (keys int64 [n, 2] viewing left-aligned uint64 words, sorted as unsigned pairs; counts int16)."""
+    dropped.  -> (keys int64 [n, 2] viewing left-aligned uint64 words, sorted as unsigned pairs; counts int16).
+    key_range: one rank's shard of that table (see diploid_table): chunks outside the range are skipped, the chunks on
+    its borders are cut, and the chunk size is taken from the rank's share -- a rank of eight generates its eighth of a
+    table eight times the size with the scratch of one chunk."""
     assert 33 <= k <= 64
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
@@ -369,6 +424,7 @@ def polyploid_table_wide(G: int, ploidy: int = 6, rates=(0.001, 0.0015, 0.002), 
     cbases = 0
     while total / (4 ** cbases) > max_chunk:
         cbases += 1
+    cbases = min(cbases, 8)                     # (chunks are whole 16-bit ranges of the leading key bits)
     nchunk = 4 ** cbases
     strands = []
     for h in haps:
@@ -380,7 +436,7 @@ def polyploid_table_wide(G: int, ploidy: int = 6, rates=(0.001, 0.0015, 0.002), 
         cid = torch.zeros(m, dtype=torch.int32, device=device)
         for j in range(cbases):
             cid = (cid << 2) | h[j: m + j].to(torch.int32)
-        return cid
+        return cid.to(torch.uint8) if cbases <= 4 else cid.to(torch.int16) if cbases <= 7 else cid
 
     def words_at(h, idx):
         w0 = torch.zeros(idx.numel(), dtype=torch.int64, device=device)
@@ -397,12 +453,22 @@ def polyploid_table_wide(G: int, ploidy: int = 6, rates=(0.001, 0.0015, 0.002), 
     cids = [chunk_ids(h) for h, _ in strands] if cbases else None
     K0, K1, CN = [], [], []
     for c in range(nchunk):
+        if key_range is not None:               # chunk c holds the leading 16-bit values [c, c + 1) << (16 - 2 cbases)
+            clo, chi = c << (16 - 2 * cbases), (c + 1) << (16 - 2 * cbases)
+            if chi <= key_range[0] or clo >= key_range[1]:
+                continue
+            cut = clo < key_range[0] or chi > key_range[1]
         W0, W1, Z = [], [], []
         for s, (h, zs) in enumerate(strands):
             idx = torch.nonzero(cids[s] == c).reshape(-1) if cbases else torch.arange(m, device=device)
             a0, a1 = words_at(h, idx)
-            W0.append(a0); W1.append(a1); Z.append(zs[idx])
+            zi = zs[idx]
             del idx
+            if key_range is not None and cut:
+                keep = _in_range16(((a0 ^ SIGN) >> 48) & 0xFFFF, key_range)
+                a0, a1, zi = a0[keep], a1[keep], zi[keep]
+                del keep
+            W0.append(a0); W1.append(a1); Z.append(zi)
         w0 = torch.cat(W0); w1 = torch.cat(W1); zz = torch.cat(Z)
         del W0, W1, Z
         if w0.numel() == 0:
@@ -504,3 +570,30 @@ def write_table_from_device(path: str, keys: torch.Tensor, cnt: torch.Tensor, k:
                 del rec
             total += f.tell()
     return total
+
+
+def table_hash(keys: torch.Tensor, cnt: torch.Tensor, first_entry: int = 0, piece: int = 1 << 26):
+    """Order-sensitive 2 x 64-bit checksum of a table (or of the shard that starts at entry `first_entry` of it) as two
+    Python ints mod 2^64: sums over the entries of a mixed k-mer word / count times an odd multiplier taken from the
+    GLOBAL position, so the shards of a table add up (mod 2^64) to the hash of the whole and any change of a word, a
+    count or the order shows.  bench.py prints it next to the golden .smu it compares with (tests/golden/bench_tables.json)."""
+    n = cnt.numel()
+    kf = keys.reshape(-1)
+    words = kf.numel() // max(n, 1) if n else 1
+    hk = torch.zeros((), dtype=torch.int64, device=cnt.device)
+    hc = torch.zeros((), dtype=torch.int64, device=cnt.device)
+    for a in range(0, kf.numel(), piece):
+        v = kf[a: a + piece]
+        pos = torch.arange(a, a + v.numel(), dtype=torch.int64, device=v.device) + first_entry * words
+        hk += (_mix(v ^ 0x243F6A8885A308D3) * (2 * pos + 1)).sum()
+        del v, pos
+    for a in range(0, n, piece):
+        c = cnt[a: a + piece].to(torch.int64) & 0xFFFF
+        pos = torch.arange(a, a + c.numel(), dtype=torch.int64, device=c.device) + first_entry
+        hc += (_mix(c + 0x13198A2E03707344) * (2 * pos + 1)).sum()
+        del c, pos
+    return int(hk.item()) & 0xFFFFFFFFFFFFFFFF, int(hc.item()) & 0xFFFFFFFFFFFFFFFF
+
+
+def table_hash_text(n: int, hk: int, hc: int) -> str:
+    return f"{n}:{hk:016x}:{hc:016x}"

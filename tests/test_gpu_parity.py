@@ -1336,3 +1336,59 @@ def test_out_of_core_mode_is_chosen_from_the_free_memory_and_says_what_it_cannot
         engine.hetmers_run(table_from(packed[keep], cnt[keep], 31), symcheck="hash")
     with pytest.raises(engine.EngineError, match="condition it first"):
         engine.hetmers_run(table_from(packed, cnt, 31), symcheck="hash", condition=engine.COND_TRIM if hasattr(engine, "COND_TRIM") else 1, ethresh=6)
+
+
+# ---- the bench tables at FULL size against the reference binary's output (tests/golden/bench_*.smu) ------------------------
+def _bench_golden(workload):
+    import json
+    tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bench_tables.json")
+    if not os.path.exists(tj):
+        pytest.skip("tests/golden/bench_tables.json not committed")
+    g = json.load(open(tj)).get(workload)
+    if not g:
+        pytest.skip(f"no golden for the {workload} bench table")
+    g["smu"] = open(os.path.join(os.path.dirname(tj), g["smu_file"])).read()
+    return g
+
+
+@pytest.mark.parametrize("workload", ["uniform", "octoploid", "hexaploid", "repeats"])
+def test_full_size_bench_table_vs_reference_golden(workload, tmp_path):
+    """BASELINE.md section 3's gate where the driver can see it: the table `bench.py --workload <w>` times (BASELINE
+    configs[2]: 2 535 258 108 entries at k = 31; the octoploid / hexaploid k = 51 stand-ins of configs[3] / [4]; the repeats
+    table), generated here by the bench's own generator and identified by its checksum, must give the .smu that the
+    REFERENCE binary (PloidyPlot.c:1603-1617) wrote for it -- tests/golden/bench_<w>.smu, made by
+    tools/make_bench_goldens.py on the GPU box.  Three ways: the engine on the resident table (what a bench step runs), and --
+    for the headline table -- the drop-in executable on the table's files as 8 virtual prefix shards (the N > 1 protocol on
+    one device) and out of core (4 shards one after the other)."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from smudgeplot_amd import sharded, synth_device
+    g = _bench_golden(workload)
+    dev = torch.device("cuda:0")
+    if torch.cuda.mem_get_info(dev)[1] < 250e9:
+        pytest.skip("needs a 288 GB device")
+    k = g["k"]
+    keys, cnt, L, _ = bench.make_table(workload, g["genome"], k, dev)
+    n = cnt.numel()
+    assert n == g["entries"]
+    assert synth_device.table_hash_text(n, *synth_device.table_hash(keys, cnt)) == g["table_hash"]
+    eng = sharded.TorchEngine(dev)
+    index = torch.cumsum(torch.bincount(((keys if keys.dim() == 1 else keys[:, 0]) >> 40) & 0xFFFFFF, minlength=1 << 24), 0)
+    eng.bind(k, keys.reshape(-1), cnt, index=index)
+    for _ in range(2):          # (the second run takes the queued, read-nothing-back form of smg_engine_run)
+        plot, st = sharded.hetmers_sharded(k, keys.reshape(-1), cnt, symcheck="hash", eng=eng, prebound=True)
+        assert st["path"] == 1
+        assert engine.smu_text(plot.cpu().numpy().reshape(1001, 501)) == g["smu"]
+    del eng, plot, index
+    if workload != "uniform":
+        return
+    synth_device.write_table_from_device(str(tmp_path / "t"), keys, cnt, k, nparts=4)
+    del keys, cnt
+    torch.cuda.empty_cache()
+    for name, env in (("vs8", {"SMG_VIRTUAL_SHARDS": "8"}), ("seq4", {"SMG_SEQUENTIAL_SHARDS": "4"}), ("one", {})):
+        r = subprocess.run([HETMERS_BIN, f"-e{L}", "-T4", "-o" + name, "t.ktab"], cwd=tmp_path, capture_output=True, text=True,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr
+        assert (tmp_path / (name + ".smu")).read_text() == g["smu"], name
