@@ -258,10 +258,22 @@ int     smg_engine_apply(smg_engine *e, const uint64_t *d_recv, int64_t nrecv, i
                          char *errbuf, size_t errlen);
 int     smg_engine_apply_own(smg_engine *e, int64_t *missing, char *errbuf, size_t errlen);
 /* (smg_engine_apply with missing == NULL does not wait for the device: the count stays there.)
-   proof: d_dst[0..2] (device) = { complements that were missing or carried another count, fingerprint residue words 0, 1 }
-   of this shard, written in stream order -- a sharded run appends them to the histogram buffer of its final all_reduce
+   proof: d_dst[0..3] (device) = { complements that were missing or carried another count, fingerprint residue words 0, 1,
+   1 if a replayed step (below) did not find the counts it was queued with, else 0 } of this shard, written in stream order -- a sharded run appends them to the histogram buffer of its final all_reduce
    without a host round trip (the residues of the ranks combine by XOR: give each rank its own two words).            */
 int     smg_engine_proof(smg_engine *e, uint64_t *d_dst, char *errbuf, size_t errlen);
+/* Replay of the phase calls (round 5; what smg_engine_run does for a single shard, for the sharded drivers).  With
+   set_replay(e, 1) a step pass1 -> [presort] -> filter -> route_device -> apply(missing = NULL) -> pass2 -> proof on a table
+   whose PREVIOUS step went the same way (hash proof, k <= 64, look-up chain) is queued without a single read-back: the
+   counts the host needs between the calls (requests emitted, deferred entries, requests kept) are last step's -- functions of
+   the table and of the exchanged maps -- and the device compares them with this step's; a difference, an overflow or an
+   order violation is reported through smg_engine_proof as d_dst[3] != 0.  The caller reads the proof words
+   (its one host wait of the step), tells the engine with replay_done(e, ok) -- ok = 0 drops the record -- and on a failure
+   runs the step again, which then takes the plain path.  replay_state: bit 0 = the current step is a replayed one, bit 1 =
+   a record exists.  Binding or conditioning a table drops the record.  No counterpart in the reference.                 */
+int     smg_engine_set_replay(smg_engine *e, int on);
+int     smg_engine_replay_state(smg_engine *e);
+int     smg_engine_replay_done(smg_engine *e, int ok, char *errbuf, size_t errlen);
 /* Request filter (hash proof, k <= 85).  A request only matters when its target is a candidate of
    pass 2 (exactly one suffix-side pair).  Pass 1 records in a bit map which block ids -- the leading
    id_bits = min(30, 2*(k/2)) bits of a k-mer -- hold a candidate; smg_engine_filter drops every request

@@ -181,6 +181,62 @@ template <int W> SMG_DEV int64_t find_key(const u64 *__restrict__ keys, const Di
   return -1;
 }
 
+// Round 5: where a requested k-mer IS, found from where it is EXPECTED (the look-ups of the fast path: sig_find without
+// signatures, smg_fast.hpp).  On a polyploid table the survivors are real hits
+// (one request in seven names a candidate that does have a prefix-side pair: 7.3e7 look-ups on the hexaploid k = 51
+// stand-in, more than half of its step), and the fused probe kernels are bound by the NUMBER of lines those look-ups
+// miss the L2 with, not by their depth (profiles/r05_lookup_experiments.txt: more waves per CU or four look-ups per lane in
+// lockstep change nothing, fewer lines do).  The k-mers of a directory bucket are spread evenly below its leading bits, so
+//    position = bucket start + bucket size x (the 32 k-mer bits below the bucket bits) / 2^32
+// is off by a few entries (sigma <= sqrt(size) / 2: 4.5 for the 81 entries of a 24-bit bucket of that table).  From there
+// the search gallops towards the k-mer -- probes 4, 12 and 28 entries on -- until it is bracketed and bisects the bracket:
+// ~4 probes in ~2 lines of k-mers instead of 6.5 in 3.5.  After three gallop steps without a bracket (a skewed bucket:
+// repeats, low-complexity sequence) it bisects what is left, so the worst case is four probes more than plain bisection.
+// A probe that hits the k-mer ends the search, and a search that ends without such a probe has seen both neighbours of
+// the place where the k-mer would be: no separate verifying load.  (Round 4 started the BISECTION at the expected position
+// and measured nothing: its next probe is the middle of what is left, i.e. just as far away.)
+#ifndef L_GALLOP
+#define L_GALLOP 1                         // 0: plain bisection of the directory bucket (find_key)
+#endif
+#define L_STEP0  3                         // first gallop step: the probe lands 4 entries from the expected position
+#define L_GSTEPS 3                         // gallop steps before the search falls back to bisection
+
+template <int W> SMG_DEV int64_t find_key_near(const u64 *__restrict__ keys, const Dir &d, const Key<W> &t)
+{ const uint32_t hb = (uint32_t) (t.w[0] >> 32) >> d.dsh;
+  if (hb < d.b0) return -1;
+  uint32_t bk = hb - d.b0;
+  if (bk >= d.nb) return -1;
+  uint32_t a = d.bstart[bk];
+  if (a == DIR_UNSET) return -1;
+  uint32_t b = d.bstart[++bk];
+  while (b == DIR_UNSET) b = d.bstart[++bk];                   // (a directory that pass 1 built skips empty buckets; bstart[nb] is set)
+  if (a >= b) return -1;
+  // [a, b): where the k-mer can still be.  First probe: the expected position; then gallop up or down, then bisect.
+  unsigned m = a + __umulhi(b - a, (unsigned) ((t.w[0] << (32 - d.dsh)) >> 32));
+  unsigned step = L_STEP0;
+  int mode = 0, left = L_GSTEPS;                                // 0 first probe, 1 galloping up, 2 galloping down, 3 bisection
+  for (;;)
+    { const Key<W> z = load_key<W>(keys, m);
+      if (key_eq<W>(z, t)) return (int64_t) m;
+      if (key_lt<W>(z, t))
+        { a = m + 1u;
+          if (mode == 0) mode = 1;
+          else if (mode == 1) { step = 2u * step + 1u; if (--left == 0) mode = 3; }
+          else mode = 3;
+        }
+      else
+        { b = m;
+          if (mode == 0) mode = 2;
+          else if (mode == 2) { step = 2u * step + 1u; if (--left == 0) mode = 3; }
+          else mode = 3;
+        }
+      if (a >= b) return -1;
+      m = a + ((b - a) >> 1);
+      if (mode == 1) { if (a + step < b) m = a + step; else mode = 3; }
+      else if (mode == 2) { if (b - a > step) m = b - 1u - step; else mode = 3; }
+    }
+}
+
 SMG_DEV u64 mix64(u64 z)
 { z ^= z >> 30; z *= 0xbf58476d1ce4e5b9ull;
   z ^= z >> 27; z *= 0x94d049bb133111ebull;

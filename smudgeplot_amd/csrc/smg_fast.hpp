@@ -131,7 +131,7 @@ template <int W> SMG_DEV int first_diff(const Key<W> &x, const Key<W> &y)
 template <int W> __device__ __forceinline__ void
 big_block_walk(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, int64_t n,
                const Geo g, int64_t i, unsigned &s_all, unsigned &s_hi, int64_t &partner,
-               unsigned &w2, int64_t *block_len = nullptr /* SMG_BF_INSTR */)
+               unsigned &w2)
 { const Key<W> x = load_key<W>(keys, i);
   const unsigned c = cnt[i];
   int64_t lo, hi;
@@ -162,7 +162,6 @@ big_block_walk(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, i
       }
     hi = a;
   }
-  if (block_len) *block_len = hi - lo;
   s_all = 0; s_hi = 0; partner = -1; w2 = 0;
   int p = g.p0;
 #pragma unroll 1
@@ -428,7 +427,7 @@ kf_pass1(FastArgs A, uint32_t *__restrict__ bstart, u64 *__restrict__ req,
 // kf_apply_sorted); `verify` (the exact proof, where the look-up IS the proof) compares the k-mer of every hit.
 // Without signatures (W = 3) the k-mers are bisected directly.
 template <int W> SMG_DEV int64_t sig_find(const FastArgs &A, const Key<W> &y, bool verify)
-{ if (A.sig == NULL) return find_key<W>(A.keys, A.dir, y);
+{ if (A.sig == NULL) return L_GALLOP ? find_key_near<W>(A.keys, A.dir, y) : find_key<W>(A.keys, A.dir, y);
   const Dir d = A.dir;
   const uint32_t hb = (uint32_t) (y.w[0] >> 32) >> d.dsh;
   if (hb < d.b0 || hb - d.b0 >= d.nb) return -1;
@@ -1083,7 +1082,7 @@ kf_route_scatter(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk
 
 template <int W> SMG_DEV void
 block_scan(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, int64_t n, const Geo g, int64_t i,
-           unsigned &s_all, unsigned &s_hi, int64_t &partner, unsigned &w2, int64_t *block_len = nullptr /* SMG_BF_INSTR */)
+           unsigned &s_all, unsigned &s_hi, int64_t &partner, unsigned &w2)
 { // The marked entries lie anywhere in the table: every load is a cold line (and mostly a cold page).  The
   // neighbours are therefore fetched eight at a time, independent loads in flight together -- a walk of one
   // dependent load per step took 0.19 us per entry with every lane of the chip busy.
@@ -1092,7 +1091,7 @@ block_scan(const u64 *__restrict__ keys, const uint16_t *__restrict__ cnt, int64
   { const int64_t lo = i - BF_LIN - 1, hi = i + BF_LIN + 1;
     const bool far_lo = lo >= 0 && same_block<W>(x, load_key<W>(keys, lo >= 0 ? lo : i), g);
     const bool far_hi = hi < n && same_block<W>(x, load_key<W>(keys, hi < n ? hi : i), g);
-    if (far_lo || far_hi) { big_block_walk<W>(keys, cnt, n, g, i, s_all, s_hi, partner, w2, block_len); return; }
+    if (far_lo || far_hi) { big_block_walk<W>(keys, cnt, n, g, i, s_all, s_hi, partner, w2); return; }
   }
   const unsigned c = cnt[i];
   s_all = 0; s_hi = 0; partner = -1; w2 = 0;
@@ -1191,19 +1190,6 @@ kf_collect(uint32_t *__restrict__ dbits, int64_t nwords, uint32_t *__restrict__ 
 // times).  Entries that owe a request are only noted; after the slab's barrier the workgroup writes their requests out.
 #define BF_SLAB  8192
 
-#ifdef SMG_BF_INSTR
-// Tuning builds only (tools/build_variants.sh bfinstr="-DSMG_BF_INSTR"): where kf_bigfix spends its time.  A listed entry's
-// class is 0 when its block is walked linearly, else 1 + the bin of its block's length (< 128, 256, 512, 1024, 2048, 16384,
-// 131072, more); a 64-entry batch has the class of its longest block.  [c]: entries, [16 + c]: batches, [32 + c]: shader
-// cycles the batches took; [48]: cycles of thread 0 in the slabs' walk phase, [49]: in their request write-out, [50]: slabs,
-// [51] / [52]: cycles of the workgroups from start to end / workgroups; [53..55] / [56]: cycles of the batches in the scan (its
-// loads), in issuing the entry's stores and map atomic, in waiting for those to drain / batches.
-__device__ unsigned long long g_bf_instr[64];
-SMG_DEV unsigned bf_class(int64_t len)
-{ if (len <= 0) return 0;
-  return len < 128 ? 1 : len < 256 ? 2 : len < 512 ? 3 : len < 1024 ? 4 : len < 2048 ? 5 : len < 16384 ? 6 : len < 131072 ? 7 : 8;
-}
-#endif
 
 template <int W, int RW> __global__ void __launch_bounds__(BF_TPB)
 kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, const unsigned *__restrict__ pcount, unsigned cap, u64 *__restrict__ req,
@@ -1216,11 +1202,6 @@ kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, const unsigned *__re
   __shared__ unsigned s_nl, s_next, s_slab, s_chunk, s_used;
   __shared__ u64      s_base, s_total;
   const int t = threadIdx.x, lane = t & 63;
-#ifdef SMG_BF_INSTR
-  __shared__ unsigned long long s_instr[64];    // (summed in LDS, flushed once: global atomics per entry would be the run time)
-  if (t < 64) s_instr[t] = 0;
-  const long long k0 = clock64();
-#endif
   if (t == 0) { s_chunk = F_NOCHUNK; s_used = 0; s_total = 0; }
   for (int b = t; b < 1024; b += BF_TPB) hist[b] = 0;
   const unsigned nbig = *pcount;
@@ -1236,9 +1217,6 @@ kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, const unsigned *__re
       const unsigned slab0 = s_slab;
       if (slab0 >= nbig) break;
       const unsigned slab_n = nbig - slab0 < slab ? nbig - slab0 : slab;
-#ifdef SMG_BF_INSTR
-      const long long w0 = clock64();
-#endif
       for (;;)
         { unsigned b = 0;
           if (lane == 0) b = atomicAdd(&s_next, 64u);
@@ -1249,21 +1227,7 @@ kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, const unsigned *__re
               const int64_t i = biglist[r];
               unsigned s_all, s_hi, w2;
               int64_t partner;
-#ifdef SMG_BF_INSTR
-              int64_t blen = 0;
-              const long long c0 = clock64();
-              block_scan<W>(A.keys, A.cnt, A.n, A.g, i, s_all, s_hi, partner, w2, &blen);
-              const long long c1 = clock64();
-              { const unsigned cls = bf_class(blen);
-                unsigned mx = cls;
-                for (int o = 32; o; o >>= 1) { const unsigned v = (unsigned) __shfl_xor((int) mx, o); mx = v > mx ? v : mx; }
-                atomicAdd(&s_instr[cls], 1ull);
-                if (lane == __ffsll((long long) __ballot(1)) - 1)
-                  { atomicAdd(&s_instr[16 + mx], 1ull); atomicAdd(&s_instr[32 + mx], (unsigned long long) (c1 - c0)); }
-              }
-#else
               block_scan<W>(A.keys, A.cnt, A.n, A.g, i, s_all, s_hi, partner, w2);
-#endif
               const unsigned code = make_code(s_all, partner - i, w2);
               A.code[i] = (uint8_t) code;
               if ((code & 63) == CODE_FAR) farp[r] = (uint32_t) partner;
@@ -1273,22 +1237,9 @@ kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, const unsigned *__re
                   else atomicOr(&A.bmap[id >> 5], 1u << (id & 31));
                 }
               if (s_hi > 0) slist[atomicAdd(&s_nl, 1u)] = (uint32_t) i;
-#ifdef SMG_BF_INSTR
-              { const long long c2 = clock64();                // (the stores and the atomic of this batch drained here, so that the
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   //  next batch's first wait is for its own loads only)
-                const long long c3 = clock64();
-                if (lane == __ffsll((long long) __ballot(1)) - 1)
-                  { atomicAdd(&s_instr[53], (unsigned long long) (c1 - c0)); atomicAdd(&s_instr[54], (unsigned long long) (c2 - c1));
-                    atomicAdd(&s_instr[55], (unsigned long long) (c3 - c2)); atomicAdd(&s_instr[56], 1ull);
-                  }
-              }
-#endif
             }
         }
       __syncthreads();
-#ifdef SMG_BF_INSTR
-      const long long w1 = clock64();
-#endif
       // the slab's requests, BF_TPB at a time into the workgroup's chunks
       const unsigned nl = s_nl;
       for (unsigned q0 = 0; q0 < nl; q0 += BF_TPB)
@@ -1318,10 +1269,6 @@ kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, const unsigned *__re
             }
           __syncthreads();
         }
-#ifdef SMG_BF_INSTR
-      if (t == 0)
-        { s_instr[48] += (unsigned long long) (w1 - w0); s_instr[49] += (unsigned long long) (clock64() - w1); s_instr[50] += 1; }
-#endif
     }
   if (t == 0)
     { if (s_chunk != F_NOCHUNK && s_chunk < max_chunks) chunk_fill[s_chunk] = s_used;
@@ -1329,11 +1276,6 @@ kf_bigfix(FastArgs A, const uint32_t *__restrict__ biglist, const unsigned *__re
       if (s_total) atomicAdd(&ctl->nreq, s_total);
     }
   __syncthreads();
-#ifdef SMG_BF_INSTR
-  if (t == 0) { s_instr[51] = (unsigned long long) (clock64() - k0); s_instr[52] = 1; }
-  __syncthreads();
-  if (t < 64 && s_instr[t]) atomicAdd(&g_bf_instr[t], s_instr[t]);
-#endif
   if (whist && hbits)
     for (int b = t; b < 1024; b += BF_TPB) whist[(size_t) blockIdx.x * 1024 + b] = hist[b];
 }

@@ -582,6 +582,13 @@ struct smg_engine
   bool         fused_last;   // the look-ups of the last run were the fused ones (kl_part -> kl_probe on the engine's own map)
   bool         spec_ok;      // the last smg_engine_run on this bound table went through the hash-proof chain: its counts size the next one
   int64_t      spec_nreq, spec_nbig;   //   requests pass 1 (+ kf_bigfix) emitted, entries deferred to kf_bigfix (functions of the table)
+  // replay of the PHASE calls (sharded runs, smg_engine_set_replay): a step on a table whose last step went through pass1 ->
+  // filter (hash proof, look-up chain) is queued without a read-back -- the counts the host needs are last step's (functions
+  // of the table and of the exchanged maps), the device compares them with this step's and reports through smg_engine_proof
+  bool         rp_want, rp_have, rp_active;    // asked for / a record exists / the current step runs from the record
+  int64_t      rp_nreq, rp_nbig, rp_nf_req;    //   pass 1: requests, deferred entries; filter: requests kept
+  unsigned     rp_nf_chunks, rp_grid;          //   filter: chunks of the kept list; pass-1 grid (rows of `partials`)
+  int          rp_bm_bits, rp_sym;             //   map geometry and proof the record belongs to
   u64         *req;    int64_t req_cap;      // bytes
   u64         *req2;   int64_t req2_cap;     // radix sort output
   void        *sort_tmp; int64_t sort_tmp_cap;
@@ -635,7 +642,7 @@ struct smg_engine
   unsigned     n_chunks;
   u64          fp[4];
   smg_stats    st;
-  hipEvent_t   ev[11];        // 0,1 decode  2,3 pass 1  4,5 look-ups  6,7 pass 2  8,9 whole run  10 between partition and probe
+  hipEvent_t   ev[13];        // 0,1 decode  2,3 pass 1  4,5 look-ups  6,7 pass 2  8,9 whole run  10 between partition and probe  11,12 filter of a replayed step
 };
 
 static int fail(char *errbuf, size_t errlen, int code, const char *fmt, const char *a = "")
@@ -692,7 +699,7 @@ extern "C" smg_engine *smg_engine_create(int device, void *stream, char *errbuf,
     { fail(errbuf, errlen, SMG_ENOMEM, "cannot allocate the control block%s");
       delete e; return NULL;
     }
-  for (int i = 0; i < 11; i++) hipEventCreate(&e->ev[i]);
+  for (int i = 0; i < 13; i++) hipEventCreate(&e->ev[i]);
   return e;
 }
 
@@ -705,7 +712,7 @@ extern "C" void smg_engine_destroy(smg_engine *e)
   hipFree(e->partials); hipFree(e->ctrl); hipFree(e->d_split); hipFree(e->p1cold); hipFree(e->ghist); hipFree(e->boff);
   hipFree(e->whist);
   hipHostFree(e->h_ctrl); hipHostFree(e->h_partials); hipHostFree(e->h_p1cold);
-  for (int i = 0; i < 11; i++) hipEventDestroy(e->ev[i]);
+  for (int i = 0; i < 13; i++) hipEventDestroy(e->ev[i]);
   delete e;
 }
 
@@ -719,7 +726,7 @@ static int set_table(smg_engine *e, int kmer, int64_t nels, char *errbuf, size_t
   e->n = nels;
   e->prepared = false; e->counted_done = false; e->lookup_pending = false;
   e->have_ixdir = false; e->dir_preset = false; e->have_ends = false;        // (properties of the table that was bound before)
-  e->spec_ok = false;
+  e->spec_ok = false; e->rp_have = false; e->rp_active = false;
   memset(&e->st, 0, sizeof(e->st));
   e->st.nels = nels;
   e->st.key_words = e->W;
@@ -1295,24 +1302,6 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
                               grid, grid + BF_MAXGRID, e->lg.nb, e->farp)
           if (e->W == 2 && e->rw == 2) BIGFIX(2, 2); else if (e->W == 2) BIGFIX(2, 3); else if (e->rw == 1) BIGFIX(1, 1); else BIGFIX(1, 2);
 #undef BIGFIX
-#ifdef SMG_BF_INSTR
-          { unsigned long long h[64], z[64] = { 0 };     // tuning builds only: see g_bf_instr
-            hipStreamSynchronize(e->stream);
-            hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bf_instr), sizeof h);
-            hipMemcpyToSymbol(HIP_SYMBOL(g_bf_instr), z, sizeof z);
-            static const char *nm[9] = { "linear", "<128", "<256", "<512", "<1024", "<2048", "<16384", "<131072", "more" };
-            for (int c = 0; c < 9; c++)
-              if (h[c] || h[16 + c])
-                fprintf(stderr, "[bf] block %-8s entries %10llu  batches %8llu  cycles/batch %10.0f\n", nm[c], h[c], h[16 + c],
-                        h[16 + c] ? (double) h[32 + c] / (double) h[16 + c] : 0.0);
-            fprintf(stderr, "[bf] slabs %llu  walk phase %.0f cycles/slab  write-out %.0f cycles/slab  workgroups %llu  %.0f cycles each\n", h[50],
-                    h[50] ? (double) h[48] / (double) h[50] : 0.0, h[50] ? (double) h[49] / (double) h[50] : 0.0, h[52],
-                    h[52] ? (double) h[51] / (double) h[52] : 0.0);
-            if (h[56])
-              fprintf(stderr, "[bf] per batch: scan %.0f  issue of stores + map atomic %.0f  their drain %.0f cycles\n", (double) h[53] / (double) h[56],
-                      (double) h[54] / (double) h[56], (double) h[55] / (double) h[56]);
-          }
-#endif
           hipEventRecord(e->ev[3], e->stream);
           HIPCHK(hipGetLastError());
         }
@@ -1358,7 +1347,8 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
   // (each redo sizes the lists from the counts the failed attempt reported, so the second attempt fits; a list that
   //  still overflows after that is a bug, and must not be read as a complete request list)
   if (spec)
-    { e->n_chunks = 1;                      // (> 0: "there are requests"; the real number is checked at the end of the run)
+    { e->rp_grid = grid;
+      e->n_chunks = 1;                      // (> 0: "there are requests"; the real number is checked at the end of the run)
       e->st.nrequests = e->st.nemitted = e->spec_nreq;
       e->st.nbig = e->spec_nbig;
       e->st.ms_filter = 0; e->st.ms_bigfix = 0;
@@ -1599,6 +1589,13 @@ static int fast_filter(smg_engine *e, const uint32_t *map, char *errbuf, size_t 
     if ((rc = grow(&e->reqf, &e->reqf_cap, want, errbuf, errlen))) return rc;
     if ((rc = grow(&e->chunk_fillf, &e->chunk_capf, wantf, errbuf, errlen))) return rc;
   }
+  if (e->rp_active)
+    { // replayed step: WHICH chunks the waves of the probe kernel fill is decided by an atomic counter, and how many by the
+      // way the buckets fall to the workgroups -- so the routing kernels walk the whole list, and a chunk nobody opened must
+      // read as empty
+      hipEventRecord(e->ev[11], e->stream);
+      HIPCHK(hipMemsetAsync(e->chunk_fillf, 0, (size_t) maxout * 4, e->stream));
+    }
   if (!e->presorted && (rc = filter_presort(e, errbuf, errlen))) return rc;
   const int64_t nslots = (int64_t) e->n_chunks * F_CH;
   if (e->presorted == 3)
@@ -1620,18 +1617,33 @@ static int fast_filter(smg_engine *e, const uint32_t *map, char *errbuf, size_t 
                        map, 64 - nbits, e->reqf, e->chunk_fillf, maxout, &e->ctrl->fast);
   hipEventRecord(e->ev[5], e->stream);
   HIPCHK(hipGetLastError());
-  if ((rc = read_ctrl(e, errbuf, errlen))) return rc;
-  if (e->h_ctrl->fast.nf_chunks > maxout) return fail(errbuf, errlen, SMG_ENODEV, "request filter overflowed its chunk list%s");
+  if (e->rp_active)
+    { // replayed step: the kept list is as long as last time (the device checks it: smg_engine_proof) -- nothing is read
+      hipEventRecord(e->ev[12], e->stream);
+      e->rp_nf_chunks = maxout;             // (the device checks that the probe kernel stayed inside the list)
+    }
+  else
+    { if ((rc = read_ctrl(e, errbuf, errlen))) return rc;
+      if (e->h_ctrl->fast.nf_chunks > maxout) return fail(errbuf, errlen, SMG_ENODEV, "request filter overflowed its chunk list%s");
+    }
   { u64 *t = e->req; e->req = e->reqf; e->reqf = t; }
   { int64_t t = e->req_cap; e->req_cap = e->reqf_cap; e->reqf_cap = t; }
   { uint32_t *t = e->chunk_fill; e->chunk_fill = e->chunk_fillf; e->chunk_fillf = t; }
   { int64_t t = e->chunk_cap; e->chunk_cap = e->chunk_capf; e->chunk_capf = t; }
+  if (e->rp_active)
+    { e->n_chunks = e->rp_nf_chunks; e->st.nrequests = e->rp_nf_req; e->filtered = true;
+      return SMG_OK;
+    }
   e->n_chunks = e->h_ctrl->fast.nf_chunks;
   e->st.nrequests = (int64_t) e->h_ctrl->fast.nf_req;
   e->filtered = true;
   float ms = 0; hipEventElapsedTime(&ms, e->ev[4], e->ev[5]);
   e->st.ms_rclookup += ms;
   e->st.ms_filter = ms;
+  // what a replayed step on this table may take for granted (key-only records through the look-up chain, k <= 64)
+  e->rp_have = e->rp_want && e->presorted == 3 && e->W <= 2 && e->rw == e->W && !e->h_p1cold->times;
+  if (e->rp_have)
+    { e->rp_nreq = e->st.nemitted; e->rp_nbig = e->st.nbig; e->rp_nf_req = e->st.nrequests; e->rp_bm_bits = e->bm_bits; }
   return SMG_OK;
 }
 
@@ -1804,7 +1816,50 @@ extern "C" int smg_engine_pass1(smg_engine *e, int symcheck, char *errbuf, size_
   e->st.ms_rclookup = 0; e->lookup_pending = false;
   if (e->kmer > FAST_MAX_K) return counted_phase_pass1(e, symcheck, errbuf, errlen);
   e->bm_cap = e->bm_want ? e->bm_want : 30;  // default: the maps of the shards are exchanged, 128 MB in total
+  e->rp_active = false;
+  if (e->rp_want && e->rp_have && symcheck == SMG_SYM_HASH && e->rp_sym == symcheck && e->n > 0
+      && e->rp_bm_bits == bm_id_bits(e->kmer, e->bm_cap))
+    { // the step before this one, on this very table, went through the look-up chain: queue this one from its counts
+      e->spec_nreq = e->rp_nreq; e->spec_nbig = e->rp_nbig;
+      const int rc = fast_pass1(e, 0, 0, 1, errbuf, errlen, true);
+      if (rc) return rc;
+      e->rp_active = true;
+      return SMG_OK;
+    }
+  e->rp_sym = symcheck;
   return fast_pass1(e, symcheck == SMG_SYM_EXACT, symcheck == SMG_SYM_EXACT, symcheck == SMG_SYM_HASH, errbuf, errlen);
+}
+
+extern "C" int smg_engine_set_replay(smg_engine *e, int on)
+{ if (!e) return SMG_EINVAL;
+  e->rp_want = on != 0;
+  if (!on) e->rp_have = false;
+  return SMG_OK;
+}
+
+// is the current step a replayed one (1), and did the LAST finished step leave a record (2)?
+extern "C" int smg_engine_replay_state(smg_engine *e) { return e ? (e->rp_active ? 1 : 0) | (e->rp_have ? 2 : 0) : 0; }
+
+// after the caller has read the proof words of a replayed step: ok != 0 = the device found every count as recorded (the
+// run stands: the engine's bookkeeping is brought up to date from the control words, which are complete by now),
+// ok == 0 = the record is dropped and the next step runs the plain way
+extern "C" int smg_engine_replay_done(smg_engine *e, int ok, char *errbuf, size_t errlen)
+{ if (!e) return fail(errbuf, errlen, SMG_EINVAL, "null engine%s");
+  if (!e->rp_active) return SMG_OK;
+  e->rp_active = false;
+  HIPCHK(hipSetDevice(e->device));
+  if (!ok) { e->rp_have = false; e->dbits_dirty = true; e->lookup_pending = false; return SMG_OK; }
+  int rc = read_ctrl(e, errbuf, errlen);
+  if (rc) return rc;
+  e->dbits_dirty = false;
+  memset(e->fp, 0, sizeof(e->fp));
+  for (unsigned b = 0; b < e->rp_grid; b++)
+    for (int q = 0; q < 4; q++) e->fp[q] ^= e->h_partials[b * 4 + q];
+  float ms = 0;
+  hipEventElapsedTime(&ms, e->ev[2], e->ev[3]); e->st.ms_pass1 = ms;
+  hipEventElapsedTime(&ms, e->ev[0], e->ev[3]); e->st.ms_bigfix = ms;
+  hipEventElapsedTime(&ms, e->ev[11], e->ev[12]); e->st.ms_filter = ms; e->st.ms_rclookup += ms;
+  return SMG_OK;
 }
 
 extern "C" int64_t smg_engine_nreq(smg_engine *e) { return e ? e->st.nrequests : 0; }
@@ -1820,12 +1875,37 @@ extern "C" int smg_engine_apply(smg_engine *e, const uint64_t *d_recv, int64_t n
 }
 
 __global__ void k_proof_words(const Ctrl *__restrict__ ctrl, int fast, u64 f0, u64 f1, u64 *__restrict__ dst)
-{ if (threadIdx.x == 0) { dst[0] = fast ? (u64) ctrl->fast.missing : ctrl->missing; dst[1] = f0; dst[2] = f1; } }
+{ if (threadIdx.x == 0) { dst[0] = fast ? (u64) ctrl->fast.missing : ctrl->missing; dst[1] = f0; dst[2] = f1; dst[3] = 0; } }
+
+// the same for a replayed step: the fingerprint residue is folded from the workgroups' partial words on the device, and the
+// counts the step was queued with are compared with what its kernels reported -- any difference sets dst[3], on which the
+// caller (all ranks of a sharded run: the word is summed with the proof) drops the record and runs the step again the plain way
+struct ReplayExpect { u64 nreq, nf_req; unsigned nbig, nf_chunks, max_chunks, grid; };
+__global__ void __launch_bounds__(64)
+k_proof_replay(const Ctrl *__restrict__ ctrl, const u64 *__restrict__ partials, ReplayExpect x, u64 *__restrict__ dst)
+{ u64 f0 = 0, f1 = 0;
+  for (unsigned b = threadIdx.x; b < x.grid; b += 64)
+    { f0 ^= partials[(size_t) b * 4] ^ partials[(size_t) b * 4 + 2]; f1 ^= partials[(size_t) b * 4 + 1] ^ partials[(size_t) b * 4 + 3]; }
+  f0 = wave_xor_u64(f0); f1 = wave_xor_u64(f1);
+  if (threadIdx.x == 0)
+    { const FastCtl &f = ctrl->fast;
+      const bool bad = f.unsorted != 0 || f.n_chunks > x.max_chunks || f.nbig != x.nbig || f.nreq != x.nreq
+                       || f.nf_chunks > x.nf_chunks || f.nf_req != x.nf_req;
+      dst[0] = (u64) f.missing; dst[1] = f0; dst[2] = f1; dst[3] = bad ? 1ull : 0ull;
+    }
+}
 
 extern "C" int smg_engine_proof(smg_engine *e, uint64_t *d_dst, char *errbuf, size_t errlen)
 { NEED_ENGINE(e)
   if (!e->prepared || !d_dst) return fail(errbuf, errlen, SMG_EINVAL, "proof before pass1%s");
   HIPCHK(hipSetDevice(e->device));
+  if (e->rp_active)
+    { ReplayExpect x;
+      x.nreq = (u64) e->rp_nreq; x.nf_req = (u64) e->rp_nf_req; x.nbig = (unsigned) e->rp_nbig; x.nf_chunks = e->rp_nf_chunks;
+      x.max_chunks = e->max_chunks; x.grid = e->rp_grid;
+      hipLaunchKernelGGL(k_proof_replay, dim3(1), dim3(64), 0, e->stream, (const Ctrl *) e->ctrl, (const u64 *) e->partials, x, (u64 *) d_dst);
+    }
+  else
   hipLaunchKernelGGL(k_proof_words, dim3(1), dim3(64), 0, e->stream,
                      (const Ctrl *) e->ctrl, e->fast ? 1 : 0, e->fp[0] ^ e->fp[2], e->fp[1] ^ e->fp[3],
                      (u64 *) d_dst);
@@ -2258,7 +2338,7 @@ extern "C" int smg_engine_condition(smg_engine *e, int ethresh, int do_trim, int
   e->n = n;
   e->prepared = false; e->counted_done = false;
   e->have_ixdir = false; e->dir_preset = false; e->have_ends = false;      // (another table now: its index and ends are gone)
-  e->spec_ok = false;
+  e->spec_ok = false; e->rp_have = false; e->rp_active = false;
   e->st.nels = n;
   e->st.ms_decode += ms;
   if (new_nels) *new_nels = n;

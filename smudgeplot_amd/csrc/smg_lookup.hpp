@@ -53,7 +53,11 @@ static inline LookupGeo lookup_geo(int fb)
 //  mark the map, the look-up reads the answer from the complement's code byte.  Correct, and no gain: on the bench table
 //  18.7 % of the entries are candidates, 17.5 % own such a pair -- the two streams are the same size.)
 template <int W> SMG_DEV void lookup_one(const FastArgs &A, const Key<W> &y, FastCtl *__restrict__ ctl)
-{ const int64_t i = sig_find<W>(A, y, false);
+{
+#ifdef L_ABL_NOLOOKUP                      // ablation build (timing only, WRONG results): what the probe kernels cost without their look-ups
+  return;
+#endif
+  const int64_t i = sig_find<W>(A, y, false);          // (no signatures bound: find_key_near, smg_device.hpp)
   if (i < 0) { if (ctl->missing == 0) ctl->missing = 1; return; }
   SET_P(A, i);
 }
@@ -409,7 +413,7 @@ kl_probe(FastArgs A, const u64 *__restrict__ recs, const u64 *__restrict__ boff,
 // kl_probe.  Needs >= 8 buckets (nb >= 3); the XCD is the hardware's XCC id (HW_REG_XCC_ID: the dispatcher's round-robin is
 // not taken for granted, nor is the number of XCDs -- see the stealing loop).
 #define PX_TPB   256
-#define PX_PART  4096                     // requests per ticket (with PX_WGS workgroups per CU: ~1.2 buckets in flight per XCD)
+#define PX_PART  2048                     // requests per ticket (with PX_WGS workgroups per CU: ~0.6 buckets in flight per XCD; 4096: +2 ... 4 %, 1024: +10 %)
 #define PX_WGS   4
 #define PX_PER   8                        // requests per lane and step
 #define PX_NXCD  8

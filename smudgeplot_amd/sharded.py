@@ -107,8 +107,18 @@ class TorchEngine:
         return self.e.apply(recv.data_ptr(), nrecv, wait)
 
     def proof_into(self, dst):
-        """dst: int64 tensor of >= 3 words on the device <- (missing, fingerprint residue), in stream order"""
+        """dst: int64 tensor of >= 4 words on the device <- (missing, fingerprint residue x 2, replayed step found other
+        counts than it was queued with), in stream order"""
         self.e.proof_into(dst.data_ptr())
+
+    def set_replay(self, on):
+        self.e.set_replay(on)
+
+    def replay_state(self):
+        return self.e.replay_state()
+
+    def replay_done(self, ok):
+        self.e.replay_done(ok)
 
     def apply_own(self):
         return self.e.apply_own()
@@ -408,9 +418,26 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
         st.update(rank=rank, world=world, shard_nels=n, sent=0, received=st.get("nemitted", 0), engine=eng)
         return plot, st
 
+    # Replay (round 5): a step on the table of the step before is queued WITHOUT a host read in the middle -- the engine takes
+    # the counts it needs between its phases from its record of that step, this driver the per-rank send / receive counts
+    # from its own; the device compares all of them with what this step produces and the verdict rides with the proof words
+    # in the one all_reduce.  A mismatch anywhere makes every rank run the step again the plain way.
+    rkey = (tag, symcheck, world)
+    rec = getattr(eng, "_replay_rec", None)
+    can_replay = (exchange and symcheck == "hash" and hasattr(eng, "set_replay") and os.environ.get("SMG_NO_REPLAY") != "1"
+                  and not owned)
+    if can_replay:
+        if rec is None or rec["key"] != rkey:
+            eng.set_replay(False)              # (no counts of ours to go with the engine's: drop its record too)
+            rec = None
+        eng.set_replay(True)
     eng.pass1(symcheck, exchange, world)
+    replay = bool(can_replay and rec is not None and (eng.replay_state() & 1))
+    if can_replay and rec is not None and not replay:
+        rec = None
     rw = eng.record_words()
     nreq = eng.nreq()
+    both = None
 
     if exchange:
         bits, nwords = eng.blockmap()
@@ -442,8 +469,11 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
         sc, rcnt = both[:world], both[world:]
         eng.route(splitters, world, send, counts_out=sc)
         dist.all_to_all_single(rcnt, sc, group=group)
-        hb = both.cpu().tolist()
-        send_counts, recv_counts = [int(v) for v in hb[:world]], [int(v) for v in hb[world:]]
+        if replay:
+            send_counts, recv_counts = rec["send"], rec["recv"]          # (checked on the device against `both` below)
+        else:
+            hb = both.cpu().tolist()
+            send_counts, recv_counts = [int(v) for v in hb[:world]], [int(v) for v in hb[world:]]
         nrecv = sum(recv_counts)
         recv = _scratch(eng, "recv", max(nrecv, 1) * rw, dev)
         dist.all_to_all_single(recv[: nrecv * rw], send[: nreq * rw],
@@ -456,25 +486,31 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
 
     # pass 2 runs before the symmetry proof is known (its result is discarded when the proof fails): the proof
     # words ride at the end of the histogram buffer, so ONE all_reduce carries both (sums wrap mod 2^64)
-    # Layout behind the plot: [missing count] + two words per rank.  The fingerprint is an XOR over the table, which
-    # a SUM all_reduce cannot combine -- so every rank writes its 128-bit residue into ITS OWN two words (zeros
-    # elsewhere), the sum hands every rank all residues, and the XOR over the ranks is taken on the host.
+    # Layout behind the plot: [missing count] + two words per rank + [replayed steps that found other counts, replayed steps].  The
+    # fingerprint is an XOR over the table, which a SUM all_reduce cannot combine -- so every rank writes its 128-bit residue
+    # into ITS OWN two words (zeros elsewhere), the sum hands every rank all residues, and the XOR over the ranks is taken on
+    # the host.
     nslot = world if exchange else 1
-    buf = _scratch(eng, "plot", PLOT_CELLS + 1 + 2 * nslot, dev)     # (pass 2 clears the plot itself; the proof words below)
+    nproof = 3 + 2 * nslot
+    buf = _scratch(eng, "plot", PLOT_CELLS + nproof, dev)     # (pass 2 clears the plot itself; the proof words below)
     buf[PLOT_CELLS:].zero_()
     plot = buf[:PLOT_CELLS]
     eng.pass2(plot)
     me = rank if exchange else 0
     if missing is None:
-        # the engine writes (missing, residue word 0, residue word 1) on the device, in stream order: no host round
-        # trip between the look-ups and the all_reduce.  Rank r's words go to [0] (summed) and to ITS slot.
-        tmp = _scratch(eng, "proof", 3, dev)
+        # the engine writes (missing, residue word 0, residue word 1, replay verdict) on the device, in stream order: no host
+        # round trip between the look-ups and the all_reduce.  Rank r's words go to [0] (summed) and to ITS slot.
+        tmp = _scratch(eng, "proof", 4, dev)
         eng.proof_into(tmp)
         buf[PLOT_CELLS] = tmp[0]
         buf[PLOT_CELLS + 1 + 2 * me: PLOT_CELLS + 3 + 2 * me] = tmp[1:3]
+        if replay:
+            # ... and this driver's part of the verdict: the counts it split the exchange by are the ones the router produced
+            buf[PLOT_CELLS + nproof - 2] = tmp[3] + (both != rec["both"]).any().to(torch.int64)
+            buf[PLOT_CELLS + nproof - 1] = 1
     else:
         fpw = eng.symhash()
-        proof = np.zeros(1 + 2 * nslot, dtype=np.uint64)
+        proof = np.zeros(nproof, dtype=np.uint64)
         proof[0] = missing
         proof[1 + 2 * me] = fpw[0] ^ fpw[2]
         proof[2 + 2 * me] = fpw[1] ^ fpw[3]
@@ -482,17 +518,31 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
     if exchange:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     pv = buf[PLOT_CELLS:].cpu().numpy().view(np.uint64)
+    replay_bad, replayed = int(pv[nproof - 2]) != 0, int(pv[nproof - 1]) != 0       # (sums over the ranks: the same everywhere)
     symmetric = pv[0] == 0
     if symcheck == "hash":
-        symmetric = symmetric and int(np.bitwise_xor.reduce(pv[1::2])) == 0 and int(np.bitwise_xor.reduce(pv[2::2])) == 0
+        symmetric = symmetric and int(np.bitwise_xor.reduce(pv[1:nproof - 2:2])) == 0 and int(np.bitwise_xor.reduce(pv[2:nproof - 2:2])) == 0
+    if can_replay:
+        if replay:
+            eng.replay_done(not replay_bad and bool(symmetric))
+        if replay_bad or (not symmetric and replayed):
+            # some rank ran from a record that no longer holds (or the table stopped being closed under a replayed step:
+            # the plain path decides): forget the records and run the step again
+            eng._replay_rec = None
+            eng.set_replay(False)
+            return hetmers_sharded(k, keys, counts, symcheck=symcheck, engine_factory=engine_factory, group=group, eng=eng,
+                                   fallback=fallback, splitters=splitters, prebound=True, sizes=sizes)
+        if symmetric and not replay and both is not None and (eng.replay_state() & 2):
+            eng._replay_rec = {"key": rkey, "send": send_counts, "recv": recv_counts, "both": both.clone()}
     if not symmetric:
         if not fallback:
             raise NotSymmetric("table is not closed under reverse complement with equal counts; "
                                "run the single-GPU engine (general path) or condition the table")
         _general_on_rank0(k, keys, counts, sizes, eng, plot, group, rank, world if exchange else 1, words)
         eng._splitter_cache = None          # (rank 0's engine is bound to the gathered table now)
+        eng._replay_rec = None
     st = eng.stats()
-    st.update(rank=rank, world=world, shard_nels=n, sent=nreq if exchange else 0, received=nrecv, engine=eng)
+    st.update(rank=rank, world=world, shard_nels=n, sent=nreq if exchange else 0, received=nrecv, engine=eng, replayed=replay)
     if not symmetric:
         st["path"] = 2
     return plot.clone(), st           # (the reduction buffer belongs to the engine: the caller gets its own 4 MB)

@@ -28,6 +28,22 @@ def _mix(z):
 class NumpyEngine:
     def __init__(self, device):
         self.device = device
+        self._rp_want, self._rp_rec, self._rp_active, self._rp_bad = False, None, False, 0
+
+    # ---- replay of the phase calls (smg_engine_set_replay): the stand-in does all the work every time, but hands out the
+    #      RECORDED counts and reports a difference through the fourth proof word, like the engine -------------------------
+    def set_replay(self, on):
+        self._rp_want = bool(on)
+        if not on:
+            self._rp_rec = None
+
+    def replay_state(self):
+        return (1 if self._rp_active else 0) | (2 if self._rp_rec is not None else 0)
+
+    def replay_done(self, ok):
+        if self._rp_active and not ok:
+            self._rp_rec = None
+        self._rp_active = False
 
     # ---- helpers on integer k-mers ------------------------------------------------------------------
     def _ints(self, words_u64):
@@ -154,6 +170,10 @@ class NumpyEngine:
             f ^= _mix(_mix(c & M64) ^ _mix(c >> 64) ^ _mix(int(cnt[i])))
         self.fp = [f, 0, 0, 0]
         self.symcheck = symcheck
+        self.missing = 0
+        self._rp_active = bool(self._rp_want and self._rp_rec is not None and symcheck == "hash" and exchange)
+        self._rp_bad = int(self._rp_active and self._rp_rec["emitted"] != self.nreq())
+        self._emitted = self.nreq()
 
     def nreq(self):
         return len(self.req) // (self.W + 1)
@@ -197,7 +217,17 @@ class NumpyEngine:
             keep[i] = (int(m[b >> 5]) >> (b & 31)) & 1
         self.dropped = int((~keep).sum())
         self.req = rec[keep].reshape(-1)
-        return len(self.req) // rw
+        kept = len(self.req) // rw
+        if self._rp_active:
+            if kept != self._rp_rec["kept"]:       # (the engine would have queued everything with the recorded count)
+                self._rp_bad = 1
+                want = self._rp_rec["kept"]
+                pad = np.zeros(max(want - kept, 0) * rw, dtype=np.uint64)
+                self.req = np.concatenate([self.req, pad])[: want * rw]
+            return self._rp_rec["kept"]
+        if self._rp_want and self.symcheck == "hash":
+            self._rp_rec = {"emitted": self._emitted, "kept": kept}
+        return kept
 
     def route(self, splitters, nranks, send, counts_out=None):
         rw = self.W + 1
@@ -234,8 +264,8 @@ class NumpyEngine:
         return self.missing if wait else None
 
     def proof_into(self, dst):
-        w = np.array([self.missing, self.fp[0] ^ self.fp[2], self.fp[1] ^ self.fp[3]], dtype=np.uint64)
-        dst[:3] = torch.from_numpy(w.view(np.int64).copy())
+        w = np.array([self.missing, self.fp[0] ^ self.fp[2], self.fp[1] ^ self.fp[3], self._rp_bad], dtype=np.uint64)
+        dst[:4] = torch.from_numpy(w.view(np.int64).copy())
 
     def apply_own(self):
         return self._apply(self.req)

@@ -392,6 +392,7 @@ def test_sharded_driver_on_the_real_backend_one_rank_group(k, symcheck, monkeypa
             plot, st = sharded.hetmers_sharded(k, tk, tc, symcheck=symcheck, eng=st["engine"] if _ else None)
             assert np.array_equal(plot.cpu().numpy().reshape(1001, 501), want)
             assert st["sent"] == st["received"] and st["world"] == 1
+            assert not st["replayed"]                    # (every call binds its table: a new table as far as the engine knows)
         # the 29-bit map that 8 ranks exchange (TorchEngine.pass1 picks it for world >= 8, which this box cannot be): forced
         # here, together with the table's prefix index as the shard's look-up directory (what bench.py --gpus N hands over)
         monkeypatch.setenv("SMG_BM_BITS", "29")
@@ -402,9 +403,34 @@ def test_sharded_driver_on_the_real_backend_one_rank_group(k, symcheck, monkeypa
             eng.bind(k, tk, tc, index=index)
         else:
             eng.bind(k, tk, tc)
-        for _ in range(2):
+        for _ in range(3):
             plot, st = sharded.hetmers_sharded(k, tk, tc, symcheck=symcheck, eng=eng, prebound=True)
             assert np.array_equal(plot.cpu().numpy().reshape(1001, 501), want)
+            # a step on the table of the step before is queued from recorded counts (hash proof, look-up chain: 12 <= k <= 64)
+            assert st["replayed"] == (_ > 0 and symcheck == "hash" and 12 <= k <= 64), (_, st["replayed"])
+            assert st["ms_pass1"] > 0 and st["nemitted"] >= st["nrequests"] and st["sent"] == st["received"]
+        # the table changes IN PLACE under a prebound engine (counts only: the k-mers of a bound table must stay): every 5th
+        # (k-mer, complement) couple gets counts that take its pairs over the sum limit -- other request counts, so the
+        # replayed step reports that its record does not hold and the step is run again the plain way; the answer is the
+        # oracle's for the changed table, and the step after that replays again
+        if symcheck == "hash" and 12 <= k <= 64:
+            assert st["replayed"]
+            rc = ktab.revcomp_packed(packed, k)
+            pos = {bytes(x): i for i, x in enumerate(packed)}
+            cnt2 = cnt.copy()
+            for i in range(0, len(cnt), 5):
+                cnt2[i] = 900; cnt2[pos[bytes(rc[i])]] = 900
+            tc.copy_(torch.from_numpy(cnt2.view(np.int16)).to(dev))
+            want2 = brute.hetmers_plot(packed, cnt2, k)
+            assert not np.array_equal(want2, want)
+            plot, st = sharded.hetmers_sharded(k, tk, tc, symcheck=symcheck, eng=eng, prebound=True)
+            assert np.array_equal(plot.cpu().numpy().reshape(1001, 501), want2) and not st["replayed"] and st["path"] == 1
+            plot, st = sharded.hetmers_sharded(k, tk, tc, symcheck=symcheck, eng=eng, prebound=True)
+            assert np.array_equal(plot.cpu().numpy().reshape(1001, 501), want2) and st["replayed"]
+            # ... and SMG_NO_REPLAY=1 is the round-4 step (every count read back)
+            monkeypatch.setenv("SMG_NO_REPLAY", "1")
+            plot, st = sharded.hetmers_sharded(k, tk, tc, symcheck=symcheck, eng=eng, prebound=True)
+            assert np.array_equal(plot.cpu().numpy().reshape(1001, 501), want2) and not st["replayed"]
     finally:
         dist.destroy_process_group()
 

@@ -241,3 +241,79 @@ def test_symm_splitters_follow_the_closed_table():
     sp = sharded.symm_splitters(np.concatenate([own, rcs]), bits, 4, 1)
     assert [int(v) >> (64 - bits) for v in sp] == [8, 16, 56]         # (bins 16..47 are empty: 16 and 48 cut the same place)
     assert list(sharded.symm_splitters(np.concatenate([own, rcs * 0]), bits, 2, 1)) == [np.uint64(8) << np.uint64(58)]
+
+
+# ---- replayed steps (round 5): a step on the table of the step before is queued from recorded counts ------------------
+def _replay_worker(rank, world, port, k, keys, cnt, cuts, edits, q):
+    sys.path.insert(0, HERE)
+    from fake_engine import NumpyEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = cuts[rank], cuts[rank + 1]
+        tk = torch.from_numpy(np.ascontiguousarray(keys[lo:hi]).view(np.int64).reshape(-1).copy())
+        tc = torch.from_numpy(cnt[lo:hi].view(np.int16).copy())
+        eng = NumpyEngine(torch.device("cpu"))
+        eng.bind(k, tk, tc)
+        out = []
+        for step, edit in enumerate(edits):
+            # edit = None | ("count", entry, value): the table changes IN PLACE between two steps (same tensors)
+            if edit is not None:
+                for e_, v in edit[1:]:
+                    if lo <= e_ < hi:
+                        tc[e_ - lo] = v
+                eng.bind(k, tk, tc)                       # (the stand-in copies the table at bind; the engine reads it in place)
+                eng._rp_want = True                       # ... and must keep its record, as an engine that was not re-bound would
+            plot, st = sharded.hetmers_sharded(k, tk, tc, symcheck="hash", engine_factory=NumpyEngine, eng=eng, prebound=True)
+            out.append((st["path"], bool(st.get("replayed")), plot.numpy().copy()))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,k", [(2, 12), (3, 13)])
+def test_replayed_steps_and_a_table_that_changes_under_them(world, k):
+    """Step 1 runs the plain way and leaves records (the engine's counts, the driver's send / receive counts); step 2 on the
+    same table is queued from them and must give the same plot; before step 3 counts change in place so that pairs drop out
+    (another number of requests on one rank): the replayed step reports the mismatch, EVERY rank runs the step again the
+    plain way, and the answer is the oracle's for the changed table; step 4 replays again; before step 5 one count of a
+    (k-mer, complement) couple changes alone: the table is not closed any more, the replayed step is settled by the plain
+    path and the general path on rank 0 answers."""
+    keys, cnt = synth.diploid_table_u64(3000, k=k, seed=11 + world, het_frac=0.5, cov=30, L=5)
+    n = len(cnt)
+    cuts = [sharded.fix_cut(keys, 1, k, c) for c in sharded.shard_bounds(n, world)]
+    rc = ktab.revcomp_u64(keys, k)
+    pos = {int(x): i for i, x in enumerate(keys)}
+    # couples (x, rc x), x != rc x: set both counts to 900 -> every pair of either exceeds the sum limit; every 7th couple of
+    # the table, so that requests certainly drop out
+    cnt3 = cnt.copy()
+    changed = []
+    for i in range(0, n, 7):
+        if int(rc[i]) != int(keys[i]):
+            j = pos[int(rc[i])]
+            cnt3[i] = 900; cnt3[j] = 900
+            changed += [(i, 900), (j, 900)]
+    i = changed[0][0]
+    cnt5 = cnt3.copy(); cnt5[i] = 901                                     # (not closed: the counts of the couple differ)
+    want1 = brute.hetmers_plot(ktab.u64_to_packed(keys, k), cnt, k)
+    want3 = brute.hetmers_plot(ktab.u64_to_packed(keys, k), cnt3, k)
+    want5 = brute.hetmers_plot(ktab.u64_to_packed(keys, k), cnt5, k)
+    edits = [None, None, ("count", *changed), None, ("count", (i, 901))]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_replay_worker, args=(r, world, port, k, keys, cnt, cuts, edits, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        steps = res[rank]
+        assert [s[0] for s in steps] == [1, 1, 1, 1, 2], rank
+        for s, want in zip(steps, [want1, want1, want3, want3, want5]):
+            assert np.array_equal(s[2].reshape(1001, 501), want), rank
+        assert steps[0][1] is False and steps[1][1] is True and steps[3][1] is True
+        assert steps[2][1] is False and steps[4][1] is False           # (settled by the plain path)

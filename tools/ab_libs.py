@@ -26,6 +26,14 @@ n = cnt.numel()
 plot = torch.zeros(engine.PLOT_CELLS, dtype=torch.int64, device=dev)
 print(f"# {wl} G={G} k={k} n={n}", flush=True)
 first = None
+golden = None
+try:
+    import json
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_tables.json"))).get(wl)
+    if g and g["genome"] == G and g["k"] == k:
+        golden = open(os.path.join(ROOT, "tests", "golden", g["smu_file"])).read()
+except Exception:
+    pass
 for spec in sys.argv[2:]:
     parts = spec.split(":")
     path, envs = parts[0], dict(p.split("=", 1) for p in parts[1:])
@@ -45,8 +53,9 @@ for spec in sys.argv[2:]:
         m = lambda key: sum(x[key] for x in r) / len(r)
         h = hashlib.sha256(plot.cpu().numpy().tobytes()).hexdigest()[:12]
         if first is None: first = h
+        gold = "" if golden is None else (" golden-ok" if engine.smu_text(plot.cpu().numpy().reshape(1001, 501)) == golden else " GOLDEN-MISMATCH")
         print(f"{spec:58s} total {m('ms_total'):7.3f} p1 {m('ms_pass1'):6.3f} (bigfix {m('ms_bigfix'):5.3f}) lookup {m('ms_rclookup'):6.3f} (part {m('ms_filter'):5.3f}) "
-              f"p2 {m('ms_pass2'):5.3f}  kept {int(m('nrequests'))} of {int(m('nemitted'))} path {r[-1]['path']} plot {h} {'same' if h == first else 'DIFFERENT'}", flush=True)
+              f"p2 {m('ms_pass2'):5.3f}  kept {int(m('nrequests'))} of {int(m('nemitted'))} path {r[-1]['path']} plot {h} {'same' if h == first else 'DIFFERENT'}{gold}", flush=True)
         e.close()
     except Exception as ex:
         print(f"{spec:58s} FAILED {ex}", flush=True)
