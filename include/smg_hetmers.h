@@ -177,7 +177,11 @@ int smg_engine_decode(smg_engine *e, int kmer, int ibyte, int64_t nels,
 /* Bind an already decoded device table (not copied; must outlive the engine's use of it):
    d_keys  = nels * words 64-bit words, k-mer left aligned (base 0 in bits 63..62 of word 0),
              words = ceil(k/32), entries strictly increasing;
-   d_counts= nels uint16.                                                                     */
+   d_counts= nels uint16.
+   While a table is bound its K-MERS must not change (the engine keeps what it has learnt about them between runs: the
+   first and the last k-mer, the directory made of the table's prefix index); its COUNTS may -- every run reads them
+   again, and a run that was queued from the counts of the run before (smg_engine_run on the same table, replayed
+   phase steps) notices the difference and is repeated the plain way.  Bind again after changing k-mers.            */
 int smg_engine_bind(smg_engine *e, int kmer, int64_t nels, const uint64_t *d_keys,
                     const uint16_t *d_counts, char *errbuf, size_t errlen);
 
@@ -226,6 +230,10 @@ int smg_engine_table(smg_engine *e, int64_t *nels, const uint64_t **d_keys, cons
    control read-backs between phases.                                                         */
 int smg_engine_run(smg_engine *e, int symcheck, int64_t *d_plot, smg_stats *stats,
                    char *errbuf, size_t errlen);
+
+/* (smg_hetmers_run / _run_source on a table that does not fit the device run it OUT OF CORE, prefix shards one after the other
+   with the table read twice: there symcheck = SMG_SYM_NONE is taken as SMG_SYM_HASH -- the shards cannot help each other on a
+   table that is not closed, which is refused with SMG_ENOTSYM and the advice to condition it first.)                    */
 
 /* ---- sharded (one process per GPU) phase calls ------------------------------------------
    The table is split by k-mer PREFIX: rank r owns the entries in [splitter[r-1], splitter[r]).

@@ -42,9 +42,20 @@
 #define CODE_W2     64
 #define CODE_DEFER  0xFF                  // placeholder until kf_bigfix has redone the entry
 #define CODE_P      0x80                  // set by the look-ups: the entry has a prefix-side pair ("P flag")
-// Exactly one request can name an entry (the one from its reverse complement), so the read-modify-write of the
-// byte needs no atomic; bytes of other entries are untouched by a byte store.
+// The flag is a BLIND byte store (round 5; rounds 1-4 read the byte, ORed the flag in and stored it: a dependent load that
+// misses the L2 for every look-up, 7.3e7 of them on the hexaploid table).  An entry with a prefix-side pair can neither be
+// counted as a candidate nor as the partner of one -- every reader of a code byte (kf_pass2 and its far twins, kf_extract)
+// tests the flag before anything else of the byte matters -- so what its low bits said is of no further use: the byte
+// becomes CODE_P | CODE_NONE.  Bytes of other entries are untouched by a byte store, and a second request that names the
+// entry (there is at most one: the one from its reverse complement) would store the same value.
+#ifndef L_BLIND_P
+#define L_BLIND_P 1                       // 0: read - or - store (A/B builds)
+#endif
+#if L_BLIND_P
+#define SET_P(A, j) ((A).code[j] = (uint8_t) CODE_P)
+#else
 #define SET_P(A, j) ((A).code[j] = (uint8_t) ((A).code[j] | CODE_P))
+#endif
 
 #define P2_TPB   1024
 #define P2_SMAX  208                  // LDS plot tile covers sums < P2_SMAX (43.7 KB; with the 32 KB queue: 2 WGs/CU)

@@ -1392,7 +1392,11 @@ static int apply_sorted(smg_engine *e, const u64 *keys_in, int64_t nsort, int ho
   int64_t nb = (nsort + F_TPB - 1) / F_TPB;
   if (nb > 16384) nb = 16384;
   const u64 *src = keys_in;
-  if (nsort >= SORT_MIN)
+  // (a short list -- what one rank of eight receives -- is looked up as it comes: the sort is eight launches, ~90 us, to put
+  //  a few hundred thousand look-ups in order, which take 70 us either way)
+  int64_t sort_min = 1 << 21;
+  { const char *v = getenv("SMG_APPLY_SORT_MIN"); if (v && atoll(v) >= SORT_MIN) sort_min = atoll(v); }
+  if (nsort >= sort_min)
     { if ((rc = grow(&e->req2, &e->req2_cap, nsort * (int64_t) sizeof(u64), errbuf, errlen))) return rc;
       size_t tmp = 0;
       unsigned lobit = 40;                   // tuning knob: sort on bits [lobit, 64) of the k-mer
@@ -2161,6 +2165,7 @@ extern "C" int smg_engine_run(smg_engine *e, int symcheck, int64_t *d_plot, smg_
             }
           if (src != SMG_ERETRY) return src;
           e->spec_ok = false;                // (the counts moved -- not the table this engine ran last time: the plain way)
+          e->have_ends = false;              // (... which reads the table's first and last k-mer again)
           e->st.ms_pass1 = e->st.ms_rclookup = e->st.ms_pass2 = 0;
         }
       rc = fast_pass1(e, exact, exact, symcheck == SMG_SYM_HASH, errbuf, errlen);
@@ -2769,11 +2774,17 @@ static int host_run(const smg_table_source *tv, const smg_opts *opts, int64_t *p
             double limit = 0;
             { const char *hl = getenv("SMG_HBM_LIMIT"); if (hl && atof(hl) > 0) limit = atof(hl); }
             if (limit <= 0 && hipSetDevice(device) == hipSuccess && hipMemGetInfo(&fr, &tot) == hipSuccess) limit = 0.9 * (double) fr;
-            const double all = (double) tv->nels * (8.0 * W + 12.0);
-            if (limit > 0 && all > limit)
-              { const double keep = (double) tv->nels * (1.0 + 2.4 * W);             // code bytes + requests of every shard
+            // what a run in core takes per entry: k-mers 8 W, count 2, code byte 1, deferred-entry map and lists 0.6, the request
+            // list (a quarter of the entries + slack) and its partitioned copy ~2.6 W -- and the candidate map (1 GiB at most)
+            const double all = (double) tv->nels * (10.6 * W + 5.5) + 1.1e9;
+            // (conditioning and the extract leg only exist in core: such a run is tried there, and says so itself if it cannot be held)
+            if (limit > 0 && all > limit && !labels && !(opts && opts->condition))
+              { // what a shard leaves behind: its code bytes and its requests -- every entry's (W + 1 words) under the exact
+                // proof, those of the owners of a pair at p > k-1-p otherwise (17 % of a diploid table, 36 % of a polyploid one)
+                const bool exact = symcheck == SMG_SYM_EXACT;
+                const double keep = (double) tv->nels * (1.0 + (exact ? 8.0 * (W + 1) : 0.36 * 8.0 * W));
                 for (int q = 2; q <= SMG_MAXGPU && !seq; q++)
-                  if (keep + (double) tv->nels / q * (8.0 * W + 14.0) <= limit && tv->nels / q < 0xFFFFFFF0ll - 16) seq = q;
+                  if (keep + (double) tv->nels / q * (10.6 * W + 5.5) <= limit && tv->nels / q < 0xFFFFFFF0ll - 16) seq = q;     // (no map out of core)
                 if (!seq)
                   return fail(errbuf, errlen, SMG_ENOMEM, "the table does not fit the device even shard by shard (16 shards, a code byte and "
                               "the requests of every entry resident): use SMUDGEPLOT_GPUS%s");

@@ -467,6 +467,9 @@ static int host_run_sequential(const smg_table_source *tv, const smg_opts *opts,
   std::vector<uint64_t *> send((size_t) n, (uint64_t *) NULL);
   std::vector<u64> splitters((size_t) (n > 1 ? n - 1 : 1) * W, 0);
   multi_cuts(tv, n, cut.data());
+  for (int sh = 0; sh < n; sh++)          // (a forced shard count -- SMG_SEQUENTIAL_SHARDS -- may leave a shard too large to index)
+    if (cut[sh + 1] - cut[sh] >= 0xFFFFFFF0ll - 16)
+      return fail(errbuf, errlen, SMG_EINVAL, "out of core: a shard of more than 2^32 entries (more shards are needed)%s");
   { // a splitter = the prefix bucket a shard starts with (cuts are bucket boundaries): everything in front is smaller
     const int64_t ixlen = 1ll << (8 * tv->ibyte);
     for (int sh = 1; sh < n; sh++)

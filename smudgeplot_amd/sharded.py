@@ -424,7 +424,11 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
     # in the one all_reduce.  A mismatch anywhere makes every rank run the step again the plain way.
     rkey = (tag, symcheck, world)
     rec = getattr(eng, "_replay_rec", None)
-    can_replay = (exchange and symcheck == "hash" and hasattr(eng, "set_replay") and os.environ.get("SMG_NO_REPLAY") != "1"
+    # OFF unless SMG_REPLAY=1: on ONE GPU with every collective forced it does not pay (2.72 against 2.64 ms per step at an
+    # eighth of the 1 Gbp table, profiles/r05_rank_share_forced_exchange.txt: what three host reads cost is what the checks of
+    # the replayed step cost) -- it is there for runs over a fabric, where a host read in the middle of a step also waits
+    # for the slowest rank, and has never run on more than one device.
+    can_replay = (exchange and symcheck == "hash" and hasattr(eng, "set_replay") and os.environ.get("SMG_REPLAY") == "1"
                   and not owned)
     if can_replay:
         if rec is None or rec["key"] != rkey:

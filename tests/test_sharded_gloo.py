@@ -249,6 +249,7 @@ def _replay_worker(rank, world, port, k, keys, cnt, cuts, edits, q):
     from fake_engine import NumpyEngine
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["SMG_REPLAY"] = "1"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         lo, hi = cuts[rank], cuts[rank + 1]
