@@ -150,9 +150,18 @@ def cpu_baseline(workload: str, sample_genome: int, k: int, dev):
             subprocess.run([ref, f"-e{L}", f"-T{cores}", "-ocpu", "t.ktab"], cwd=d, check=True,
                            capture_output=True)
             best = time.time() - t0
-    return {"value": cnt.numel() / best, "unit": "k-mers/s", "cores": cores, "kind": "reference",
-            "sample": f"reference hetmers -T{cores} on a {cnt.numel()}-entry table of the same generator "
-                      f"(genome {sample_genome} bp, k={k}; warm second run, {best:.1f} s wall)"}
+    out = {"value": cnt.numel() / best, "unit": "k-mers/s", "cores": cores, "kind": "reference",
+           "sample": f"reference hetmers -T{cores} on a {cnt.numel()}-entry table of the same generator "
+                     f"(genome {sample_genome} bp, k={k}; warm second run, {best:.1f} s wall)"}
+    # the reference on the IDENTICAL full-size table takes minutes: measured once per round by
+    # tools/e2e_full_table.py on the GPU box and kept under profiles/ -- quoted here, not re-run in the driver's time
+    ident = {"uniform": ("profiles/r04_e2e_config3_full.json", 2535258108, 156.03),
+             "octoploid": ("profiles/r04_e2e_octoploid_full.json", 637035910, 42.57),
+             "hexaploid": ("profiles/r04_e2e_hexaploid_k51_full.json", 1356853458, 141.82)}.get(workload)
+    if ident and sample_genome * 25 == default_genome(workload) and k == default_k(workload):
+        out["identical_table"] = {"kmers_per_s": ident[1] / ident[2], "wall_s": ident[2], "entries": ident[1], "cores": 64,
+                                  "source": ident[0] + " (reference -T64 on this bench table's files, byte-identical .smu)"}
+    return out
 
 
 def main():

@@ -270,12 +270,18 @@ int     smg_engine_apply_own(smg_engine *e, int64_t *missing, char *errbuf, size
    1 if a replayed step (below) did not find the counts it was queued with, else 0 } of this shard, written in stream order -- a sharded run appends them to the histogram buffer of its final all_reduce
    without a host round trip (the residues of the ranks combine by XOR: give each rank its own two words).            */
 int     smg_engine_proof(smg_engine *e, uint64_t *d_dst, char *errbuf, size_t errlen);
+/* ... or the whole proof tail of a sharded step's reduction buffer in one launch: d_tail[0] = missing, d_tail[1 + 2 slot],
+   d_tail[2 + 2 slot] = this shard's residue words (the other ranks' slots are zeroed: a SUM over the ranks then hands every
+   rank all residues), d_tail[1 + 2 nslots] = a replayed step found other counts, d_tail[2 + 2 nslots] = 1 if this step was a
+   replayed one: 3 + 2 nslots words.                                                                                      */
+int     smg_engine_proof_tail(smg_engine *e, uint64_t *d_tail, int nslots, int slot, char *errbuf, size_t errlen);
 /* Replay of the phase calls (round 5; what smg_engine_run does for a single shard, for the sharded drivers).  With
    set_replay(e, 1) a step pass1 -> [presort] -> filter -> route_device -> apply(missing = NULL) -> pass2 -> proof on a table
    whose PREVIOUS step went the same way (hash proof, k <= 64, look-up chain) is queued without a single read-back: the
    counts the host needs between the calls (requests emitted, deferred entries, requests kept) are last step's -- functions of
-   the table and of the exchanged maps -- and the device compares them with this step's; a difference, an overflow or an
-   order violation is reported through smg_engine_proof as d_dst[3] != 0.  The caller reads the proof words
+   the table and of the exchanged maps -- and the device compares them with this step's (and the per-destination totals of
+   route_device with the recorded ones: the caller splits its exchange by those); a difference, an overflow or an order
+   violation is reported through smg_engine_proof as d_dst[3] != 0.  The caller reads the proof words
    (its one host wait of the step), tells the engine with replay_done(e, ok) -- ok = 0 drops the record -- and on a failure
    runs the step again, which then takes the plain path.  replay_state: bit 0 = the current step is a replayed one, bit 1 =
    a record exists.  Binding or conditioning a table drops the record.  No counterpart in the reference.                 */

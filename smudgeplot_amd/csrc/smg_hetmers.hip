@@ -587,7 +587,10 @@ struct smg_engine
   // of the table and of the exchanged maps), the device compares them with this step's and reports through smg_engine_proof
   bool         rp_want, rp_have, rp_active;    // asked for / a record exists / the current step runs from the record
   int64_t      rp_nreq, rp_nbig, rp_nf_req;    //   pass 1: requests, deferred entries; filter: requests kept
-  unsigned     rp_nf_chunks, rp_grid;          //   filter: chunks of the kept list; pass-1 grid (rows of `partials`)
+  unsigned     rp_nf_chunks, rp_grid;          //   filter: chunks of the kept list (the list the routing kernels walk); pass-1 grid (rows of `partials`)
+  unsigned     rp_seen_chunks;                 //   chunks the plain step's filter filled (a replayed step walks that many + slack)
+  u64         *rp_totals;  int rp_nranks;      //   router: per-destination totals of the recorded step (device, 16 words) and of this step (16 more)
+  bool         rp_routed;                      //   ... this step's totals are there to be compared
   int          rp_bm_bits, rp_sym;             //   map geometry and proof the record belongs to
   u64         *req;    int64_t req_cap;      // bytes
   u64         *req2;   int64_t req2_cap;     // radix sort output
@@ -688,7 +691,7 @@ extern "C" smg_engine *smg_engine_create(int device, void *stream, char *errbuf,
   e->bm_cap = 30;
   if (hipMalloc(&e->ctrl, sizeof(Ctrl)) != hipSuccess
       || hipHostMalloc(&e->h_ctrl, sizeof(Ctrl)) != hipSuccess
-      || hipMalloc(&e->partials, sizeof(u64) * 4 * P1_MAXGRID) != hipSuccess
+      || hipMalloc(&e->partials, sizeof(u64) * 4 * (P1_MAXGRID + 1)) != hipSuccess      // (+ a row for the proof words)
       || hipHostMalloc(&e->h_partials, sizeof(u64) * 4 * P1_MAXGRID) != hipSuccess
       || hipMalloc(&e->d_split, sizeof(u64) * 16 * 4) != hipSuccess
       || hipMalloc(&e->p1cold, sizeof(P1Cold)) != hipSuccess
@@ -710,7 +713,7 @@ extern "C" void smg_engine_destroy(smg_engine *e)
   hipFree(e->own_keys); hipFree(e->own_cnt); hipFree(e->deg); hipFree(e->sig); hipFree(e->bstart); hipFree(e->ixdir);
   hipFree(e->req); hipFree(e->req2); hipFree(e->sort_tmp); hipFree(e->dense); hipFree(e->chunk_off); hipFree(e->skey[0]); hipFree(e->skey[1]); hipFree(e->sidx[0]); hipFree(e->sidx[1]); hipFree(e->dbits); hipFree(e->biglist); hipFree(e->farp); hipFree(e->p1times); hipFree(e->p1tick); hipFree(e->xtick); hipFree(e->chunk_fill); hipFree(e->bmap); hipFree(e->reqf); hipFree(e->chunk_fillf); hipFree(e->route_cnt); hipFree(e->route_off);
   hipFree(e->partials); hipFree(e->ctrl); hipFree(e->d_split); hipFree(e->p1cold); hipFree(e->ghist); hipFree(e->boff);
-  hipFree(e->whist);
+  hipFree(e->whist); hipFree(e->rp_totals);
   hipHostFree(e->h_ctrl); hipHostFree(e->h_partials); hipHostFree(e->h_p1cold);
   for (int i = 0; i < 13; i++) hipEventDestroy(e->ev[i]);
   delete e;
@@ -1534,7 +1537,10 @@ static int lookup_probe(smg_engine *e, const uint32_t *map, bool list, unsigned 
       { int rc2;
         if ((rc2 = grow(&e->xtick, &e->xtick_cap, (int64_t) PX_NXCD * PX_TICKW * 4, errbuf, errlen))) return rc2;
         HIPCHK(hipMemsetAsync(e->xtick, 0, (size_t) PX_NXCD * PX_TICKW * 4, e->stream));
-        unsigned xw = PX_WGS, part = PX_PART;               // (tuning: SMG_PX_WGS workgroups per CU, SMG_PX_PART requests per ticket)
+        // tickets of 2048 requests where many requests survive (polyploid tables: one in seven, all real hits -- half as many
+        // buckets in flight per XCD keep more of a bucket's k-mer lines in reach: -0.25 ms on the hexaploid table), 4096 where the
+        // kernel is mostly streaming (a table with repeats: 1 request in 50 survives, and a ticket's fixed cost shows: +0.5 ms at 2048)
+        unsigned xw = PX_WGS, part = e->st.nemitted * 100 > e->n * 28 ? PX_PART : 2 * PX_PART;   // (tuning: SMG_PX_WGS workgroups per CU, SMG_PX_PART requests per ticket)
         { const char *v = getenv("SMG_PX_WGS"); if (v && atoi(v) > 0 && atoi(v) <= 8) xw = (unsigned) atoi(v);
           v = getenv("SMG_PX_PART"); if (v && atoi(v) >= 512) part = (unsigned) atoi(v) & ~511u;
           if (getenv("SMG_PX_ONE_XCC")) part |= 0x80000000u;                    // (tests: every workgroup claims XCD 0)
@@ -1598,6 +1604,8 @@ static int fast_filter(smg_engine *e, const uint32_t *map, char *errbuf, size_t 
       // way the buckets fall to the workgroups -- so the routing kernels walk the whole list, and a chunk nobody opened must
       // read as empty
       hipEventRecord(e->ev[11], e->stream);
+      // (as many chunks as the recorded step's filter filled, and some: the device checks that this step stayed inside)
+      if (e->rp_seen_chunks + 64u < maxout) maxout = e->rp_seen_chunks + 64u;
       HIPCHK(hipMemsetAsync(e->chunk_fillf, 0, (size_t) maxout * 4, e->stream));
     }
   if (!e->presorted && (rc = filter_presort(e, errbuf, errlen))) return rc;
@@ -1647,7 +1655,9 @@ static int fast_filter(smg_engine *e, const uint32_t *map, char *errbuf, size_t 
   // what a replayed step on this table may take for granted (key-only records through the look-up chain, k <= 64)
   e->rp_have = e->rp_want && e->presorted == 3 && e->W <= 2 && e->rw == e->W && !e->h_p1cold->times;
   if (e->rp_have)
-    { e->rp_nreq = e->st.nemitted; e->rp_nbig = e->st.nbig; e->rp_nf_req = e->st.nrequests; e->rp_bm_bits = e->bm_bits; }
+    { e->rp_nreq = e->st.nemitted; e->rp_nbig = e->st.nbig; e->rp_nf_req = e->st.nrequests; e->rp_bm_bits = e->bm_bits;
+      e->rp_seen_chunks = e->n_chunks; e->rp_nranks = 0;
+    }
   return SMG_OK;
 }
 
@@ -1827,7 +1837,7 @@ extern "C" int smg_engine_pass1(smg_engine *e, int symcheck, char *errbuf, size_
       e->spec_nreq = e->rp_nreq; e->spec_nbig = e->rp_nbig;
       const int rc = fast_pass1(e, 0, 0, 1, errbuf, errlen, true);
       if (rc) return rc;
-      e->rp_active = true;
+      e->rp_active = true; e->rp_routed = false;
       return SMG_OK;
     }
   e->rp_sym = symcheck;
@@ -1884,35 +1894,73 @@ __global__ void k_proof_words(const Ctrl *__restrict__ ctrl, int fast, u64 f0, u
 // the same for a replayed step: the fingerprint residue is folded from the workgroups' partial words on the device, and the
 // counts the step was queued with are compared with what its kernels reported -- any difference sets dst[3], on which the
 // caller (all ranks of a sharded run: the word is summed with the proof) drops the record and runs the step again the plain way
-struct ReplayExpect { u64 nreq, nf_req; unsigned nbig, nf_chunks, max_chunks, grid; };
+struct ReplayExpect { u64 nreq, nf_req; unsigned nbig, nf_chunks, max_chunks, grid; const u64 *totals; int nranks; };
 __global__ void __launch_bounds__(64)
 k_proof_replay(const Ctrl *__restrict__ ctrl, const u64 *__restrict__ partials, ReplayExpect x, u64 *__restrict__ dst)
 { u64 f0 = 0, f1 = 0;
   for (unsigned b = threadIdx.x; b < x.grid; b += 64)
     { f0 ^= partials[(size_t) b * 4] ^ partials[(size_t) b * 4 + 2]; f1 ^= partials[(size_t) b * 4 + 1] ^ partials[(size_t) b * 4 + 3]; }
   f0 = wave_xor_u64(f0); f1 = wave_xor_u64(f1);
+  // the router's per-destination totals: recorded step in totals[0..16), this step in totals[16..32)
+  bool moved = x.totals == NULL;
+  if (x.totals && (int) threadIdx.x < x.nranks) moved = x.totals[threadIdx.x] != x.totals[16 + threadIdx.x];
+  const bool anymoved = __ballot(moved) != 0;
   if (threadIdx.x == 0)
     { const FastCtl &f = ctrl->fast;
       const bool bad = f.unsorted != 0 || f.n_chunks > x.max_chunks || f.nbig != x.nbig || f.nreq != x.nreq
-                       || f.nf_chunks > x.nf_chunks || f.nf_req != x.nf_req;
+                       || f.nf_chunks > x.nf_chunks || f.nf_req != x.nf_req || anymoved;
       dst[0] = (u64) f.missing; dst[1] = f0; dst[2] = f1; dst[3] = bad ? 1ull : 0ull;
     }
+}
+
+// the proof tail of a sharded step's reduction buffer in ONE launch: tail[0] = missing, tail[1 + 2 s .. 2 + 2 s] = this rank's
+// residue in ITS slot s (zeros in the others'), tail[1 + 2 nslots] = a replayed step found other counts, tail[2 + 2 nslots] =
+// this step was a replayed one; src = the four words of k_proof_words / k_proof_replay
+__global__ void __launch_bounds__(64)
+k_proof_tail(const u64 *__restrict__ src, int nslots, int slot, int replayed, u64 *__restrict__ tail)
+{ const int n = 3 + 2 * nslots;
+  for (int i = threadIdx.x; i < n; i += 64)
+    { u64 v = 0;
+      if (i == 0) v = src[0];
+      else if (i == 1 + 2 * slot) v = src[1];
+      else if (i == 2 + 2 * slot) v = src[2];
+      else if (i == n - 2) v = src[3];
+      else if (i == n - 1) v = replayed ? 1ull : 0ull;
+      tail[i] = v;
+    }
+}
+
+static int proof_words(smg_engine *e, u64 *d_dst, char *errbuf, size_t errlen)
+{ if (e->rp_active)
+    { ReplayExpect x;
+      x.nreq = (u64) e->rp_nreq; x.nf_req = (u64) e->rp_nf_req; x.nbig = (unsigned) e->rp_nbig; x.nf_chunks = e->rp_nf_chunks;
+      x.max_chunks = e->max_chunks; x.grid = e->rp_grid;
+      x.totals = e->rp_routed ? e->rp_totals : (const u64 *) NULL; x.nranks = e->rp_nranks;     // (not routed: nothing to vouch for the split)
+      hipLaunchKernelGGL(k_proof_replay, dim3(1), dim3(64), 0, e->stream, (const Ctrl *) e->ctrl, (const u64 *) e->partials, x, d_dst);
+    }
+  else
+    hipLaunchKernelGGL(k_proof_words, dim3(1), dim3(64), 0, e->stream,
+                       (const Ctrl *) e->ctrl, e->fast ? 1 : 0, e->fp[0] ^ e->fp[2], e->fp[1] ^ e->fp[3], d_dst);
+  HIPCHK(hipGetLastError());
+  return SMG_OK;
 }
 
 extern "C" int smg_engine_proof(smg_engine *e, uint64_t *d_dst, char *errbuf, size_t errlen)
 { NEED_ENGINE(e)
   if (!e->prepared || !d_dst) return fail(errbuf, errlen, SMG_EINVAL, "proof before pass1%s");
   HIPCHK(hipSetDevice(e->device));
-  if (e->rp_active)
-    { ReplayExpect x;
-      x.nreq = (u64) e->rp_nreq; x.nf_req = (u64) e->rp_nf_req; x.nbig = (unsigned) e->rp_nbig; x.nf_chunks = e->rp_nf_chunks;
-      x.max_chunks = e->max_chunks; x.grid = e->rp_grid;
-      hipLaunchKernelGGL(k_proof_replay, dim3(1), dim3(64), 0, e->stream, (const Ctrl *) e->ctrl, (const u64 *) e->partials, x, (u64 *) d_dst);
-    }
-  else
-  hipLaunchKernelGGL(k_proof_words, dim3(1), dim3(64), 0, e->stream,
-                     (const Ctrl *) e->ctrl, e->fast ? 1 : 0, e->fp[0] ^ e->fp[2], e->fp[1] ^ e->fp[3],
-                     (u64 *) d_dst);
+  return proof_words(e, (u64 *) d_dst, errbuf, errlen);
+}
+
+extern "C" int smg_engine_proof_tail(smg_engine *e, uint64_t *d_tail, int nslots, int slot, char *errbuf, size_t errlen)
+{ NEED_ENGINE(e)
+  if (!e->prepared || !d_tail || nslots < 1 || nslots > 16 || slot < 0 || slot >= nslots)
+    return fail(errbuf, errlen, SMG_EINVAL, "proof_tail: 1..16 slots, after pass1%s");
+  HIPCHK(hipSetDevice(e->device));
+  u64 *tmp = e->partials + (size_t) 4 * P1_MAXGRID;           // (the row behind the workgroups' partial sums)
+  int rc = proof_words(e, tmp, errbuf, errlen);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_proof_tail, dim3(1), dim3(64), 0, e->stream, (const u64 *) tmp, nslots, slot, e->rp_active ? 1 : 0, (u64 *) d_tail);
   HIPCHK(hipGetLastError());
   return SMG_OK;
 }
@@ -2070,7 +2118,16 @@ extern "C" int smg_engine_route_device(smg_engine *e, const uint64_t *splitters,
   if (!e->prepared) return fail(errbuf, errlen, SMG_EINVAL, "route before pass1%s");
   HIPCHK(hipSetDevice(e->device));
   if (e->st.nrequests > capacity) return fail(errbuf, errlen, SMG_EINVAL, "send buffer too small%s");
-  return route_records(e, e->req, e->chunk_fill, e->n_chunks, e->rw, splitters, nranks, d_send, NULL, errbuf, errlen, d_counts);
+  int rc = route_records(e, e->req, e->chunk_fill, e->n_chunks, e->rw, splitters, nranks, d_send, NULL, errbuf, errlen, d_counts);
+  if (rc || !e->rp_want || !e->fast) return rc;
+  // replay: the per-destination totals of a plain step are kept, those of a replayed step are put beside them -- the verdict
+  // kernel (smg_engine_proof) compares the two: the caller splits its exchange by the RECORDED totals
+  if (!e->rp_totals) HIPCHK(hipMalloc(&e->rp_totals, sizeof(u64) * 32));
+  const bool rep = e->rp_active;
+  if (rep && e->rp_nranks != nranks) { e->rp_routed = false; return SMG_OK; }
+  HIPCHK(hipMemcpyAsync(e->rp_totals + (rep ? 16 : 0), d_counts, sizeof(u64) * nranks, hipMemcpyDeviceToDevice, e->stream));
+  if (rep) e->rp_routed = true; else e->rp_nranks = nranks;
+  return SMG_OK;
 }
 
 extern "C" int smg_engine_pass2(smg_engine *e, int64_t *d_plot, char *errbuf, size_t errlen)

@@ -413,7 +413,7 @@ kl_probe(FastArgs A, const u64 *__restrict__ recs, const u64 *__restrict__ boff,
 // kl_probe.  Needs >= 8 buckets (nb >= 3); the XCD is the hardware's XCC id (HW_REG_XCC_ID: the dispatcher's round-robin is
 // not taken for granted, nor is the number of XCDs -- see the stealing loop).
 #define PX_TPB   256
-#define PX_PART  2048                     // requests per ticket (with PX_WGS workgroups per CU: ~0.6 buckets in flight per XCD; 4096: +2 ... 4 %, 1024: +10 %)
+#define PX_PART  2048                     // requests per ticket on a table with many survivors (~0.6 buckets in flight per XCD; lookup_probe doubles it elsewhere)
 #define PX_WGS   4
 #define PX_PER   8                        // requests per lane and step
 #define PX_NXCD  8

@@ -64,7 +64,7 @@ EXPORTS = [
     "smg_engine_apply_own", "smg_engine_blockmap", "smg_engine_blockmap_copy", "smg_engine_filter",
     "smg_engine_presort", "smg_engine_merge_maps", "smg_engine_set_blockmap_bits",
     "smg_engine_symhash", "smg_engine_pass2", "smg_engine_stats", "smg_engine_proof",
-    "smg_engine_set_replay", "smg_engine_replay_state", "smg_engine_replay_done",
+    "smg_engine_set_replay", "smg_engine_replay_state", "smg_engine_replay_done", "smg_engine_proof_tail",
     "smg_engine_symm_hist", "smg_engine_symm_route", "smg_engine_symm_finish", "smg_engine_table",
     "smg_engine_extract", "smg_hetmers_extract", "smg_free", "smg_condition_table", "smg_version",
 ]
@@ -136,6 +136,7 @@ def load_library():
     lib.smg_engine_merge_maps.argtypes = [vp, vp, i64, i32, C.POINTER(i64), C.POINTER(i64), vp, *err]
     lib.smg_engine_symhash.argtypes = [vp, C.POINTER(C.c_uint64), *err]
     lib.smg_engine_proof.argtypes = [vp, vp, *err]
+    lib.smg_engine_proof_tail.argtypes = [vp, vp, i32, i32, *err]
     lib.smg_engine_set_replay.argtypes = [vp, i32]
     lib.smg_engine_replay_state.argtypes = [vp]
     lib.smg_engine_replay_done.argtypes = [vp, i32, *err]
@@ -363,6 +364,10 @@ class Engine:
     def proof_into(self, dst_ptr: int):
         """device uint64[3] at dst_ptr <- (missing complements, fingerprint residue words), in stream order"""
         _check(self.lib.smg_engine_proof(self.h, dst_ptr, self._buf, 512), self._buf)
+
+    def proof_tail(self, tail_ptr: int, nslots: int, slot: int):
+        """device uint64[3 + 2 nslots] at tail_ptr <- the proof words of this shard laid out for the final all_reduce (one launch)"""
+        _check(self.lib.smg_engine_proof_tail(self.h, tail_ptr, nslots, slot, self._buf, 512), self._buf)
 
     def set_replay(self, on: bool):
         """queue the phase calls of a step from the counts of the step before (smg_hetmers.h: smg_engine_set_replay)"""

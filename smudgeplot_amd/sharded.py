@@ -111,6 +111,10 @@ class TorchEngine:
         counts than it was queued with), in stream order"""
         self.e.proof_into(dst.data_ptr())
 
+    def proof_tail(self, tail, nslots, slot):
+        """tail: int64 tensor of 3 + 2 nslots words (the end of the reduction buffer) <- the whole proof tail, one launch"""
+        self.e.proof_tail(tail.data_ptr(), nslots, slot)
+
     def set_replay(self, on):
         self.e.set_replay(on)
 
@@ -208,12 +212,29 @@ def fix_cut(keys_u64: np.ndarray, words: int, k: int, cut: int) -> int:
 def blockmap_ranges(splitters, words: int, world: int, bits: int, scale: int = 1):
     """Word ranges (first word, length) of the candidate block map that the k-mer ranges of the ranks cover.
     Block id = leading `bits` bits of a k-mer; rank r holds ids [id(first_r), id(first_{r+1})], so neighbours
-    share their boundary word (the receiver ORs the ranges together).  scale = 32-bit words per 32 block ids
-    (2 for the engine's two-bit map: 64 bits per group)."""
+    share their boundary word (the receiver ORs the ranges together) -- unless the splitter is a CUT VALUE with nothing
+    below its id bits (a table generated or cut on key-space boundaries): every k-mer of rank r then lies below id(first_{r+1}),
+    and if that id starts a map word the two ranges do not meet.  scale = 32-bit words per 32 block ids (2 for the engine's
+    two-bit map: 64 bits per group)."""
     ids = [0] + [int(splitters[(r - 1) * words]) >> (64 - bits) for r in range(1, world)] + [(1 << bits) - 1]
+    last = []
+    for r in range(world):
+        nxt = ids[r + 1]
+        if r + 1 < world:
+            sp = [int(splitters[r * words + w]) for w in range(words)]
+            clean = (sp[0] & ((1 << (64 - bits)) - 1)) == 0 and all(x == 0 for x in sp[1:])
+            if clean and nxt > ids[r]:
+                nxt -= 1                       # (all k-mers of rank r are below the splitter: its last id is the one in front)
+        last.append(nxt)
     wlo = [(ids[r] >> 5) * scale for r in range(world)]
-    wlen = [max(((ids[r + 1] >> 5) + 1) * scale - wlo[r], 1) for r in range(world)]
+    wlen = [max(((last[r] >> 5) + 1) * scale - wlo[r], 1) for r in range(world)]
     return wlo, wlen
+
+
+def ranges_tile_the_map(wlo, wlen, nwords: int) -> bool:
+    """the ranks' word ranges are equally long, disjoint and cover the map in rank order: the all_gather can write the map itself"""
+    w = wlen[0]
+    return all(x == w for x in wlen) and all(wlo[r] == r * w for r in range(len(wlo))) and w * len(wlo) == nwords
 
 
 def _general_on_rank0(k, keys, counts, sizes, eng, plot, group, rank, world, words):
@@ -459,11 +480,14 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
                 eng._map_bufs = bufs
             _, mine, parts, full = bufs
             eng.blockmap_copy(wlo[rank], wlen[rank], mine)
-            work = dist.all_gather_into_tensor(parts, mine, group=group, async_op=True)
+            direct = ranges_tile_the_map(wlo, wlen, nwords)
+            # (shards cut on key-space boundaries -- bench.py's -- cover equal, disjoint word ranges: the gather IS the map)
+            work = dist.all_gather_into_tensor(full if direct else parts, mine, group=group, async_op=True)
             eng.presort()          # the map-independent half of the filter runs while the maps are in flight
             work.wait()
-            # ranges of neighbours share their boundary word: the merge ORs them (one launch)
-            eng.merge_maps(parts, width, wlo, wlen, full)
+            if not direct:
+                # ranges of neighbours share their boundary word: the merge ORs them (one launch)
+                eng.merge_maps(parts, width, wlo, wlen, full)
             nreq = eng.filter(full)
         # (the exchange buffers live as long as the engine and only ever grow: a step allocates nothing)
         send = _scratch(eng, "send", max(nreq, 1) * rw, dev)
@@ -497,11 +521,15 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
     nslot = world if exchange else 1
     nproof = 3 + 2 * nslot
     buf = _scratch(eng, "plot", PLOT_CELLS + nproof, dev)     # (pass 2 clears the plot itself; the proof words below)
-    buf[PLOT_CELLS:].zero_()
     plot = buf[:PLOT_CELLS]
     eng.pass2(plot)
     me = rank if exchange else 0
-    if missing is None:
+    if missing is None and hasattr(eng, "proof_tail"):
+        # the engine lays the whole tail out on the device, in stream order, in one launch: no host round trip between the
+        # look-ups and the all_reduce (a replayed step's verdict on its counts and on the router's totals included)
+        eng.proof_tail(buf[PLOT_CELLS:], nslot, me)
+    elif missing is None:
+        buf[PLOT_CELLS:].zero_()
         # the engine writes (missing, residue word 0, residue word 1, replay verdict) on the device, in stream order: no host
         # round trip between the look-ups and the all_reduce.  Rank r's words go to [0] (summed) and to ITS slot.
         tmp = _scratch(eng, "proof", 4, dev)
@@ -513,6 +541,7 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
             buf[PLOT_CELLS + nproof - 2] = tmp[3] + (both != rec["both"]).any().to(torch.int64)
             buf[PLOT_CELLS + nproof - 1] = 1
     else:
+        buf[PLOT_CELLS:].zero_()
         fpw = eng.symhash()
         proof = np.zeros(nproof, dtype=np.uint64)
         proof[0] = missing

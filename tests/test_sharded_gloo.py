@@ -318,3 +318,63 @@ def test_replayed_steps_and_a_table_that_changes_under_them(world, k):
             assert np.array_equal(s[2].reshape(1001, 501), want), rank
         assert steps[0][1] is False and steps[1][1] is True and steps[3][1] is True
         assert steps[2][1] is False and steps[4][1] is False           # (settled by the plain path)
+
+
+# ---- shards cut on key-space boundaries (what bench.py --gpus N generates): cut values as splitters, the gathered map ranges ARE the map
+def _cut_worker(rank, world, port, k, keys, cnt, q):
+    sys.path.insert(0, HERE)
+    from fake_engine import NumpyEngine
+    from smudgeplot_amd import synth_device
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lead = (keys >> np.uint64(48)).astype(np.int64)
+        cuts = [int(np.searchsorted(lead, synth_device.key_range_of(r, world)[0], side="left")) for r in range(world)] + [len(cnt)]
+        lo, hi = cuts[rank], cuts[rank + 1]
+        tk = torch.from_numpy(np.ascontiguousarray(keys[lo:hi]).view(np.int64).copy())
+        tc = torch.from_numpy(cnt[lo:hi].view(np.int16).copy())
+        split = np.array([np.uint64(synth_device.key_range_of(r, world)[0]) << np.uint64(48) for r in range(1, world)], dtype=np.uint64)
+        sizes = [cuts[r + 1] - cuts[r] for r in range(world)]
+        plot, st = sharded.hetmers_sharded(k, tk, tc, symcheck="hash", engine_factory=NumpyEngine, splitters=split, sizes=sizes)
+        q.put((rank, st["path"], plot.numpy().copy(), st["sent"], st["received"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,k", [(2, 12), (4, 13), (3, 12)])
+def test_key_space_cuts_with_cut_values_as_splitters(world, k):
+    keys, cnt = synth.diploid_table_u64(3000, k=k, seed=5 + world, het_frac=0.5, cov=30, L=5)
+    want = brute.hetmers_plot(ktab.u64_to_packed(keys, k), cnt, k)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cut_worker, args=(r, world, port, k, keys, cnt, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, path, plot, sent, received in res:
+        assert path == 1 and np.array_equal(plot.reshape(1001, 501), want), rank
+    assert sum(r[3] for r in res) == sum(r[4] for r in res) > 0
+
+
+def test_blockmap_ranges_of_cut_values_and_of_first_kmers():
+    from smudgeplot_amd import synth_device
+    bits, scale = 29, 2
+    nwords = (((1 << bits) + 31) >> 5) * scale
+    for world in (2, 4, 8):
+        sp = np.array([np.uint64(synth_device.key_range_of(r, world)[0]) << np.uint64(48) for r in range(1, world)], dtype=np.uint64)
+        wlo, wlen = sharded.blockmap_ranges(sp, 1, world, bits, scale)
+        assert sharded.ranges_tile_the_map(wlo, wlen, nwords)
+    # first k-mers of the ranks (something below the id bits): neighbours share their boundary word group, as ever
+    sp = np.array([0x4000000012345678, 0x8000000000000001], dtype=np.uint64)
+    wlo, wlen = sharded.blockmap_ranges(sp, 1, 3, bits, scale)
+    assert wlo[1] + wlen[1] == wlo[2] + scale and wlo[0] + wlen[0] == wlo[1] + scale
+    assert not sharded.ranges_tile_the_map(wlo, wlen, nwords)
+    # two-word k-mers: a second word that is not zero makes the cut an ordinary k-mer
+    sp = np.array([0x4000000000000000, 5], dtype=np.uint64)
+    wlo, wlen = sharded.blockmap_ranges(sp, 2, 2, bits, scale)
+    assert wlo[0] + wlen[0] == wlo[1] + scale
