@@ -2834,8 +2834,8 @@ static int host_run(const smg_table_source *tv, const smg_opts *opts, int64_t *p
             // what a run in core takes per entry: k-mers 8 W, count 2, code byte 1, deferred-entry map and lists 0.6, the request
             // list (a quarter of the entries + slack) and its partitioned copy ~2.6 W -- and the candidate map (1 GiB at most)
             const double all = (double) tv->nels * (10.6 * W + 5.5) + 1.1e9;
-            // (conditioning and the extract leg only exist in core: such a run is tried there, and says so itself if it cannot be held)
-            if (limit > 0 && all > limit && !labels && !(opts && opts->condition))
+            // (conditioning only exists in core: such a run is tried there, and says so itself if it cannot be held)
+            if (limit > 0 && all > limit && !(opts && opts->condition))
               { // what a shard leaves behind: its code bytes and its requests -- every entry's (W + 1 words) under the exact
                 // proof, those of the owners of a pair at p > k-1-p otherwise (17 % of a diploid table, 36 % of a polyploid one)
                 const bool exact = symcheck == SMG_SYM_EXACT;
@@ -2848,13 +2848,11 @@ static int host_run(const smg_table_source *tv, const smg_opts *opts, int64_t *p
               }
           }
         if (seq)
-          { if (labels)
-              return fail(errbuf, errlen, SMG_EINVAL, "extract on a table that does not fit the device is not supported (run hetmers, or use SMUDGEPLOT_GPUS)%s");
-            if (verbose) fprintf(stderr, "  [smg] %lld entries do not fit the device together: %d prefix shards one after the other\n",
+          { if (verbose) fprintf(stderr, "  [smg] %lld entries do not fit the device together: %d prefix shards one after the other\n",
                                  (long long) tv->nels, seq);
             smg_opts o; memset(&o, 0, sizeof(o));
             if (opts) o = *opts; else o.symcheck = SMG_SYM_HASH;
-            return host_run_sequential(tv, &o, seq, plot, stats, errbuf, errlen);
+            return host_run_sequential(tv, &o, seq, plot, stats, errbuf, errlen, labels, records, nrec, rec_words);
           }
       }
     // SMG_FORCE_MULTI=1 (tests): take the multi-GPU code path even with one GPU -- a one-rank RCCL

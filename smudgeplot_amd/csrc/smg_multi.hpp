@@ -451,8 +451,10 @@ static void multi_cuts(const smg_table_source *tv, int n, int64_t *cut)
 //            of all requests that name this shard, pass 2 into the one histogram.
 // Symmetry proof as everywhere: XOR of the shards' fingerprints, no look-up may miss.  A table that fails it, a table that
 // still has to be conditioned and k > 85 are refused with a precise message (condition the table with smg_condition first).
+// The extract leg runs per shard in round 2 (the two members of a pair share a shard).
 static int host_run_sequential(const smg_table_source *tv, const smg_opts *opts, int nshards, int64_t *plot, smg_stats *stats,
-                               char *errbuf, size_t errlen)
+                               char *errbuf, size_t errlen, const uint16_t *labels = NULL, uint64_t **records = NULL,
+                               int64_t *nrec_out = NULL, int *rec_words = NULL)
 { const int W = (tv->kmer + 31) / 32, kbyte = (tv->kmer + 3) >> 2, pbyte = kbyte + 2 - tv->ibyte;
   if (tv->kmer > FAST_MAX_K)
     return fail(errbuf, errlen, SMG_EINVAL, "a table of k > 85 that does not fit the device is not supported (its degrees need all shards at once)%s");
@@ -482,6 +484,10 @@ static int host_run_sequential(const smg_table_source *tv, const smg_opts *opts,
   smg_engine *e = smg_engine_create(opts->device, NULL, errbuf, errlen);
   if (!e) return SMG_ENODEV;
   e->no_filter = true;
+  // extract leg (round 5): the two members of a pair share a window block, hence a shard -- every shard lists the pairs behind
+  // the labelled pixels while it is resident for its second round; the lists are only handed out if the whole table proves closed
+  std::vector<uint64_t> xrec;
+  uint16_t *d_labels = NULL;
   int rc = SMG_OK, rw = W;
   int64_t *d_index = NULL, *d_plot = NULL, *h_plot = NULL;
   uint64_t *recv = NULL;
@@ -543,6 +549,27 @@ static int host_run_sequential(const smg_table_source *tv, const smg_opts *opts,
             if ((rc = smg_engine_pass2(e, d_plot, errbuf, errlen))) break;
             if (hipMemcpy(h_plot, d_plot, sizeof(int64_t) * SMG_PLOT_CELLS, hipMemcpyDeviceToHost) != hipSuccess) SBAIL(SMG_ENODEV, "device to host copy failed")
             for (int cell = 0; cell < SMG_PLOT_CELLS; cell++) plot[cell] += h_plot[cell];
+            if (labels)
+              { int64_t cnt = 0, got = 0;
+                uint64_t *d_out = NULL;
+                if (!d_labels && (hipMalloc(&d_labels, sizeof(uint16_t) * SMG_PLOT_CELLS) != hipSuccess
+                                  || hipMemcpy(d_labels, labels, sizeof(uint16_t) * SMG_PLOT_CELLS, hipMemcpyHostToDevice) != hipSuccess))
+                  SBAIL(SMG_ENOMEM, "out of device memory for the pair list")
+                if ((rc = smg_engine_extract(e, d_labels, NULL, 0, &cnt, errbuf, errlen))) break;          // count first
+                if (cnt > 0)
+                  { const size_t at = xrec.size(), words = (size_t) cnt * (W + 1);
+                    if (hipMalloc(&d_out, sizeof(uint64_t) * words) != hipSuccess) SBAIL(SMG_ENOMEM, "out of device memory for the pair list")
+                    rc = smg_engine_extract(e, d_labels, d_out, cnt, &got, errbuf, errlen);
+                    if (rc == SMG_OK && got != cnt) rc = fail(errbuf, errlen, SMG_ENODEV, "internal error: the pair list changed between two passes%s");
+                    if (rc == SMG_OK)
+                      { xrec.resize(at + words);
+                        if (hipMemcpy(xrec.data() + at, d_out, sizeof(uint64_t) * words, hipMemcpyDeviceToHost) != hipSuccess)
+                          rc = fail(errbuf, errlen, SMG_ENODEV, "device to host copy failed%s");
+                      }
+                    hipFree(d_out);
+                    if (rc) break;
+                  }
+              }
             smg_stats st2; smg_engine_stats(e, &st2);
             ms_look += st2.ms_rclookup; ms_p2 += st2.ms_pass2 > 0 ? st2.ms_pass2 : 0;
           }
@@ -553,6 +580,21 @@ static int host_run_sequential(const smg_table_source *tv, const smg_opts *opts,
       if (!symmetric)
         rc = fail(errbuf, errlen, SMG_ENOTSYM, "the table is not closed under reverse complement with equal counts, and it does not fit the "
                   "device in one piece: condition it first (smg_condition)%s");
+    }
+  if (rc == SMG_OK && labels)
+    { // as everywhere: the number of records is the plot's weight on the labelled pixels
+      int64_t want = 0;
+      for (int cell = 0; cell < SMG_PLOT_CELLS; cell++) if (labels[cell]) want += plot[cell];
+      const int64_t have = (int64_t) (xrec.size() / (size_t) (W + 1));
+      if (have != want) rc = fail(errbuf, errlen, SMG_ENODEV, "internal error: pair list and plot disagree%s");
+      else
+        { uint64_t *all = (uint64_t *) malloc(sizeof(uint64_t) * (xrec.size() ? xrec.size() : 1));
+          if (!all) rc = fail(errbuf, errlen, SMG_ENOMEM, "out of host memory for the pair list%s");
+          else
+            { if (!xrec.empty()) memcpy(all, xrec.data(), sizeof(uint64_t) * xrec.size());
+              *records = all; *nrec_out = have; *rec_words = W + 1;
+            }
+        }
     }
   if (rc == SMG_OK)
     { clock_gettime(CLOCK_MONOTONIC, &w1);
@@ -573,6 +615,7 @@ done:
   if (recv) hipFree(recv);
   if (d_index) hipFree(d_index);
   if (d_plot) hipFree(d_plot);
+  if (d_labels) hipFree(d_labels);
   free(h_plot);
   smg_engine_destroy(e);
   return rc;

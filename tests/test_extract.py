@@ -184,3 +184,16 @@ def test_extract_over_prefix_shards_matches_reference_golden(name, shards, monke
     monkeypatch.setenv("SMG_SHARD_LIMIT", str(len(g["counts"]) // shards + 1))          # the automatic shards of a big table
     plot, got = engine.hetmers_extract(make_table(g), labels)
     assert {lab: sorted(v) for lab, v in got.items()} == lines
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shards", [2, 5])
+@pytest.mark.parametrize("name", ["k31_i1", "k51_i1_p3", "k65_i1"])
+def test_extract_out_of_core_matches_reference_golden(name, shards, monkeypatch):
+    """... and over a table that does not fit the device (prefix shards one after the other, the table read twice: smg_multi.hpp,
+    host_run_sequential): every shard lists the pairs behind the labelled pixels while it is resident for its second round"""
+    g, labels, lines, _ = load_extract(name)
+    monkeypatch.setenv("SMG_SEQUENTIAL_SHARDS", str(shards))
+    plot, got = engine.hetmers_extract(make_table(g), labels)
+    assert engine.smu_text(plot) == g["smu"]
+    assert {lab: sorted(v) for lab, v in got.items()} == lines

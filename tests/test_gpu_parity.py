@@ -1343,7 +1343,8 @@ def test_out_of_core_shards_one_after_the_other(name, nshards, mode, monkeypatch
 
 def test_out_of_core_mode_is_chosen_from_the_free_memory_and_says_what_it_cannot_do(monkeypatch, tmp_path):
     """SMG_HBM_LIMIT (bytes) stands in for the free device memory: the executable picks the number of shards itself and says
-    so; a raw table, k > 85, a table that is not closed and an extract run get a precise refusal instead of a wrong answer"""
+    so; a raw table, k > 85 and a table that is not closed get a precise refusal instead of a wrong answer (the extract leg runs
+    out of core since round 5: tests/test_extract.py)"""
     g = load_golden("k31_i3_p4")
     n = len(g["counts"])
     ktab.write_ktab(str(tmp_path / "t"), g["k"], g["packed"], g["counts"], ibyte=g["ibyte"], nparts=g["nparts"])
