@@ -21,7 +21,19 @@
  *                                        probes entry #1, PloidyPlot.c:1199-1229)
  *    SMUDGEPLOT_IO_THREADS=<n>           threads that read the part files (default: the -T value, at least 8)
  *    SMUDGEPLOT_GPUS=<n>                 prefix-shard the table over n GPUs of the node
+ *    SMUDGEPLOT_ONE_PROCESS=1            everything in the one process the caller started (see below)
  *    under -v the engine adds one "[smg]" timing line to stderr
+ *
+ *  Two processes (round 5).  The HIP runtime takes 80-240 ms to start and ~75 ms to take down, whatever the program does
+ *  with it, and neither overlaps with anything inside ONE process: started in a thread beside the table probe the two get
+ *  in each other's way (they share an address space; profiles/r04_hip_startup.txt).  So the program the caller started
+ *  forks a WORKER first thing -- which starts the runtime at once -- and itself opens the table (stub, the 134 MB prefix
+ *  index read straight into a mapping both share, part headers) and runs the reference's conditioning probe, with the
+ *  reference's messages.  Then the worker opens the parts for itself, streams them into HBM, runs the passes, writes the
+ *  .smu and reports its exit status through a pipe; the starter leaves with that status at once, while the worker is
+ *  still handing its device context back.  When `hetmers` returns, the .smu is complete and closed, exactly as before;
+ *  what is still going on for a few tens of milliseconds is the release of the GPU by a process nobody waits for.
+ *  Any failure to set this up (fork, mmap, pipe) falls back to the one process.
  *
  *  Deviations, deliberate:
  *    - the "use it?" prompt stops at EOF on stdin (the reference spins forever there,
@@ -33,6 +45,9 @@
 
 #include <time.h>
 #include <unistd.h>
+#include <sys/mman.h>
+#include <sys/types.h>
+#include <sys/wait.h>
 #include "smg_cli.h"
 
 static double now_s(void)
@@ -45,6 +60,75 @@ static double real_s(void)
 { struct timespec t;
   clock_gettime(CLOCK_REALTIME, &t);
   return (double) t.tv_sec + 1e-9 * (double) t.tv_nsec;
+}
+
+/* what the starter hands to the worker (a mapping both share; the index is the only big thing in it) */
+#define SHARED_IXWORDS (1ll << 24)
+typedef struct
+{ smg_opts opts;
+  int      have_input;
+  double   t_probe;
+  char     input[4096], name[4096];
+  int64_t  index[SHARED_IXWORDS];
+} Shared;
+
+/* run the engine on the open table T (conditioned, or to be conditioned on the device: opts), write <OUT>.smu: the part of
+   main() behind the table probe.  Returns the exit status. */
+static int run(const smg_cli *c, const char *OUT, smg_ktab *Tp, const smg_opts *opts, char *input,
+               double t_start, double rt_start, double t_probe)
+{ smg_ktab T = *Tp;
+  smg_stats stats;
+  smg_table_source src;
+  int64_t *plot;
+  char  errbuf[512];
+  int   rc, i;
+  double t_engine;
+
+  if (c->verbose)
+    { fprintf(stderr, "\n  Starting to count covariant pairs\n"); fflush(stderr); }
+
+  plot = (int64_t *) malloc(sizeof(int64_t) * SMG_PLOT_CELLS);
+  if (plot == NULL)
+    { fprintf(stderr, "%s: Out of memory (Allocating plot)\n", Prog_Name); return 1; }
+
+  smg_cli_table_source(&T, &src, c->nthreads);
+  errbuf[0] = 0;
+  rc = smg_hetmers_run_source(&src, opts, plot, &stats, errbuf, sizeof(errbuf));
+  if (rc != SMG_OK)
+    { fprintf(stderr, "%s: %s\n", Prog_Name, errbuf[0] ? errbuf : "GPU engine failed");
+      return 1;
+    }
+  t_engine = now_s();
+  smg_ktab_free(&T);
+  smg_cli_remove_temp(input);
+
+  if (c->verbose)
+    { fprintf(stderr, "\n  Count complete, outputting table\n"); fflush(stderr); }
+
+  /* writer, PloidyPlot.c:1603-1617: sum ascending, min ascending, min == 500 never printed */
+  { char *fname = (char *) malloc(strlen(OUT) + 8);
+    FILE *f;
+    int   a;
+    sprintf(fname, "%s.smu", OUT);
+    f = fopen(fname, "w");
+    if (f == NULL)
+      { fprintf(stderr, "Could not open %s.smu\n", OUT);
+        return 1;
+      }
+    for (a = 0; a <= SMG_SMAX; a++)
+      for (i = 0; i < SMG_FMAX; i++)
+        if (plot[a * SMG_PLOT_COLS + i] > 0)
+          fprintf(f, "%i\t%i\t%lld\n", i, a - i, (long long) plot[a * SMG_PLOT_COLS + i]);
+    fclose(f);
+    free(fname);
+  }
+  free(plot);
+  if (c->verbose)               /* where the wall time of the process went, next to the engine's own lines */
+    fprintf(stderr, "  [smg] process %.1f ms since main(): arguments + stub, index and conditioning probe %.1f, engine call %.1f, "
+            ".smu writer %.1f; main() entered at %.3f, left at %.3f (CLOCK_REALTIME: what lies outside is the loader and exit())\n",
+            (now_s() - t_start) * 1e3, (t_probe - t_start) * 1e3, (t_engine - t_probe) * 1e3,
+            (now_s() - t_engine) * 1e3, rt_start, real_s());
+  return 0;
 }
 
 static const char *Usage[] = { " [-v] [-T<int(4)>] [-P<dir(/tmp)>]",
@@ -87,65 +171,71 @@ int main(int argc, char *argv[])
     free(name);
   }
 
-  { smg_ktab T;
-    smg_opts  opts;
-    smg_stats stats;
-    smg_table_source src;
-    int64_t *plot;
-    char  errbuf[512];
+  { smg_opts  opts;
     char *input;
-    int   rc;
-
-    double t_probe, t_engine;
+    Shared *sh = NULL;
+    /* (a profiler or any other atexit hook -- SMUDGEPLOT_FULL_EXIT -- wants the GPU work in the process it was started with) */
+    int   two = getenv("SMUDGEPLOT_ONE_PROCESS") == NULL && getenv("SMUDGEPLOT_FULL_EXIT") == NULL;
+    int   to_worker[2] = { -1, -1 }, to_starter[2] = { -1, -1 };
+    pid_t pid = -1;
 
     Load_Lazy = 1;                 /* stub + index only: the engine streams the parts into HBM (smg_ingest.hpp) */
-    input = smg_cli_open_table(&c, SRC, &T, &opts);
-    t_probe = now_s();
-
-    if (c.verbose)
-      { fprintf(stderr, "\n  Starting to count covariant pairs\n"); fflush(stderr); }
-
-    plot = (int64_t *) malloc(sizeof(int64_t) * SMG_PLOT_CELLS);
-    if (plot == NULL)
-      { fprintf(stderr, "%s: Out of memory (Allocating plot)\n", Prog_Name); exit(1); }
-
-    smg_cli_table_source(&T, &src, c.nthreads);
-    errbuf[0] = 0;
-    rc = smg_hetmers_run_source(&src, &opts, plot, &stats, errbuf, sizeof(errbuf));
-    if (rc != SMG_OK)
-      { fprintf(stderr, "%s: %s\n", Prog_Name, errbuf[0] ? errbuf : "GPU engine failed");
-        exit(1);
+    if (two)
+      { sh = (Shared *) mmap(NULL, sizeof(Shared), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+        if (sh == MAP_FAILED) { sh = NULL; two = 0; }
       }
-    t_engine = now_s();
-    smg_ktab_free(&T);
-    smg_cli_remove_temp(input);
-
-    if (c.verbose)
-      { fprintf(stderr, "\n  Count complete, outputting table\n"); fflush(stderr); }
-
-    /* writer, PloidyPlot.c:1603-1617: sum ascending, min ascending, min == 500 never printed */
-    { char *name = (char *) malloc(strlen(OUT) + 8);
-      FILE *f;
-      int   a;
-      sprintf(name, "%s.smu", OUT);
-      f = fopen(name, "w");
-      if (f == NULL)
-        { fprintf(stderr, "Could not open %s.smu\n", OUT);
-          exit(1);
+    if (two && (pipe(to_worker) != 0 || pipe(to_starter) != 0)) two = 0;
+    if (two)
+      { fflush(NULL);
+        pid = fork();
+        if (pid < 0) two = 0;
+      }
+    if (two && pid == 0)
+      { /* ---- the worker: start the runtime, wait for the table, do the work ---- */
+        char go = 0, status;
+        close(to_worker[1]); close(to_starter[0]);
+        (void) smg_device_count();                               /* the first HIP call of the process */
+        if (read(to_worker[0], &go, 1) != 1 || go != 1) _exit(1);   /* (the starter failed, and has said why) */
+        { smg_ktab T;
+          smg_ktab_set_index_memory(sh->index, SHARED_IXWORDS, 1);           /* (the index is there: the stub is only looked at) */
+          load_or_die(sh->name, &T);
+          smg_ktab_set_index_memory(NULL, 0, 0);
+          status = (char) run(&c, OUT, &T, &sh->opts, sh->have_input ? sh->input : NULL, t_start, rt_start, sh->t_probe);
         }
-      for (a = 0; a <= SMG_SMAX; a++)
-        for (i = 0; i < SMG_FMAX; i++)
-          if (plot[a * SMG_PLOT_COLS + i] > 0)
-            fprintf(f, "%i\t%i\t%lld\n", i, a - i, (long long) plot[a * SMG_PLOT_COLS + i]);
-      fclose(f);
-      free(name);
+        fflush(NULL);
+        if (write(to_starter[1], &status, 1) != 1) _exit(1);
+        _exit(status);                                           /* (nobody waits for what this takes) */
+      }
+    if (two)
+      { /* ---- the starter: open and probe the table while the worker's runtime comes up ---- */
+        smg_ktab T;
+        char go = 1, status = 1;
+        close(to_worker[0]); close(to_starter[1]);
+        smg_ktab_set_index_memory(sh->index, SHARED_IXWORDS, 0);
+        input = smg_cli_open_table(&c, SRC, &T, &opts);          /* (exits 1 with the reference's message when it cannot) */
+        smg_ktab_set_index_memory(NULL, 0, 0);
+        if (strlen(input ? input : SRC) >= sizeof(sh->name)) { fprintf(stderr, "%s: table name too long\n", Prog_Name); exit(1); }
+        sh->opts = opts;
+        sh->have_input = input != NULL;
+        snprintf(sh->input, sizeof(sh->input), "%s", input ? input : "");
+        snprintf(sh->name, sizeof(sh->name), "%s", input ? input : SRC);
+        sh->t_probe = now_s();
+        if (write(to_worker[1], &go, 1) != 1) { fprintf(stderr, "%s: lost the worker process\n", Prog_Name); exit(1); }
+        if (read(to_starter[0], &status, 1) != 1)                /* the worker died without a word: its exit status says how */
+          { int ws = 0;
+            waitpid(pid, &ws, 0);
+            fprintf(stderr, "%s: the GPU worker process ended unexpectedly\n", Prog_Name);
+            exit(1);
+          }
+        fflush(NULL);
+        _exit(status);
+      }
+    if (sh != NULL) munmap(sh, sizeof(Shared));
+    /* ---- one process ---- */
+    { smg_ktab T;
+      input = smg_cli_open_table(&c, SRC, &T, &opts);
+      i = run(&c, OUT, &T, &opts, input, t_start, rt_start, now_s());
     }
-    free(plot);
-    if (c.verbose)               /* where the wall time of the process went, next to the engine's own lines */
-      fprintf(stderr, "  [smg] process %.1f ms since main(): arguments + stub, index and conditioning probe %.1f, engine call %.1f, "
-              ".smu writer %.1f; main() entered at %.3f, left at %.3f (CLOCK_REALTIME: what lies outside is the loader and exit())\n",
-              (now_s() - t_start) * 1e3, (t_probe - t_start) * 1e3, (t_engine - t_probe) * 1e3,
-              (now_s() - t_engine) * 1e3, rt_start, real_s());
   }
 
   free(OUT);
@@ -153,6 +243,6 @@ int main(int argc, char *argv[])
      teardown of the HIP runtime (~95 ms of a 0.57 s run, profiles/r03_e2e_1e9_entries.json).  Flush and leave. */
   fflush(NULL);
   if (getenv("SMUDGEPLOT_FULL_EXIT") != NULL)      /* a profiler or any other atexit hook that must run: exit() as the reference */
-    exit(0);
-  _exit(0);                                        /* (atexit handlers are skipped: this program registers none) */
+    exit(i);
+  _exit(i);                                        /* (atexit handlers are skipped: this program registers none) */
 }

@@ -55,6 +55,13 @@ int smg_ktab_load(const char *name, smg_ktab *t, char *what)
 
 static int ktab_open(const char *name, smg_ktab *t, char *what, int load, int nthreads);
 
+static int64_t *g_ixbuf = NULL;
+static int64_t  g_ixcap = 0;
+static int      g_ixfilled = 0;
+
+void smg_ktab_set_index_memory(int64_t *buf, int64_t cap_words, int filled)
+{ g_ixbuf = buf; g_ixcap = buf ? cap_words : 0; g_ixfilled = buf ? filled : 0; }
+
 int smg_ktab_open(const char *name, smg_ktab *t, char *what)
 { return ktab_open(name, t, what, 0, 1); }
 
@@ -111,7 +118,8 @@ static int ktab_open(const char *name, smg_ktab *t, char *what, int load, int nt
   t->pbyte = t->tbyte - t->ibyte;
   t->hbyte = t->kbyte - t->ibyte;
   t->ixlen = 1ll << (8 * t->ibyte);
-  t->index = (int64_t *) malloc(sizeof(int64_t) * (size_t) t->ixlen);
+  if (g_ixbuf != NULL && t->ixlen <= g_ixcap) { t->index = g_ixbuf; t->index_borrowed = 1; }
+  else t->index = (int64_t *) malloc(sizeof(int64_t) * (size_t) t->ixlen);
   t->part = (uint8_t **) calloc((size_t) (t->nparts > 0 ? t->nparts : 1), sizeof(uint8_t *));
   t->part_nels = (int64_t *) calloc((size_t) (t->nparts > 0 ? t->nparts : 1), sizeof(int64_t));
   t->part_end = (int64_t *) calloc((size_t) (t->nparts > 0 ? t->nparts : 1), sizeof(int64_t));
@@ -119,7 +127,7 @@ static int ktab_open(const char *name, smg_ktab *t, char *what, int load, int nt
   if (!t->index || !t->part || !t->part_nels || !t->part_end || !t->fd)
     { close(fd); rc = SMG_KTAB_NOMEM; goto out; }
   for (p = 0; p < t->nparts; p++) t->fd[p] = -1;
-  if (read_full(fd, t->index, sizeof(int64_t) * (size_t) t->ixlen))
+  if (!(t->index_borrowed && g_ixfilled) && read_full(fd, t->index, sizeof(int64_t) * (size_t) t->ixlen))
     { close(fd); rc = SMG_KTAB_SHORT; goto out; }
   close(fd);
 
@@ -175,7 +183,8 @@ static int ktab_open(const char *name, smg_ktab *t, char *what, int load, int nt
       { /* the index must be the cumulative entry count of the parts (a hostile or damaged stub would otherwise send
            the readers out of bounds): non-decreasing, ending at nels                                            */
         int64_t i, prev = 0;
-        for (i = 0; i < t->ixlen && rc == SMG_KTAB_OK; i++)
+        if (t->index_borrowed && g_ixfilled) prev = -1;        /* (checked by whoever filled it) */
+        for (i = 0; prev >= 0 && i < t->ixlen && rc == SMG_KTAB_OK; i++)
           { if (t->index[i] < prev || t->index[i] > t->nels) rc = SMG_KTAB_SHORT;
             prev = t->index[i];
           }
@@ -197,7 +206,7 @@ void smg_ktab_free(smg_ktab *t)
     for (p = 0; p < t->nparts; p++) free(t->part[p]);
   if (t->fd)
     for (p = 0; p < t->nparts; p++) if (t->fd[p] >= 0) close(t->fd[p]);
-  free(t->part); free(t->part_nels); free(t->part_end); free(t->index); free(t->fd);
+  free(t->part); free(t->part_nels); free(t->part_end); if (!t->index_borrowed) free(t->index); free(t->fd);
   memset(t, 0, sizeof(*t));
 }
 

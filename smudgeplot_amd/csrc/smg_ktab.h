@@ -25,6 +25,7 @@ typedef struct smg_ktab
   int64_t  *part_nels;                      /* [nparts]                                        */
   int64_t  *part_end;                       /* [nparts] cumulative (neps, libfastk.c:857)      */
   int      *fd;                             /* [nparts] open part files (-1 when closed)       */
+  int       index_borrowed;                 /* `index` is the caller's memory (smg_ktab_set_index_memory): not freed here */
 } smg_ktab;
 
 #define SMG_KTAB_MAX_KMER   128   /* = SMG_MAX_KMER of the engine: larger k is refused at open time            */
@@ -36,6 +37,12 @@ typedef struct smg_ktab
 #define SMG_KTAB_KMISMATCH 3     /* "... does not have k-mer length matching stub ?"  858-862  */
 #define SMG_KTAB_NOMEM     4
 #define SMG_KTAB_SHORT     5     /* file shorter than its header promises                       */
+
+/* The prefix index (8 << 8 ibyte bytes: 134 MB at ibyte = 3) of the NEXT table that is opened goes into -- filled = 0 -- or is
+   taken as it stands from -- filled = 1: nothing is read, nothing is checked again -- `buf` (room for cap_words words; a table
+   whose index does not fit is opened the ordinary way).  `hetmers` puts it into a mapping shared by the process that opens and
+   probes the table and the one that drives the GPU.  buf = NULL: back to malloc.  Not thread safe (set, open, unset). */
+void smg_ktab_set_index_memory(int64_t *buf, int64_t cap_words, int filled);
 
 /* name: "<path>[.ktab]".  On failure `what` (>= 4096 bytes) receives the offending file name. */
 int  smg_ktab_open(const char *name, smg_ktab *t, char *what);      /* part[p] stay NULL: use smg_ktab_read */

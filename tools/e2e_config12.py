@@ -59,14 +59,23 @@ with tempfile.TemporaryDirectory(prefix="smg_e2e") as d:
     if not OURS_ONLY:
         dt, _ = run([ref, f"-e{L}", f"-T{cores}", "-orefN", "t.ktab"], "refN")
         out[f"reference_T{cores}"] = {"wall_s": round(dt, 3), "kmers_per_s": len(cnt) / dt}
-    for T in (4, 32):                      # -T = host threads that read the part files (CLI default: 4)
-        best = None
+    # -T = host threads that read the part files (CLI default: 4).  The executable works in two processes (a worker that
+    # starts the HIP runtime while the starter opens and probes the table, and whose release of the device nobody waits
+    # for: hetmers_main.c); SMUDGEPLOT_ONE_PROCESS=1 is the round-4 form.  Best of three; a pause between two runs lets the
+    # worker of the run before finish handing its device context back.
+    for T, one in ((4, False), (32, False), (4, True)):
+        best, walls = None, []
         for _ in range(3):
-            dt, err = run([ours, f"-e{L}", f"-T{T}", "-v", "-ogpu", "t.ktab"], "gpu")
+            time.sleep(0.4)
+            dt, err = run([ours, f"-e{L}", f"-T{T}", "-v", "-ogpu", "t.ktab"], "gpu",
+                          env=dict(os.environ, SMUDGEPLOT_ONE_PROCESS="1") if one else None)
+            walls.append(round(dt, 3))
             if best is None or dt < best[0]:
                 best = (dt, err)
-        out[f"mi355x_hetmers_end_to_end_T{T}"] = {"wall_s": round(best[0], 3), "kmers_per_s": len(cnt) / best[0],
-                                                  "engine_line": [l.strip() for l in best[1].splitlines() if "[smg]" in l]}
+        out[f"mi355x_hetmers_end_to_end_T{T}" + ("_one_process" if one else "")] = {
+            "wall_s": round(best[0], 3), "all_runs_s": walls, "kmers_per_s": len(cnt) / best[0],
+            "engine_line": [l.strip() for l in best[1].splitlines() if "[smg]" in l]}
+    time.sleep(0.4)
     a = open(os.path.join(d, "gpu.smu"), "rb").read()
     out["smu_bytes"] = len(a)
     if OURS_ONLY:
