@@ -88,6 +88,52 @@ def make_table(workload: str, G: int, k: int, dev, seed: int = 1, key_range=None
     return keys, cnt, L, desc
 
 
+def make_shard(workload: str, G: int, k: int, dev, rank: int, world: int, with_index: bool = True, group=None):
+    """This rank's prefix shard of a bench table and what the sharded run needs to know about the whole of it -- collective when
+    world > 1 (any backend: the CPU test-suite runs it under gloo).  Every rank GENERATES its own shard (synth_device
+    key_range_of: equal slices of the key space, cut on window-block boundaries), so no rank ever holds the table.
+    -> dict: keys, counts, L, desc, sizes (entries of every rank), n_total, first_entry (number of this shard's first entry in
+    the whole table), index (the WHOLE table's FastK prefix index, int64[2^24]: bucket counts summed over the ranks -- what the
+    stub of a .ktab carries, libfastk.c:841 -- or None), splitters (the cut values: lower bound of the k-mer range of ranks 1 ..
+    world-1, W words each; None for one rank), hk / hc (synth_device.table_hash of the whole table: the shards' sums)."""
+    words = (k + 31) // 32
+    key_range = synth_device.key_range_of(rank, world) if world > 1 else None
+    keys, cnt, L, desc = make_table(workload, G, k, dev, key_range=key_range)
+    n_local = cnt.numel()
+    kw0 = keys if keys.dim() == 1 else keys[:, 0]          # the word that holds the window-block prefix
+    sizes = [n_local]
+    if world > 1:
+        mine = torch.tensor([n_local], dtype=torch.int64, device=dev)
+        allv = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine, group=group)
+        sizes = [int(v) for v in torch.cat(allv).cpu().tolist()]
+    first_entry = sum(sizes[:rank])
+    # A FastK table comes with its prefix index (entries up to every 3-byte prefix: the stub of the .ktab file,
+    # libfastk.c:841); the generator stands in for the table file, so it supplies the index too -- the engine takes it
+    # as its look-up directory (the `hetmers` executable hands over the index it read from the stub the same way)
+    index = None
+    if with_index:
+        per = torch.bincount((kw0 >> 40) & 0xFFFFFF, minlength=1 << 24)
+        if world > 1:
+            dist.all_reduce(per, op=dist.ReduceOp.SUM, group=group)
+        index = torch.cumsum(per, 0)
+        del per
+    splitters = None
+    if world > 1:
+        splitters = np.zeros((world - 1, words), dtype=np.uint64)
+        for r in range(1, world):
+            splitters[r - 1, 0] = np.uint64(synth_device.key_range_of(r, world)[0]) << np.uint64(48)
+        splitters = splitters.reshape(-1)
+    # checksum of the table (summed over the ranks): what the golden .smu of the parity block was made on
+    hk, hc = synth_device.table_hash(keys, cnt, first_entry=first_entry)
+    if world > 1:
+        hv = torch.tensor([hk - (1 << 64) if hk >> 63 else hk, hc - (1 << 64) if hc >> 63 else hc], dtype=torch.int64, device=dev)
+        dist.all_reduce(hv, op=dist.ReduceOp.SUM, group=group)
+        hk, hc = [int(v) & 0xFFFFFFFFFFFFFFFF for v in hv.cpu().tolist()]
+    return {"keys": keys, "counts": cnt, "L": L, "desc": desc, "sizes": sizes, "n_total": sum(sizes), "first_entry": first_entry,
+            "index": index, "splitters": splitters, "hk": hk, "hc": hc}
+
+
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 
@@ -201,44 +247,11 @@ def main():
 
     # ---- workload: every rank generates ITS prefix shard only (the generators cut the key space; no rank holds the table)
     G = int(args.genome)
-    words = (args.k + 31) // 32
-    key_range = synth_device.key_range_of(rank, world) if world > 1 else None
-    keys, cnt, L, desc = make_table(args.workload, G, args.k, dev, key_range=key_range)
-    n_local = cnt.numel()
-    kw0 = keys if keys.dim() == 1 else keys[:, 0]          # the word that holds the window-block prefix
-    sizes = [n_local]
-    if world > 1:
-        mine = torch.tensor([n_local], dtype=torch.int64, device=dev)
-        allv = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(allv, mine)
-        sizes = [int(v) for v in torch.cat(allv).cpu().tolist()]
-    n_total = sum(sizes)
-    first_entry = sum(sizes[:rank])
-    # A FastK table comes with its prefix index (entries up to every 3-byte prefix: the stub of the .ktab file,
-    # libfastk.c:841); the generator stands in for the table file, so it supplies the index too -- the engine takes it
-    # as its look-up directory (the `hetmers` executable hands over the index it read from the stub the same way).
-    # The index is the WHOLE table's (every rank's shard starts at entry `first_entry` of it): bucket counts summed over ranks
-    index = None
-    if not args.no_index:
-        per = torch.bincount((kw0 >> 40) & 0xFFFFFF, minlength=1 << 24)
-        if world > 1:
-            dist.all_reduce(per, op=dist.ReduceOp.SUM)
-        index = torch.cumsum(per, 0)
-        del per
-    # splitters of the sharded run = the cut values the shards were generated by (lower bound of every rank's k-mer range)
-    splitters = None
-    if world > 1:
-        splitters = np.zeros((world - 1, words), dtype=np.uint64)
-        for r in range(1, world):
-            splitters[r - 1, 0] = np.uint64(synth_device.key_range_of(r, world)[0]) << np.uint64(48)
-        splitters = splitters.reshape(-1)
-    # checksum of the table (summed over the ranks): what the golden .smu of the parity block was made on
-    hk, hc = synth_device.table_hash(keys, cnt, first_entry=first_entry)
-    if world > 1:
-        hv = torch.tensor([hk - (1 << 64) if hk >> 63 else hk, hc - (1 << 64) if hc >> 63 else hc], dtype=torch.int64, device=dev)
-        dist.all_reduce(hv, op=dist.ReduceOp.SUM)
-        hk, hc = [int(v) & 0xFFFFFFFFFFFFFFFF for v in hv.cpu().tolist()]
-    del kw0
+    sh = make_shard(args.workload, G, args.k, dev, rank, world, with_index=not args.no_index)
+    keys, cnt, L, desc = sh["keys"], sh["counts"], sh["L"], sh["desc"]
+    n_local, n_total, sizes, first_entry = cnt.numel(), sh["n_total"], sh["sizes"], sh["first_entry"]
+    index, splitters, hk, hc = sh["index"], sh["splitters"], sh["hk"], sh["hc"]
+    del sh
     keys = keys.reshape(-1)
     torch.cuda.synchronize()
     torch.cuda.empty_cache()

@@ -1263,8 +1263,9 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
               e->h_p1cold->times = e->p1times;
             }
           HIPCHK(hipMemcpyAsync(e->p1cold, e->h_p1cold, sizeof(P1Cold), hipMemcpyHostToDevice, e->stream));
-#define LAUNCH_R(W_, RW_, ODD_, KF_) hipLaunchKernelGGL((kf_pass1_d<W_, RW_, ODD_, KF_>), dim3(grid), dim3(D_TPB), 0, e->stream, hot, \
-                              (const P1Cold *) e->p1cold)
+#define LAUNCH_R(W_, RW_, ODD_, KF_) do { if (hot.bstart == NULL && hot.sig == NULL && e->bm2 && hot.bmap != NULL && want_fp && !emit_all && e->lg.nb && (RW_) == (W_)) /* the hot form */ \
+            hipLaunchKernelGGL((kf_pass1_d<W_, RW_, ODD_, KF_, 2>), dim3(grid), dim3(D_TPB), 0, e->stream, hot, (const P1Cold *) e->p1cold); \
+          else hipLaunchKernelGGL((kf_pass1_d<W_, RW_, ODD_, KF_, 1>), dim3(grid), dim3(D_TPB), 0, e->stream, hot, (const P1Cold *) e->p1cold); } while (0)
 #define LAUNCH_R2(RW_, ODD_) { if (kf) LAUNCH_R(1, RW_, ODD_, true); else LAUNCH_R(1, RW_, ODD_, false); }
           const bool kf = gr.pshift < 32 && gr.kshift < 32;          // 17 <= k <= 32
           if (e->W == 2 && e->rw == 2) { if (odd) LAUNCH_R(2, 2, true, false); else LAUNCH_R(2, 2, false, false); }

@@ -299,10 +299,11 @@ SMG_DEV bool d_code_uq(unsigned c) { return ((c & 63u) - 1u) < 62u && c < 128u; 
 
 // One tile.  INNER tiles lie completely inside the table: vector loads, no bounds checks, no table-end cases.
 // RW = 64-bit words per request record: W (the complement k-mer) or W + 1 (+ count | has-hi-pair << 16).
-template <int W, int RW, bool ODD, bool KF, bool INNER> SMG_DEV void
+template <int W, int RW, bool ODD, bool KF, bool INNER, int VAR> SMG_DEV void
 d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64 &fa, u64 &fb, DPrefetch<W> &pf)
 { typedef typename DWord<W>::type WT;
   constexpr bool D_BM = (W == 1 && RW == 1) || (W == 2 && RW != 1);     // variants that feed the request filter
+  constexpr bool DIR = (VAR & 1) != 0;       // this launch writes a directory and / or signatures
   const GeoR &G = A.G;
   const int lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);       // the wave number is uniform: keep it scalar
   const int slot0 = (wv * D_WL + lane) * 4;
@@ -392,7 +393,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
       if (bad & scanM) *S.s_unsorted = 1u;
       // raw bucket numbers; the offset and the bound are applied on the (rare) store path only
       // (no directory is written when the table came with its own: the FastK prefix index, smg_engine_set_prefix_index)
-      if (A.bstart != nullptr) {
+      if (DIR && A.bstart != nullptr) {
       uint32_t bq[5];
 #pragma unroll
       for (int e = 0; e < 4; e++) bq[e] = (uint32_t) (kk[e].w[0] >> 32) >> A.dsh();
@@ -416,7 +417,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
   // ---- signatures ---------------------------------------------------------------------------------------------------
   //@mark D_SIG
   D_FENCE_P();
-  if (W <= 2 && !(D_ABL & 4) && A.sig && owned)     // (no signatures: the look-ups bisect the k-mers themselves)
+  if (DIR && W <= 2 && !(D_ABL & 4) && A.sig && owned)     // (no signatures: the look-ups bisect the k-mers themselves)
     { unsigned sg[4];
 #pragma unroll
       for (int e = 0; e < 4; e++)
@@ -516,7 +517,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
 #pragma unroll
           for (int e = 0; e < 4; e++) kw[e] = S.ent[(slot0 + e) * W];
         }
-      if (A.two())
+      if ((VAR & 2) || A.two())
         { u64 *bm64 = reinterpret_cast<u64 *>(S.bm);
           u64 *gm64 = reinterpret_cast<u64 *>(A.bmap);
 #pragma unroll
@@ -558,13 +559,13 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
   // ---- complement, fingerprint, requests: one entry at a time from the thread's own LDS copy ----------------------
   //@mark D_RC
   D_FENCE_P();
-  if (!(D_ABL & 16) || A.want_fp())
+  if (!(D_ABL & 16) || (VAR & 2) || A.want_fp())
     { // hash proof: rc(x) of every owned entry that owns a pair at p > k-1-p; exact proof: of every owned entry, with
       // that flag.  (A deferred entry that turns out to own more pairs than the register scan saw sends again from
       // kf_bigfix: the flag of a request is only ever ORed into its target.)
       u64 E0 = 0, E1 = 0, E2 = 0, E3 = 0;
       if (!(D_ABL & 16))
-        { const u64 all = A.emit_all() ? ~0ull : 0ull;
+        { const u64 all = (!(VAR & 2) && A.emit_all()) ? ~0ull : 0ull;       // (VAR & 2: the hash proof -- owners of a hi-side pair only)
           E0 = (hiM[0] | all) & ownM; E1 = (hiM[1] | all) & ownM; E2 = (hiM[2] | all) & ownM; E3 = (hiM[3] | all) & ownM;
           if (!INNER) { E0 &= V[0]; E1 &= V[1]; E2 &= V[2]; E3 &= V[3]; }
         }
@@ -572,7 +573,7 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
       unsigned base = 0;
       if (cnt_w)
         base = d_wave_add(S.s_qn, cnt_w, lane);
-      const bool fp = A.want_fp() && !(D_ABL & 1);
+      const bool fp = ((VAR & 2) || A.want_fp()) && !(D_ABL & 1);
       // Unrolled, the four entries kept apart by scheduling fences (interleaved they need ~30 more vector registers
       // than the kernel has).  The rolled loop -- the masks rotating through one register pair, a counter, two branches
       // per entry -- cost 0.7 ms more: scalar instructions and branches are not free next to a busy vector unit
@@ -709,7 +710,12 @@ d_detect(const P1Hot &A, const u64 *ent, const uint16_t *lcn, int64_t g0, int sa
 #define D_NCLS   8
 #define D_TICKW  32                       // words between two counters
 
-template <int W, int RW, bool ODD, bool KF> __global__ void __launch_bounds__(D_TPB)
+// VAR (round 5): bit 0 = this launch writes a bucket directory and / or look-up signatures; bit 1 = THE HOT FORM: the hash proof
+// through the look-up chain on a table that came with its prefix index -- no directory, no signatures, the two-bit candidate map,
+// the fingerprint, requests from the owners of a hi-side pair only, the per-bucket request histogram: all of it known at compile
+// time, none of those tests in the tile and none of their arguments in registers (33 -> 15 spilled SGPRs, 52 -> ~20 spill moves
+// per thread and tile: -0.27 ms on the diploid table for the directory / signature half alone).  VAR = 1 is the general form.
+template <int W, int RW, bool ODD, bool KF, int VAR = 1> __global__ void __launch_bounds__(D_TPB)
 __attribute__((amdgpu_waves_per_eu(D_WAVES(W, RW), D_WAVES(W, RW))))
 kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
 { __shared__ uint16_t tailq[D_OWN + 8];   // deferred tail: slots of this tile's queued entries
@@ -787,16 +793,16 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
       int64_t g0n = tnext * D_OWN - D_LEAD;
       if (tnext >= A.ntiles || g0n + D_SLOTS + 32 > n) g0n = -1;
       if (inner)
-        d_tile<W, RW, ODD, KF, true>(A, S, g0, g0n, t, fa, fb, pf);
+        d_tile<W, RW, ODD, KF, true, VAR>(A, S, g0, g0n, t, fa, fb, pf);
       else
-        d_tile<W, RW, ODD, KF, false>(A, S, g0, g0n, t, fa, fb, pf);
+        d_tile<W, RW, ODD, KF, false, VAR>(A, S, g0, g0n, t, fa, fb, pf);
       if (!(D_ABL & 4096)) lds_barrier();          // the staged copy and the queues of this tile are complete
       //@mark D_FLUSH
       const bool last = tnext >= A.ntiles;
       const unsigned tn = s_tn[par];               // (zeroed again behind the barrier at the end of this iteration: the
       const unsigned qn = s_qn;                    //  next tile counts in the other one)
       if (D_BM && A.bmap)                           // candidate-block bits of this tile -> global map
-        { const int two = A.two() ? 1 : 0;          // (two-bit map: twice the words, at twice the word offset)
+        { const int two = ((VAR & 2) || A.two()) ? 1 : 0;          // (two-bit map: twice the words, at twice the word offset)
           for (int w = t; w < (D_BMW << two); w += D_TPB)
             { const unsigned v = bm[w];
               if (v)
@@ -844,7 +850,7 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
               if (qn > head)
                 { if (old_chunk != F_NOCHUNK && old_chunk < max_chunks) cold->chunk_fill[old_chunk] = F_CH;
                   // (look-up chain: the partition kernel finds the chunks of owner w at w + j * owners, no list needed)
-                  if (D_BM && RW == W && A.hbits()) s_chunk = old_chunk == F_NOCHUNK ? blockIdx.x : old_chunk + cold->owners;
+                  if (D_BM && RW == W && ((VAR & 2) || A.hbits())) s_chunk = old_chunk == F_NOCHUNK ? blockIdx.x : old_chunk + cold->owners;
                   else s_chunk = atomicAdd(&cold->ctl->n_chunks, 1u);
                   s_used = qn - head;
                 }
@@ -853,7 +859,7 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
               s_qn = 0;
             }
           lds_barrier();
-          if (D_BM && RW == W && A.hbits())            // requests per bucket, for the partition of the look-up chain
+          if (D_BM && RW == W && ((VAR & 2) || A.hbits()))            // requests per bucket, for the partition of the look-up chain
             { const int hsh = 32 - A.hbits();
               for (unsigned e = t; e < qn; e += D_TPB) atomicAdd(&hist[(unsigned) (sq[e * RW] >> 32) >> hsh], 1u);
             }
@@ -873,15 +879,15 @@ kf_pass1_d(P1Hot A, const P1Cold *__restrict__ cold)
     }
 
   if (cold->times && t == 0) cold->times[3 * (size_t) blockIdx.x + 1] = wall_clock64();
-  if (D_BM && RW == W && A.hbits())                   // this workgroup's row of the request histogram (kl_tot / kl_woff)
+  if (D_BM && RW == W && ((VAR & 2) || A.hbits()))                   // this workgroup's row of the request histogram (kl_tot / kl_woff)
     for (int w = t; w < D_HB; w += D_TPB) cold->whist[(size_t) blockIdx.x * D_HB + w] = hist[w];
   if (t == 0)
     { if (s_chunk != F_NOCHUNK && s_chunk < cold->max_chunks) cold->chunk_fill[s_chunk] = s_used;
-      if (D_BM && RW == W && A.hbits() && s_chunk != F_NOCHUNK) atomicMax(&cold->ctl->n_chunks, s_chunk + 1u);   // slots in use
+      if (D_BM && RW == W && ((VAR & 2) || A.hbits()) && s_chunk != F_NOCHUNK) atomicMax(&cold->ctl->n_chunks, s_chunk + 1u);   // slots in use
       if (s_total) atomicAdd(&cold->ctl->nreq, s_total);
       if (s_unsorted) cold->ctl->unsorted = 1;
     }
-  if (A.want_fp())
+  if ((VAR & 2) || A.want_fp())
     { fa = wave_xor_u64(fa);
       fb = wave_xor_u64(fb);
       if ((t & 63) == 0) { sfp[t >> 6][0] = fa; sfp[t >> 6][1] = fb; }

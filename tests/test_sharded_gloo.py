@@ -378,3 +378,63 @@ def test_blockmap_ranges_of_cut_values_and_of_first_kmers():
     sp = np.array([0x4000000000000000, 5], dtype=np.uint64)
     wlo, wlen = sharded.blockmap_ranges(sp, 2, 2, bits, scale)
     assert wlo[0] + wlen[0] == wlo[1] + scale
+
+
+# ---- bench.py --gpus N on CPU: make_shard (per-rank generation, summed prefix index, summed checksum, cut-value splitters) and the
+#      sharded step on what it returns -- everything of the N > 1 bench path but the HIP engine
+def _bench_shard_worker(rank, world, port, workload, G, k, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    from fake_engine import NumpyEngine
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cpu")
+        sh = bench.make_shard(workload, G, k, dev, rank, world)
+        keys, cnt = sh["keys"].reshape(-1), sh["counts"]
+        plot, st = sharded.hetmers_sharded(k, keys, cnt, symcheck="hash", engine_factory=NumpyEngine, splitters=sh["splitters"],
+                                           sizes=sh["sizes"])
+        par = bench.parity_against_golden(workload, G, k, sh["n_total"], sh["hk"], sh["hc"], plot)
+        q.put((rank, sh["keys"].numpy().copy(), cnt.numpy().copy(), sh["sizes"], sh["first_entry"], sh["index"].numpy().copy(),
+               sh["hk"], sh["hc"], st["path"], plot.numpy().copy(), par["ok"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,workload,G,k", [(2, "uniform", 3000, 16), (3, "octoploid", 700, 17), (2, "hexaploid", 500, 35)])
+def test_bench_shards_and_the_sharded_step_on_them(world, workload, G, k):
+    sys.path.insert(0, os.path.dirname(HERE))
+    import bench
+    from smudgeplot_amd import synth_device
+    dev = torch.device("cpu")
+    k0, c0, L, _ = bench.make_table(workload, G, k, dev)
+    W = (k + 31) // 32
+    k0 = k0.reshape(c0.numel(), W)
+    keys_u = k0.numpy().view(np.uint64)
+    packed = np.ascontiguousarray(keys_u.astype(">u8")).view(np.uint8).reshape(len(keys_u), 8 * W)[:, : (k + 3) // 4]
+    want = brute.hetmers_plot(np.ascontiguousarray(packed), c0.numpy().view(np.uint16), k)
+    assert want.sum() > 0
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_shard_worker, args=(r, world, port, workload, G, k, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    whole_index = torch.cumsum(torch.bincount((k0[:, 0] >> 40) & 0xFFFFFF, minlength=1 << 24), 0).numpy()
+    hk, hc = synth_device.table_hash(k0, c0)
+    first = 0
+    for rank, kk, cc, sizes, fe, index, rhk, rhc, path, plot, par_ok in res:
+        assert fe == first and sizes == [len(r[2]) for r in res]
+        assert np.array_equal(kk.reshape(-1, W), k0.numpy()[first: first + len(cc)]) and np.array_equal(cc, c0.numpy()[first: first + len(cc)])
+        assert np.array_equal(index, whole_index)                 # the WHOLE table's prefix index on every rank
+        assert (rhk, rhc) == (hk, hc)                             # ... and its checksum
+        assert path == 1 and np.array_equal(plot.reshape(1001, 501), want), rank
+        assert par_ok is None                                     # (no golden at this size: the block says so, it does not fail)
+        first += len(cc)
+    assert first == c0.numel()
