@@ -151,8 +151,12 @@ def _worker(rank, world, port, workload, G, k, steps, replay, drop, q, table=Non
 
 
 def _run(world, workload, G, k, steps=2, replay=False, drop=None, table=None):
+    import gc
     import torch
     import torch.multiprocessing as mp
+    # the ranks share this process's GPU: what earlier tests of the session left in torch's cache (the full-size tables) goes back
+    gc.collect()
+    torch.cuda.empty_cache()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
