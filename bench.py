@@ -15,6 +15,10 @@ N>1: STRONG scaling -- the same table, prefix-sharded across the ranks (every ra
 the whole table); one all_to_all of the complement requests and one all_reduce of the 2-D histogram per step.
 After the timed loop the plot of the last step is rendered as .smu text and compared with the REFERENCE binary's output
 for this very table (tests/golden/bench_<workload>.smu; "parity" in the JSON line); a mismatch exits non-zero.
+Then, still outside the timed region, the END-TO-END comparison of SURVEY.md section 8d (ii) / BASELINE.md section 3 is run in
+this very process ("e2e" in the JSON line): a ~1e9-entry table of the bench's own generator is written as FastK files, the
+drop-in executable (smudgeplot_amd/bin/hetmers) and the reference binary (oracle/_ref/hetmers_ref) run on those IDENTICAL files,
+wall clock around each process, and the two .smu files are compared byte for byte.  "cpu_baseline" is that reference run.
 
 value = table entries (k-mers) x steps / wall time, wall = max over ranks between barriers.
 """
@@ -67,9 +71,8 @@ def make_table(workload: str, G: int, k: int, dev, seed: int = 1, key_range=None
         rep = 0.05 if workload == "repeats" else 0.0
         if k <= 31:
             keys, cnt = synth_device.diploid_table(G, k=k, het=0.01, cov=50.0, L=L, seed=seed, device=dev, repeats=rep, **kr)
-        elif G <= 5 * 10 ** 8 and key_range is None:   # two-word k-mers (BASELINE configs[4] is k=51); keys is [n, 2]
-            keys, cnt = synth_device.diploid_table_wide(G, k=k, het=0.01, cov=50.0, L=L, seed=seed, device=dev)
-        else:                                  # the same model generated chunk by chunk of the key space (1 Gbp fits)
+        else:                                  # two-word k-mers (BASELINE configs[4] is k=51); keys is [n, 2].  ONE generator whatever
+            # the size and the number of ranks (chunk by chunk of the key space), so that the shards of N ranks are the table of N = 1
             keys, cnt = synth_device.polyploid_table_wide(G, ploidy=2, rates=(0.01,), cov_hap=25.0, k=k, L=L, seed=seed, device=dev, **kr)
         desc = f"synthetic diploid {G:.3g} bp, 50x, 1% het, k={k}, L={L}" + \
                (", 5% of the genome repeats (dispersed, tandem, homopolymer)" if rep else "")
@@ -173,41 +176,83 @@ def lib_hash() -> str:
     return codeobj.code_object_hash()
 
 
-def cpu_baseline(workload: str, sample_genome: int, k: int, dev):
-    """Time the REFERENCE hetmers binary (oracle/_ref, compiled from the reference's own sources) on a bounded sample
-    of the SAME workload -- the bench's own generator at 1/25 of the genome: ~1e8 table entries, ~6 s of wall time
-    at -T64 -- on this box's host cores.  (Round 1 timed a 2e7-entry table, on which the reference reaches 1.1e7
-    k-mers/s; on 1e8 entries it reaches 1.7e7 -- as on the 1e9-entry table of profiles/r02_e2e_1e9_entries.json.)"""
-    ref = os.path.join(ROOT, "oracle", "_ref", "hetmers_ref")
-    if not os.path.exists(ref):
-        return None
-    cores = min(64, os.cpu_count() or 1)
-    tk, tc, L, _ = make_table(workload, sample_genome, k, dev, seed=7)
-    cnt = tc
-    with tempfile.TemporaryDirectory(prefix="smg_cpu") as d:
-        synth_device.write_table_from_device(os.path.join(d, "t"), tk, tc, k, nparts=4)
-        del tk
-        best = None
-        for _ in range(2):                       # second run = warm page cache
-            out = os.path.join(d, "cpu.smu")
-            if os.path.exists(out):
-                os.remove(out)
-            t0 = time.time()
-            subprocess.run([ref, f"-e{L}", f"-T{cores}", "-ocpu", "t.ktab"], cwd=d, check=True,
-                           capture_output=True)
-            best = time.time() - t0
-    out = {"value": cnt.numel() / best, "unit": "k-mers/s", "cores": cores, "kind": "reference",
-           "sample": f"reference hetmers -T{cores} on a {cnt.numel()}-entry table of the same generator "
-                     f"(genome {sample_genome} bp, k={k}; warm second run, {best:.1f} s wall)"}
-    # the reference on the IDENTICAL full-size table (BASELINE.md section 3) takes minutes: measured once per round by
-    # tools/e2e_full_table.py on the GPU box and kept under profiles/ -- quoted here, not re-run in the driver's time
-    ident = {"uniform": ("profiles/r04_e2e_config3_full.json", 2535258108, 156.03),
-             "octoploid": ("profiles/r04_e2e_octoploid_full.json", 637035910, 42.57),
-             "hexaploid": ("profiles/r04_e2e_hexaploid_k51_full.json", 1356853458, 141.82)}.get(workload)
-    if ident and sample_genome * 25 == default_genome(workload) and k == default_k(workload):
-        out["identical_table"] = {"kmers_per_s": ident[1] / ident[2], "wall_s": ident[2], "entries": ident[1], "cores": 64,
-                                  "source": ident[0] + " (reference -T64 on this bench table's files, byte-identical .smu)"}
-    return out
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "hetmers_ref")
+OUR_BIN = os.path.join(ROOT, "smudgeplot_amd", "bin", "hetmers")
+
+
+def e2e_genome(workload: str, G: int) -> int:
+    """size of the end-to-end table: the north-star's "1e9-entry k=31 table" for the diploid workloads (4e8 bp -> 1.01e9
+    entries; the reference takes about a minute on it at -T64), the bench table itself for the octoploid stand-in, 1.5e8 bp
+    of the hexaploid one (the reference needs 140 s for the whole of it)"""
+    cap = {"uniform": 4 * 10 ** 8, "repeats": 4 * 10 ** 8, "octoploid": 2 * 10 ** 8, "hexaploid": 15 * 10 ** 7}[workload]
+    return min(int(G), cap)
+
+
+def _scratch_dir(nbytes: int) -> str:
+    """where the table files go: memory-backed /dev/shm when it has room for them twice over (the files are read from the page
+    cache either way: both programs are timed warm), else the default temporary directory"""
+    try:
+        st = os.statvfs("/dev/shm")
+        if st.f_bavail * st.f_frsize > 2 * nbytes + (8 << 30):
+            return "/dev/shm"
+    except OSError:
+        pass
+    return tempfile.gettempdir()
+
+
+def end_to_end(workload: str, G: int, k: int, dev, runs: int = 2):
+    """process start -> .smu closed, on the IDENTICAL table files, for the drop-in executable and for
+    the reference binary, timed in THIS process on this box's host cores; the two .smu files are compared byte for byte.
+    -> (e2e block, cpu_baseline block).  The reference binary is the judge and the baseline here, never part of the product
+    path; without it (or without the executable) the bench fails loudly instead of printing a line without a baseline."""
+    for path, what in ((REF_BIN, "the reference binary (python -c 'import __graft_entry__ as g; g.build()' builds it where "
+                                 "/root/reference exists; it travels to the GPU box with the tree)"),
+                       (OUR_BIN, "the drop-in executable (make -C smudgeplot_amd/csrc)")):
+        if not (os.path.isfile(path) and os.access(path, os.X_OK)):
+            raise SystemExit(f"bench.py: {os.path.relpath(path, ROOT)} is missing -- {what}; --no-cpu runs without the CPU comparison")
+    cores = min(64, os.cpu_count() or 1)                        # (the reference clamps -T at 64, PloidyPlot.c:1279-1282)
+    t0 = time.time()
+    tk, tc, L, desc = make_table(workload, G, k, dev)           # the bench's own generator, the bench's own seed
+    torch.cuda.synchronize()
+    n = tc.numel()
+    t_gen = time.time() - t0
+    nbytes = n * ((k + 3) // 4 - 3 + 2) + (1 << 27)
+    with tempfile.TemporaryDirectory(prefix="smg_e2e", dir=_scratch_dir(nbytes)) as d:
+        t0 = time.time()
+        written = synth_device.write_table_from_device(os.path.join(d, "t"), tk, tc, k, nparts=4)
+        t_write = time.time() - t0
+        del tk, tc
+        torch.cuda.empty_cache()
+
+        def timed(argv, out):
+            p = os.path.join(d, out + ".smu")
+            if os.path.exists(p):
+                os.remove(p)
+            with open(os.path.join(d, out + ".err"), "w") as err:      # (files, not pipes: a pipe is read until the GPU worker
+                t0 = time.perf_counter()                               #  process has closed its end too, hetmers_main.c)
+                r = subprocess.run(argv, cwd=d, stdin=subprocess.DEVNULL, stdout=err, stderr=err)
+                dt = time.perf_counter() - t0
+            if r.returncode != 0:
+                raise SystemExit("bench.py: %s failed (exit %d): %s" % (" ".join(argv), r.returncode,
+                                                                        open(os.path.join(d, out + ".err")).read()[-2000:]))
+            return dt, open(p, "rb").read()
+
+        ours = [timed([OUR_BIN, f"-e{L}", "-T4", "-ogpu", "t.ktab"], "gpu") for _ in range(runs)]
+        ref_s, ref_smu = timed([REF_BIN, f"-e{L}", f"-T{cores}", "-oref", "t.ktab"], "ref")
+    best = min(dt for dt, _ in ours)
+    same = all(smu == ref_smu for _, smu in ours)
+    e2e = {"entries": int(n), "k": k, "table": f"{desc}: {n} entries, {written} bytes in 4 part files + stub (format F, ibyte 3)",
+           "hetmers_wall_s": round(best, 3), "hetmers_runs_s": [round(dt, 3) for dt, _ in ours],
+           "reference_wall_s": round(ref_s, 3), "cores": cores, "smu_identical": bool(same), "smu_bytes": len(ref_smu),
+           "speedup": round(ref_s / best, 1),
+           "what": "wall clock around each process (exec -> exit), same files, page cache warm from the write; hetmers = "
+                   "smudgeplot_amd/bin/hetmers -T4 (two processes: hetmers_main.c), reference = oracle/_ref/hetmers_ref "
+                   f"-T{cores}; generated in {t_gen:.1f} s, written in {t_write:.1f} s"}
+    cpu = {"value": n / ref_s, "unit": "k-mers/s", "cores": cores, "kind": "reference",
+           "sample": f"reference hetmers -T{cores}, wall clock of the whole process on a {n}-entry table of the bench's generator "
+                     f"(genome {G} bp, k={k}): {ref_s:.1f} s, .smu {'identical to' if same else 'DIFFERENT from'} the drop-in's "
+                     "on the same files (the e2e block)"}
+    return e2e, cpu
 
 
 def main():
@@ -218,8 +263,9 @@ def main():
     ap.add_argument("--genome", type=float, default=0, help="haploid genome size in bases (default: the workload's, 1e9 for uniform)")
     ap.add_argument("--k", type=int, default=0, help="default 31 (hexaploid: 51)")
     ap.add_argument("--symcheck", default="hash", choices=["exact", "hash"])
-    ap.add_argument("--cpu-sample", type=float, default=0, help="genome size of the CPU baseline's sample (default: genome / 25)")
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--e2e-genome", type=float, default=0, help="genome size of the end-to-end / CPU-baseline table (default: "
+                                                                "4e8 bp = 1.01e9 entries for the diploid workloads)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the end-to-end comparison with the reference binary (e2e, cpu_baseline)")
     ap.add_argument("--no-index", action="store_true", help="do not hand the table's prefix index to the engine (pass 1 builds "
                                                             "a directory of its own, as in rounds 1-3)")
     ap.add_argument("--workload", default="uniform", choices=list(WORKLOADS),
@@ -300,10 +346,13 @@ def main():
     # the dominant KERNEL: pass 1 and pass 2 are one launch each; the look-up phase is a chain of
     # short launches (compact, 4 radix passes, in-order look-ups), each well below pass 1
     tf = lambda b: "true" if b else "false"                                   # noqa: E731
+    # (the name as rocprofv3 prints it: <W, RW, ODD, KF, VAR>; VAR = 2 is the hot form -- hash proof, the table's prefix index
+    #  as directory, the 32-bit two-bit candidate map of a run that exchanges no maps: fast_pass1 in smg_hetmers.hip)
+    var = 2 if (args.symcheck == "hash" and not args.no_index and not (world > 1 or force) and args.k >= 24) else 1
     if args.k <= 32:
-        p1 = "kf_pass1_d<1, %d, %s, %s>" % (1 if args.symcheck == "hash" else 2, tf(args.k & 1), tf(17 <= args.k))
+        p1 = "kf_pass1_d<1, %d, %s, %s, %d>" % (1 if args.symcheck == "hash" else 2, tf(args.k & 1), tf(17 <= args.k), var)
     elif args.k <= 64:
-        p1 = "kf_pass1_d<2, %d, %s, false>" % (2 if args.symcheck == "hash" else 3, tf(args.k & 1))
+        p1 = "kf_pass1_d<2, %d, %s, false, %d>" % (2 if args.symcheck == "hash" else 3, tf(args.k & 1), var)
     else:
         p1 = "kf_pass1<3>"
     single = {"ms_pass1": p1, "ms_pass2": "kf_pass2<%d>" % ((args.k + 31) // 32)}
@@ -327,10 +376,10 @@ def main():
 
     if rank == 0:
         parity = parity_against_golden(args.workload, G, args.k, n_total, hk, hc, plot)
-        # the CPU baseline is timed on rank 0 of the single-GPU run only (it takes ~25 s of host time)
-        cpu = None
+        # the end-to-end comparison and the CPU baseline: rank 0 of the single-GPU run only (the reference takes about a minute)
+        cpu = e2e = None
         if not (args.no_cpu or world > 1):
-            cpu = cpu_baseline(args.workload, int(args.cpu_sample) if args.cpu_sample else max(G // 25, 100000), args.k, dev)
+            e2e, cpu = end_to_end(args.workload, int(args.e2e_genome) if args.e2e_genome else e2e_genome(args.workload, G), args.k, dev)
         value = n_total * args.steps / dt
         out = {
             "metric": "k-mers/sec through hetmers (k=%d)" % args.k,
@@ -357,6 +406,8 @@ def main():
                          "whole_job_frac_of_the_B_alg_roofline":
                              (n_total * 2.0 * alg_bytes_per_kmer_pass(args.k) / (dt / args.steps)) / 1e9 / (HBM_PEAK_GBS * world)},
             "cpu_baseline": cpu,
+            # process start -> .smu closed on identical table files: the drop-in executable next to the reference binary
+            "e2e": e2e,
             # the plot of the last TIMED step against the reference binary's .smu of this very table (outside the timed region)
             "parity": parity,
             "pairs_in_plot": int(plot.sum().item()),
@@ -365,6 +416,8 @@ def main():
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0 and e2e is not None and not e2e["smu_identical"]:
+        raise SystemExit("bench.py: the drop-in executable's .smu differs from the reference binary's on the end-to-end table")
     if rank == 0 and parity["ok"] is False:
         raise SystemExit("bench.py: the plot of the timed run differs from the reference binary's .smu of this table (%s)"
                          % parity.get("golden"))

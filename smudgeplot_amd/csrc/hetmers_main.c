@@ -35,6 +35,14 @@
  *  what is still going on for a few tens of milliseconds is the release of the GPU by a process nobody waits for.
  *  Any failure to set this up (fork, mmap, pipe) falls back to the one process.
  *
+ *  The caller still deals with ONE process (round 6).  The reference is a single process without signal handlers
+ *  (PloidyPlot.c:1232-1630; cli.py:57-72 waits for it with subprocess.run): killed, it is gone and nothing writes
+ *  <out>.smu afterwards.  So the worker asks the kernel for SIGTERM when the starter dies (PR_SET_PDEATHSIG, and looks at
+ *  getppid() once more behind it), the starter hands SIGINT / SIGTERM / SIGHUP / SIGQUIT on to the worker and then dies
+ *  of the signal itself, a worker that is signalled while <out>.smu is open unlinks the half-written file, and a worker
+ *  that dies without a word costs the starter exit status 1 and the half-written file.  The death signal is withdrawn
+ *  once the .smu is closed: from there on the worker only hands the device back.
+ *
  *  Deviations, deliberate:
  *    - the "use it?" prompt stops at EOF on stdin (the reference spins forever there,
  *      PloidyPlot.c:1328);
@@ -45,6 +53,8 @@
 
 #include <time.h>
 #include <unistd.h>
+#include <signal.h>
+#include <sys/prctl.h>
 #include <sys/mman.h>
 #include <sys/types.h>
 #include <sys/wait.h>
@@ -67,6 +77,7 @@ static double real_s(void)
 typedef struct
 { smg_opts opts;
   int      have_input;
+  volatile int smu_state;        /* 0 not opened yet, 1 open and being written, 2 complete and closed */
   double   t_probe;
   char     input[4096], name[4096];
   int64_t  index[SHARED_IXWORDS];
@@ -74,6 +85,16 @@ typedef struct
 
 /* run the engine on the open table T (conditioned, or to be conditioned on the device: opts), write <OUT>.smu: the part of
    main() behind the table probe.  Returns the exit status. */
+/* the output while it is open: a signalled process takes the half-written file with it (handlers below) */
+static char                  Smu_Path[4200];
+static volatile sig_atomic_t Smu_Open = 0;
+static volatile int         *Smu_State = NULL;      /* the starter's view of the same (two processes), or NULL */
+
+static void smu_mark(int state)
+{ Smu_Open = state == 1;
+  if (Smu_State != NULL) *Smu_State = state;
+}
+
 static int run(const smg_cli *c, const char *OUT, smg_ktab *Tp, const smg_opts *opts, char *input,
                double t_start, double rt_start, double t_probe)
 { smg_ktab T = *Tp;
@@ -110,16 +131,19 @@ static int run(const smg_cli *c, const char *OUT, smg_ktab *Tp, const smg_opts *
     FILE *f;
     int   a;
     sprintf(fname, "%s.smu", OUT);
+    snprintf(Smu_Path, sizeof(Smu_Path), "%s", strlen(fname) < sizeof(Smu_Path) ? fname : "");
     f = fopen(fname, "w");
     if (f == NULL)
       { fprintf(stderr, "Could not open %s.smu\n", OUT);
         return 1;
       }
+    smu_mark(1);
     for (a = 0; a <= SMG_SMAX; a++)
       for (i = 0; i < SMG_FMAX; i++)
         if (plot[a * SMG_PLOT_COLS + i] > 0)
           fprintf(f, "%i\t%i\t%lld\n", i, a - i, (long long) plot[a * SMG_PLOT_COLS + i]);
     fclose(f);
+    smu_mark(2);
     free(fname);
   }
   free(plot);
@@ -129,6 +153,34 @@ static int run(const smg_cli *c, const char *OUT, smg_ktab *Tp, const smg_opts *
             (now_s() - t_start) * 1e3, (t_probe - t_start) * 1e3, (t_engine - t_probe) * 1e3,
             (now_s() - t_engine) * 1e3, rt_start, real_s());
   return 0;
+}
+
+/* ---- one process as far as the caller can tell (two processes) ---- */
+
+static volatile pid_t Worker_Pid = -1;
+static const int Handed_On[] = { SIGINT, SIGTERM, SIGHUP, SIGQUIT };
+
+/* worker: take a half-written .smu along and go (unlink and _exit are async-signal-safe) */
+static void worker_signalled(int sig)
+{ if (Smu_Open && Smu_Path[0] != 0) unlink(Smu_Path);
+  _exit(128 + sig);
+}
+
+/* starter: hand the signal on, then die of it as the reference's one process would */
+static void starter_signalled(int sig)
+{ if (Worker_Pid > 0) kill(Worker_Pid, sig);
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+
+static void install(void (*handler)(int))
+{ struct sigaction sa;
+  size_t i;
+  memset(&sa, 0, sizeof(sa));
+  sa.sa_handler = handler;
+  sigemptyset(&sa.sa_mask);
+  for (i = 0; i < sizeof(Handed_On) / sizeof(Handed_On[0]); i++)
+    sigaction(Handed_On[i], &sa, NULL);
 }
 
 static const char *Usage[] = { " [-v] [-T<int(4)>] [-P<dir(/tmp)>]",
@@ -186,23 +238,33 @@ int main(int argc, char *argv[])
       }
     if (two && (pipe(to_worker) != 0 || pipe(to_starter) != 0)) two = 0;
     if (two)
-      { fflush(NULL);
+      { const pid_t starter = getpid();
+        sh->smu_state = 0;
+        fflush(NULL);
         pid = fork();
         if (pid < 0) two = 0;
+        if (pid == 0)
+          { install(worker_signalled);
+            prctl(PR_SET_PDEATHSIG, SIGTERM);                    /* the starter gone (however: SIGKILL too) = this one gone */
+            if (getppid() != starter) _exit(1);                  /* (it went between fork() and prctl()) */
+          }
       }
     if (two && pid == 0)
       { /* ---- the worker: start the runtime, wait for the table, do the work ---- */
         char go = 0, status;
         close(to_worker[1]); close(to_starter[0]);
+        Smu_State = &sh->smu_state;
         (void) smg_device_count();                               /* the first HIP call of the process */
         if (read(to_worker[0], &go, 1) != 1 || go != 1) _exit(1);   /* (the starter failed, and has said why) */
         { smg_ktab T;
           smg_ktab_set_index_memory(sh->index, SHARED_IXWORDS, 1);           /* (the index is there: the stub is only looked at) */
           load_or_die(sh->name, &T);
           smg_ktab_set_index_memory(NULL, 0, 0);
-          status = (char) run(&c, OUT, &T, &sh->opts, sh->have_input ? sh->input : NULL, t_start, rt_start, sh->t_probe);
+          /* (run() frees the name of a temporary table it was given: a heap copy, not the shared mapping's array) */
+          status = (char) run(&c, OUT, &T, &sh->opts, sh->have_input ? strdup(sh->input) : NULL, t_start, rt_start, sh->t_probe);
         }
         fflush(NULL);
+        prctl(PR_SET_PDEATHSIG, 0);                              /* the .smu is closed: the starter may leave first from here on */
         if (write(to_starter[1], &status, 1) != 1) _exit(1);
         _exit(status);                                           /* (nobody waits for what this takes) */
       }
@@ -211,6 +273,8 @@ int main(int argc, char *argv[])
         smg_ktab T;
         char go = 1, status = 1;
         close(to_worker[0]); close(to_starter[1]);
+        Worker_Pid = pid;
+        install(starter_signalled);
         smg_ktab_set_index_memory(sh->index, SHARED_IXWORDS, 0);
         input = smg_cli_open_table(&c, SRC, &T, &opts);          /* (exits 1 with the reference's message when it cannot) */
         smg_ktab_set_index_memory(NULL, 0, 0);
@@ -224,7 +288,14 @@ int main(int argc, char *argv[])
         if (read(to_starter[0], &status, 1) != 1)                /* the worker died without a word: its exit status says how */
           { int ws = 0;
             waitpid(pid, &ws, 0);
-            fprintf(stderr, "%s: the GPU worker process ended unexpectedly\n", Prog_Name);
+            if (sh->smu_state == 1)                              /* it died over the output: no half-written .smu stays behind */
+              { char *name = (char *) malloc(strlen(OUT) + 8);
+                if (name != NULL) { sprintf(name, "%s.smu", OUT); unlink(name); free(name); }
+              }
+            if (WIFSIGNALED(ws))
+              fprintf(stderr, "%s: the GPU worker process ended unexpectedly (signal %d)\n", Prog_Name, WTERMSIG(ws));
+            else
+              fprintf(stderr, "%s: the GPU worker process ended unexpectedly\n", Prog_Name);
             exit(1);
           }
         fflush(NULL);

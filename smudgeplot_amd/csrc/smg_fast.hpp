@@ -1057,7 +1057,7 @@ kf_route_offsets(const uint32_t *__restrict__ counts, unsigned nc, int nranks, u
 template <int W> __global__ void __launch_bounds__(F_TPB)
 kf_route_scatter(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk_fill, int rw,
                  const u64 *__restrict__ split, int nranks, const u64 *__restrict__ offsets, const u64 *__restrict__ totals,
-                 u64 *__restrict__ out)
+                 u64 *__restrict__ out, u64 capacity /* records the send buffer holds */)
 { __shared__ unsigned cur[16];
   __shared__ u64 rbase[16];
   if (threadIdx.x < 16)
@@ -1072,6 +1072,10 @@ kf_route_scatter(const u64 *__restrict__ req, const uint32_t *__restrict__ chunk
     { const u64 *q = req + ((size_t) blockIdx.x * F_CH + r) * rw;
       const int d = rank_of<W>(q, split, nranks);
       const u64 slot = rbase[d] + offsets[(size_t) blockIdx.x * nranks + d] + atomicAdd(&cur[d], 1u);
+      // A plain step sized the buffer from this very list.  A REPLAYED step sized it from the recorded step's count: if the
+      // table's counts moved so that more requests survive, the surplus is dropped here instead of written past the end --
+      // the totals differ from the record, the verdict kernel says so and every rank runs the step again the plain way.
+      if (slot >= capacity) continue;
       u64 *o = out + slot * rw;
       for (int w = 0; w < rw; w++) o[w] = q[w];
     }

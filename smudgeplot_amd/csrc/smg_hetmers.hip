@@ -579,9 +579,6 @@ struct smg_engine
   bool         dir_preset;                   //   the current run looks up through ixdir: pass 1 writes no directory
   bool         have_ends;  u64 end_first, end_last;     // leading words of the first and the last entry of the bound table (read once)
   bool         no_filter;    // pass 1 builds no candidate map and nothing is filtered (out-of-core shards: smg_multi.hpp, host_run_sequential)
-  bool         fused_last;   // the look-ups of the last run were the fused ones (kl_part -> kl_probe on the engine's own map)
-  bool         spec_ok;      // the last smg_engine_run on this bound table went through the hash-proof chain: its counts size the next one
-  int64_t      spec_nreq, spec_nbig;   //   requests pass 1 (+ kf_bigfix) emitted, entries deferred to kf_bigfix (functions of the table)
   // replay of the PHASE calls (sharded runs, smg_engine_set_replay): a step on a table whose last step went through pass1 ->
   // filter (hash proof, look-up chain) is queued without a read-back -- the counts the host needs are last step's (functions
   // of the table and of the exchanged maps), the device compares them with this step's and reports through smg_engine_proof
@@ -729,7 +726,7 @@ static int set_table(smg_engine *e, int kmer, int64_t nels, char *errbuf, size_t
   e->n = nels;
   e->prepared = false; e->counted_done = false; e->lookup_pending = false;
   e->have_ixdir = false; e->dir_preset = false; e->have_ends = false;        // (properties of the table that was bound before)
-  e->spec_ok = false; e->rp_have = false; e->rp_active = false;
+  e->rp_have = false; e->rp_active = false;
   memset(&e->st, 0, sizeof(e->st));
   e->st.nels = nels;
   e->st.key_words = e->W;
@@ -1113,11 +1110,11 @@ static int bm_id_bits(int kmer, int cap);
 static bool filter_ok(const smg_engine *e)
 { return e->kmer >= 2 && ((e->W == 1 && e->rw == 1) || (e->W == 2 && e->rw != 1) || (e->W == 3 && e->rw == 4)); }
 
-// spec: a run on a table this engine has run before (smg_engine_run).  Everything is launched as ever, but nothing is read
-// back here: the lists are as large as last time, the counts that later launches take from the host (requests, deferred
-// entries) are last run's -- they are functions of the table -- and the caller checks all of it against the control words
-// once, at the end of the run.
-static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, char *errbuf, size_t errlen, bool spec = false)
+// replay: a step of the phase API on the table of the step before (smg_engine_set_replay).  Everything is launched as ever, but
+// nothing is read back here: the lists are as large as last time, the counts that later launches take from the host (requests,
+// deferred entries) are the recorded step's -- they are functions of the table -- and the device checks all of it against the
+// control words at the end of the step (k_proof_replay).
+static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, char *errbuf, size_t errlen, bool replay = false)
 { int rc;
   // record = the complement k-mer (W words) [+ one word: count | has-hi-pair << 16]
   // (two-word k-mers send key-only records for the hash proof as one-word ones do: 16 instead of 24 bytes for 21.6 % of
@@ -1309,7 +1306,7 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
           hipEventRecord(e->ev[3], e->stream);
           HIPCHK(hipGetLastError());
         }
-      if (spec) { done = true; break; }
+      if (replay) { done = true; break; }
       if ((rc = read_ctrl(e, errbuf, errlen))) return rc;
       if (narrow && e->h_p1cold->times)
         { std::vector<u64> tm((size_t) grid * 3);
@@ -1350,11 +1347,11 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
     }
   // (each redo sizes the lists from the counts the failed attempt reported, so the second attempt fits; a list that
   //  still overflows after that is a bug, and must not be read as a complete request list)
-  if (spec)
+  if (replay)
     { e->rp_grid = grid;
-      e->n_chunks = 1;                      // (> 0: "there are requests"; the real number is checked at the end of the run)
-      e->st.nrequests = e->st.nemitted = e->spec_nreq;
-      e->st.nbig = e->spec_nbig;
+      e->n_chunks = 1;                      // (> 0: "there are requests"; the real number is checked at the end of the step)
+      e->st.nrequests = e->st.nemitted = e->rp_nreq;
+      e->st.nbig = e->rp_nbig;
       e->st.ms_filter = 0; e->st.ms_bigfix = 0;
       e->far_listed = narrow;
       e->prepared = true;
@@ -1680,19 +1677,16 @@ static int compact_chunks(smg_engine *e, int64_t nreq, char *errbuf, size_t errl
 // look-ups of this engine's own request chunks (flat = NULL; filtered first if a block map was built) or of a flat
 // array of received records
 static int fast_apply(smg_engine *e, const u64 *flat, int64_t nflat, int check_count, int64_t *missing,
-                      char *errbuf, size_t errlen, bool spec = false)
+                      char *errbuf, size_t errlen)
 { int rc = SMG_OK;
-  e->fused_last = false;
   if (!flat && e->lg.nb && e->bm_bits && !e->filtered && !getenv("SMG_LOOKUP_SPLIT"))
     { // own requests, own map: partition, then filter and look-ups in one kernel (no survivor list, no sort)
       if (e->n_chunks == 0 || e->st.nrequests == 0) { if (missing) *missing = 0; return SMG_OK; }
       if (!e->presorted && (rc = filter_presort(e, errbuf, errlen))) return rc;
-      e->fused_last = true;
       hipEvent_t mid = e->ev[10];
       hipEventRecord(mid, e->stream);
       if ((rc = lookup_probe(e, e->bmap, false, 0u, errbuf, errlen))) return rc;
       hipEventRecord(e->ev[5], e->stream);
-      if (spec) { e->filtered = true; e->n_chunks = 0; return SMG_OK; }      // (missing / kept: read at the end of the run)
       if ((rc = read_ctrl(e, errbuf, errlen))) return rc;
       float ms = 0;
       hipEventElapsedTime(&ms, e->ev[4], mid); e->st.ms_filter = ms;       // scan + partition
@@ -1835,7 +1829,6 @@ extern "C" int smg_engine_pass1(smg_engine *e, int symcheck, char *errbuf, size_
   if (e->rp_want && e->rp_have && symcheck == SMG_SYM_HASH && e->rp_sym == symcheck && e->n > 0
       && e->rp_bm_bits == bm_id_bits(e->kmer, e->bm_cap))
     { // the step before this one, on this very table, went through the look-up chain: queue this one from its counts
-      e->spec_nreq = e->rp_nreq; e->spec_nbig = e->rp_nbig;
       const int rc = fast_pass1(e, 0, 0, 1, errbuf, errlen, true);
       if (rc) return rc;
       e->rp_active = true; e->rp_routed = false;
@@ -2063,7 +2056,7 @@ extern "C" int smg_engine_symhash(smg_engine *e, uint64_t out[4], char *errbuf, 
 // records (rw words each, the first W of them a k-mer) in chunks of F_CH -> d_send, grouped by the rank whose k-mer
 // range holds the k-mer (splitters = first k-mer of ranks 1..nranks-1); counts[nranks] on the host
 static int route_records(smg_engine *e, const u64 *req, const uint32_t *chunk_fill, unsigned nc, int rw,
-                         const uint64_t *splitters, int nranks, uint64_t *d_send, int64_t *counts,
+                         const uint64_t *splitters, int nranks, uint64_t *d_send, int64_t capacity, int64_t *counts,
                          char *errbuf, size_t errlen, int64_t *d_counts = NULL /* device: the totals stay there, no host wait */)
 { if (counts) for (int r = 0; r < nranks; r++) counts[r] = 0;
   if (nc == 0)
@@ -2084,7 +2077,8 @@ static int route_records(smg_engine *e, const u64 *req, const uint32_t *chunk_fi
   // offsets and scatter follow on the device; the host only learns the totals (what the exchange needs): ONE round trip
   hipLaunchKernelGGL(kf_route_offsets, dim3(nranks), dim3(1024), 0, e->stream, (const uint32_t *) e->route_cnt, nc, nranks, e->route_off, totals);
 #define CALL(WW) hipLaunchKernelGGL(kf_route_scatter<WW>, dim3(nc), dim3(F_TPB), 0, e->stream, req, \
-                   chunk_fill, rw, e->d_split, nranks, (const u64 *) e->route_off, (const u64 *) totals, (u64 *) d_send)
+                   chunk_fill, rw, e->d_split, nranks, (const u64 *) e->route_off, (const u64 *) totals, (u64 *) d_send, \
+                   (u64) (capacity < 0 ? 0 : capacity))
   DISPATCH_W(e, CALL)
 #undef CALL
   HIPCHK(hipGetLastError());
@@ -2108,7 +2102,7 @@ extern "C" int smg_engine_route(smg_engine *e, const uint64_t *splitters, int nr
   if (!e->prepared) return fail(errbuf, errlen, SMG_EINVAL, "route before pass1%s");
   HIPCHK(hipSetDevice(e->device));
   if (e->st.nrequests > capacity) return fail(errbuf, errlen, SMG_EINVAL, "send buffer too small%s");
-  return route_records(e, e->req, e->chunk_fill, e->n_chunks, e->rw, splitters, nranks, d_send, counts, errbuf, errlen);
+  return route_records(e, e->req, e->chunk_fill, e->n_chunks, e->rw, splitters, nranks, d_send, capacity, counts, errbuf, errlen);
 }
 
 extern "C" int smg_engine_route_device(smg_engine *e, const uint64_t *splitters, int nranks, uint64_t *d_send, int64_t capacity,
@@ -2119,7 +2113,7 @@ extern "C" int smg_engine_route_device(smg_engine *e, const uint64_t *splitters,
   if (!e->prepared) return fail(errbuf, errlen, SMG_EINVAL, "route before pass1%s");
   HIPCHK(hipSetDevice(e->device));
   if (e->st.nrequests > capacity) return fail(errbuf, errlen, SMG_EINVAL, "send buffer too small%s");
-  int rc = route_records(e, e->req, e->chunk_fill, e->n_chunks, e->rw, splitters, nranks, d_send, NULL, errbuf, errlen, d_counts);
+  int rc = route_records(e, e->req, e->chunk_fill, e->n_chunks, e->rw, splitters, nranks, d_send, capacity, NULL, errbuf, errlen, d_counts);
   if (rc || !e->rp_want || !e->fast) return rc;
   // replay: the per-destination totals of a plain step are kept, those of a replayed step are put beside them -- the verdict
   // kernel (smg_engine_proof) compares the two: the caller splits its exchange by the RECORDED totals
@@ -2157,44 +2151,6 @@ extern "C" int smg_engine_stats(smg_engine *e, smg_stats *stats)
   return SMG_OK;
 }
 
-// The hash-proof run of a table that this engine has run before, without a host round trip in the middle.  SMG_OK: the
-// plot is in d_plot and e->st is filled in; SMG_ERETRY: one of the counts differs from last time's (or a list overflowed):
-// nothing of this attempt is to be used, the caller runs the table the plain way.
-#define SMG_ERETRY (-1000)
-static int run_speculative(smg_engine *e, int64_t *d_plot, char *errbuf, size_t errlen)
-{ int rc;
-  if ((rc = fast_pass1(e, 0, 0, 1, errbuf, errlen, true))) return rc;
-  const unsigned grid = e->p1grid;
-  if ((rc = fast_apply(e, NULL, 0, 0, NULL, errbuf, errlen, true))) return rc;
-  if (!e->fused_last) return SMG_ERETRY;                     // (not the fused chain after all: nothing to take for granted)
-  if ((rc = fast_pass2(e, d_plot, false, errbuf, errlen))) return rc;
-  HIPCHK(hipMemsetAsync(&e->ctrl->plot_sum, 0, sizeof(u64), e->stream));
-  hipLaunchKernelGGL(kf_plot_sum, dim3(64), dim3(1024), 0, e->stream, (const u64 *) d_plot, &e->ctrl->plot_sum);
-  HIPCHK(hipGetLastError());
-  if ((rc = read_ctrl(e, errbuf, errlen))) return rc;        // the ONE wait of the run
-  const FastCtl &f = e->h_ctrl->fast;
-  if (f.unsorted) return fail(errbuf, errlen, SMG_EFORMAT, "table entries are not strictly increasing%s");
-  if (f.n_chunks > e->max_chunks || (int64_t) f.nbig != e->spec_nbig || (int64_t) f.nreq != e->spec_nreq)
-    { e->dbits_dirty = true; return SMG_ERETRY; }
-  e->dbits_dirty = false;
-  memset(e->fp, 0, sizeof(e->fp));
-  for (unsigned b = 0; b < grid; b++)
-    for (int q = 0; q < 4; q++) e->fp[q] ^= e->h_partials[b * 4 + q];
-  if (f.missing != 0 || e->fp[0] != e->fp[2] || e->fp[1] != e->fp[3]) return SMG_ERETRY;    // (not closed any more: the plain way decides)
-  float ms = 0;
-  hipEventElapsedTime(&ms, e->ev[2], e->ev[3]); e->st.ms_pass1 = ms;
-  hipEventElapsedTime(&ms, e->ev[0], e->ev[3]); e->st.ms_bigfix = ms;
-  hipEventElapsedTime(&ms, e->ev[4], e->ev[5]); e->st.ms_rclookup = ms;
-  hipEventElapsedTime(&ms, e->ev[4], e->ev[10]); e->st.ms_filter = ms;        // scan + partition
-  hipEventElapsedTime(&ms, e->ev[6], e->ev[7]); e->st.ms_pass2 = ms;
-  e->st.nemitted = (int64_t) f.nreq;
-  e->st.nrequests = (int64_t) f.nf_req;
-  e->st.nbig = (int64_t) f.nbig;
-  e->st.npairs = (int64_t) e->h_ctrl->plot_sum;
-  e->st.path = 1;
-  return SMG_OK;
-}
-
 extern "C" int smg_engine_run(smg_engine *e, int symcheck, int64_t *d_plot, smg_stats *stats,
                               char *errbuf, size_t errlen)
 { if (!e || !d_plot) return fail(errbuf, errlen, SMG_EINVAL, "null argument%s");
@@ -2209,23 +2165,9 @@ extern "C" int smg_engine_run(smg_engine *e, int symcheck, int64_t *d_plot, smg_
       //        sharded protocol exchanges, index-sorted look-ups (kf_apply_indexed)
       const int exact = symcheck == SMG_SYM_EXACT;
       e->bm_cap = 32;
-      if (!exact && e->spec_ok && e->n > 0 && !getenv("SMG_NO_SPEC"))
-        { // the same table as last time: queue the whole run without reading anything back in between (round 3 read the
-          // control words three times per run and the plot's weight once: 0.7 ms of host round trips in a 19 ms step)
-          const int src = run_speculative(e, d_plot, errbuf, errlen);
-          if (src == SMG_OK)
-            { hipEventRecord(e->ev[9], e->stream);
-              HIPCHK(hipStreamSynchronize(e->stream));
-              float ms = 0; hipEventElapsedTime(&ms, e->ev[8], e->ev[9]);
-              e->st.ms_total = ms;
-              if (stats) *stats = e->st;
-              return SMG_OK;
-            }
-          if (src != SMG_ERETRY) return src;
-          e->spec_ok = false;                // (the counts moved -- not the table this engine ran last time: the plain way)
-          e->have_ends = false;              // (... which reads the table's first and last k-mer again)
-          e->st.ms_pass1 = e->st.ms_rclookup = e->st.ms_pass2 = 0;
-        }
+      // (Rounds 3-5 queued a re-run on the same table from the counts of the run before -- "run_speculative", one host wait
+      //  instead of four.  Measured twice without a gain, 17.94 against 17.7-18.0 ms per step, profiles/r05_lookup_experiments.txt:
+      //  taken out in round 6.  The one mechanism of that kind left is the replayed step of the phase API, for sharded runs.)
       rc = fast_pass1(e, exact, exact, symcheck == SMG_SYM_HASH, errbuf, errlen);
       if (rc) return rc;
       int64_t missing = 0;
@@ -2234,9 +2176,6 @@ extern "C" int smg_engine_run(smg_engine *e, int symcheck, int64_t *d_plot, smg_
       if (symmetric && symcheck == SMG_SYM_HASH)
         symmetric = e->fp[0] == e->fp[2] && e->fp[1] == e->fp[3];
       if (symmetric && (rc = fast_pass2(e, d_plot, true, errbuf, errlen))) return rc;
-      // what the next run on this table may take for granted (hash proof through the fused look-up chain only)
-      if (symmetric && !exact && e->lg.nb && e->fused_last && e->W <= 2 && !e->h_p1cold->times)
-        { e->spec_ok = true; e->spec_nreq = e->st.nemitted; e->spec_nbig = e->st.nbig; }
     }
   else if (symcheck != SMG_SYM_NONE)
     { if ((rc = counted_symmetric(e, symcheck, d_plot, &symmetric, errbuf, errlen))) return rc; }
@@ -2401,7 +2340,7 @@ extern "C" int smg_engine_condition(smg_engine *e, int ethresh, int do_trim, int
   e->n = n;
   e->prepared = false; e->counted_done = false;
   e->have_ixdir = false; e->dir_preset = false; e->have_ends = false;      // (another table now: its index and ends are gone)
-  e->spec_ok = false; e->rp_have = false; e->rp_active = false;
+  e->rp_have = false; e->rp_active = false;
   e->st.nels = n;
   e->st.ms_decode += ms;
   if (new_nels) *new_nels = n;
@@ -2630,7 +2569,7 @@ extern "C" int smg_engine_symm_route(smg_engine *e, const uint64_t *splitters, i
   hipLaunchKernelGGL(kc_fill_u32, dim3((unsigned) ((nc + TPB - 1) / TPB)), dim3(TPB), 0, e->stream, fill, nc, (uint32_t) F_CH,
                      (uint32_t) (n2 - (nc - 1) * F_CH));
   if (hipGetLastError() != hipSuccess) rc = fail(errbuf, errlen, SMG_ENODEV, "symm_route: launch failed%s");
-  if (rc == SMG_OK) rc = route_records(e, rec, fill, (unsigned) nc, rw, splitters, nranks, d_send, counts, errbuf, errlen);
+  if (rc == SMG_OK) rc = route_records(e, rec, fill, (unsigned) nc, rw, splitters, nranks, d_send, capacity, counts, errbuf, errlen);
   hipStreamSynchronize(e->stream);
   hipFree(rec); hipFree(fill);
   return rc;
@@ -2727,7 +2666,7 @@ extern "C" int smg_engine_symm_finish(smg_engine *e, const uint64_t *d_recv, int
     }
   e->n = kept;
   e->prepared = false; e->counted_done = false;
-  e->have_ixdir = false; e->dir_preset = false; e->have_ends = false; e->spec_ok = false;
+  e->have_ixdir = false; e->dir_preset = false; e->have_ends = false;
   e->st.nels = kept;
   if (new_nels) *new_nels = kept;
   return SMG_OK;

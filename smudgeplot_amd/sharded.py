@@ -61,7 +61,6 @@ class TorchEngine:
         # what the engine is bound to: hetmers_sharded(prebound=True) checks it (a run that failed the symmetry proof
         # leaves rank 0's engine on the GATHERED table, see _general_on_rank0) and binds again when it does not match
         self._bound = (keys.data_ptr(), counts.numel())
-        self._index = None
         if index is not None:
             # the engine reads 2^24 int64 words from this pointer: anything else is an out-of-bounds read on the device
             if not (index.dtype == torch.int64 and index.numel() == 1 << 24 and index.is_contiguous()
@@ -69,17 +68,15 @@ class TorchEngine:
                 raise ValueError("prefix index: need a contiguous int64 tensor of 2^24 words on the table's device "
                                  "(entries up to every 3-byte prefix, libfastk.c:841)")
             self.e.set_prefix_index(index.data_ptr(), 3, first_entry)
-            # (kept: the directory kernel runs on the ENGINE's stream, which need not be torch's current one, and a
-            #  re-bind after a fallback hands the index over again)
-            self._index = (index, first_entry, keys.data_ptr(), counts.numel())
+            # The engine turns the 2^24 int64 words into its own 32-bit directory by a kernel on ITS stream (which need not be
+            # torch's current one).  bind is set-up, not a step: wait for it here, so that the caller's 134 MB tensor is the
+            # caller's again when bind returns -- nothing of it is kept alive by this object (round 5 kept a reference).
+            torch.cuda.synchronize(self.device)
 
     def rebind(self, k, keys, counts):
-        """bind again, with the prefix index of the last bind if these are the tensors it was given for"""
-        ix = getattr(self, "_index", None)
-        if ix is not None and ix[2:] == (keys.data_ptr(), counts.numel()):
-            self.bind(k, keys, counts, index=ix[0], first_entry=ix[1])
-        else:
-            self.bind(k, keys, counts)
+        """bind again after the engine was left on another table (rank 0 after a failed symmetry proof).  The prefix index of the
+        first bind is not kept: the engine builds a directory of its own in pass 1, as for any table that comes without one."""
+        self.bind(k, keys, counts)
 
     def pass1(self, symcheck, exchange=True, world=1):
         # nobody to exchange block maps with: the finest map (32 id bits) costs nothing but its memset.  Exchanged maps:
@@ -452,7 +449,10 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
     can_replay = (exchange and symcheck == "hash" and hasattr(eng, "set_replay") and os.environ.get("SMG_REPLAY") == "1"
                   and not owned)
     if can_replay:
-        if rec is None or rec["key"] != rkey:
+        # A step is replayed by ALL ranks or by none: a replaying rank splits the exchange by its recorded counts, a plain one by
+        # this step's -- if the counts moved, the split sizes would disagree across the ranks, which RCCL answers with a hang, not
+        # with an error.  rec["all"] says that EVERY rank left the recorded step with a record (summed in that step's all_reduce).
+        if rec is None or rec["key"] != rkey or not rec["all"]:
             eng.set_replay(False)              # (no counts of ours to go with the engine's: drop its record too)
             rec = None
         eng.set_replay(True)
@@ -520,16 +520,17 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
     # the host.
     nslot = world if exchange else 1
     nproof = 3 + 2 * nslot
-    buf = _scratch(eng, "plot", PLOT_CELLS + nproof, dev)     # (pass 2 clears the plot itself; the proof words below)
+    # (+ 1 word behind the proof: how many ranks hold a record that the NEXT step could be replayed from)
+    buf = _scratch(eng, "plot", PLOT_CELLS + nproof + 1, dev)     # (pass 2 clears the plot itself; the proof words below)
     plot = buf[:PLOT_CELLS]
     eng.pass2(plot)
     me = rank if exchange else 0
     if missing is None and hasattr(eng, "proof_tail"):
         # the engine lays the whole tail out on the device, in stream order, in one launch: no host round trip between the
         # look-ups and the all_reduce (a replayed step's verdict on its counts and on the router's totals included)
-        eng.proof_tail(buf[PLOT_CELLS:], nslot, me)
+        eng.proof_tail(buf[PLOT_CELLS: PLOT_CELLS + nproof], nslot, me)
     elif missing is None:
-        buf[PLOT_CELLS:].zero_()
+        buf[PLOT_CELLS: PLOT_CELLS + nproof].zero_()
         # the engine writes (missing, residue word 0, residue word 1, replay verdict) on the device, in stream order: no host
         # round trip between the look-ups and the all_reduce.  Rank r's words go to [0] (summed) and to ITS slot.
         tmp = _scratch(eng, "proof", 4, dev)
@@ -541,16 +542,20 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
             buf[PLOT_CELLS + nproof - 2] = tmp[3] + (both != rec["both"]).any().to(torch.int64)
             buf[PLOT_CELLS + nproof - 1] = 1
     else:
-        buf[PLOT_CELLS:].zero_()
         fpw = eng.symhash()
         proof = np.zeros(nproof, dtype=np.uint64)
         proof[0] = missing
         proof[1 + 2 * me] = fpw[0] ^ fpw[2]
         proof[2 + 2 * me] = fpw[1] ^ fpw[3]
-        buf[PLOT_CELLS:] = torch.from_numpy(proof.view(np.int64).copy()).to(dev)
+        buf[PLOT_CELLS: PLOT_CELLS + nproof] = torch.from_numpy(proof.view(np.int64).copy()).to(dev)
+    # this rank's vote on replaying the next step: it holds a record (a replayed step keeps the one it ran from)
+    have_rec = bool(can_replay and both is not None and (replay or (eng.replay_state() & 2)))
+    buf[PLOT_CELLS + nproof:].fill_(1 if have_rec else 0)
     if exchange:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     pv = buf[PLOT_CELLS:].cpu().numpy().view(np.uint64)
+    all_have = int(pv[nproof]) == (world if exchange else 1)
+    pv = pv[:nproof]
     replay_bad, replayed = int(pv[nproof - 2]) != 0, int(pv[nproof - 1]) != 0       # (sums over the ranks: the same everywhere)
     symmetric = pv[0] == 0
     if symcheck == "hash":
@@ -558,6 +563,7 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
     if can_replay:
         if replay:
             eng.replay_done(not replay_bad and bool(symmetric))
+            rec["all"] = all_have
         if replay_bad or (not symmetric and replayed):
             # some rank ran from a record that no longer holds (or the table stopped being closed under a replayed step:
             # the plain path decides): forget the records and run the step again
@@ -565,8 +571,10 @@ def hetmers_sharded(k: int, keys: torch.Tensor, counts: torch.Tensor, symcheck: 
             eng.set_replay(False)
             return hetmers_sharded(k, keys, counts, symcheck=symcheck, engine_factory=engine_factory, group=group, eng=eng,
                                    fallback=fallback, splitters=splitters, prebound=True, sizes=sizes)
-        if symmetric and not replay and both is not None and (eng.replay_state() & 2):
-            eng._replay_rec = {"key": rkey, "send": send_counts, "recv": recv_counts, "both": both.clone()}
+        if symmetric and not replay and have_rec:
+            # (the receive counts are other ranks' send totals: every rank vouches for its own on the device, and the verdicts
+            #  are summed -- a replayed step in which ANY count moved is run again by all)
+            eng._replay_rec = {"key": rkey, "send": send_counts, "recv": recv_counts, "both": both.clone(), "all": all_have}
     if not symmetric:
         if not fallback:
             raise NotSymmetric("table is not closed under reverse complement with equal counts; "

@@ -13,7 +13,7 @@ from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 NEED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-        "dtype", "data", "config", "roofline", "cpu_baseline"}
+        "dtype", "data", "config", "roofline", "cpu_baseline", "e2e", "parity"}
 
 
 def _line(cmd, env=None):
@@ -31,9 +31,14 @@ def _line(cmd, env=None):
 def test_bench_default_launcher_small_table_with_cpu_baseline():
     j = _line([sys.executable, "bench.py", "--genome", "3e6", "--steps", "2", "--warmup", "1"])
     assert j["n_gpus"] == 1 and j["dtype"] == "u64" and j["steps"] == 2
-    assert j["roofline"]["kernel"].startswith("kf_pass")
+    assert j["roofline"]["kernel"] == "kf_pass1_d<1, 1, true, true, 2>"           # the name rocprofv3 prints for the hot form
     cb = j["cpu_baseline"]
     assert cb["kind"] == "reference" and cb["value"] > 0 and cb["cores"] >= 1 and "entry table" in cb["sample"]
+    # the end-to-end block: both programs ran in this bench process on the same files, byte-identical .smu
+    e = j["e2e"]
+    assert e["smu_identical"] is True and e["entries"] > 0 and e["hetmers_wall_s"] > 0 and e["reference_wall_s"] > 0
+    assert len(e["hetmers_runs_s"]) == 2 and e["cores"] == cb["cores"]
+    assert abs(cb["value"] - e["entries"] / e["reference_wall_s"]) < 0.02 * cb["value"]      # one and the same reference run
 
 
 def test_bench_under_torch_distributed_run_one_rank():
@@ -42,7 +47,7 @@ def test_bench_under_torch_distributed_run_one_rank():
         port = s.getsockname()[1]
     j = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                "--master-port", str(port), "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--genome", "3e6", "--no-cpu"])
-    assert j["n_gpus"] == 1 and j["cpu_baseline"] is None
+    assert j["n_gpus"] == 1 and j["cpu_baseline"] is None and j["e2e"] is None
 
 
 def test_bench_k51_and_the_forced_exchange_protocol():
@@ -53,6 +58,21 @@ def test_bench_k51_and_the_forced_exchange_protocol():
                env=dict(os.environ, SMG_FORCE_EXCHANGE="1"))
     j1 = _line([sys.executable, "bench.py", "--genome", "3e6", "--steps", "2", "--warmup", "1", "--no-cpu"])
     assert j1["pairs_in_plot"] == j2["pairs_in_plot"]
+
+
+def test_bench_fails_loudly_without_the_reference_binary(tmp_path):
+    """a fresh clone has no oracle/_ref (git-ignored): the line must not silently lose its baseline"""
+    import bench
+    ref = bench.REF_BIN
+    hidden = ref + ".hidden_by_test"
+    os.rename(ref, hidden)
+    try:
+        r = subprocess.run([sys.executable, "bench.py", "--genome", "3e6", "--steps", "1", "--warmup", "0"], cwd=ROOT,
+                           capture_output=True, text=True, timeout=600)
+    finally:
+        os.rename(hidden, ref)
+    assert r.returncode != 0 and "hetmers_ref is missing" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
 def test_bench_repeats_workload_reaches_the_rare_paths():
