@@ -275,13 +275,16 @@ int     smg_engine_proof(smg_engine *e, uint64_t *d_dst, char *errbuf, size_t er
    rank all residues), d_tail[1 + 2 nslots] = a replayed step found other counts, d_tail[2 + 2 nslots] = 1 if this step was a
    replayed one: 3 + 2 nslots words.                                                                                      */
 int     smg_engine_proof_tail(smg_engine *e, uint64_t *d_tail, int nslots, int slot, char *errbuf, size_t errlen);
-/* Replay of the phase calls (round 5; what smg_engine_run does for a single shard, for the sharded drivers).  With
+/* Replay of the phase calls (round 5) -- the ONE mechanism that queues a step without reading anything back in between
+   (smg_engine_run's own variant of it, "run_speculative", measured no gain in two rounds and was removed in round 6).  With
    set_replay(e, 1) a step pass1 -> [presort] -> filter -> route_device -> apply(missing = NULL) -> pass2 -> proof on a table
    whose PREVIOUS step went the same way (hash proof, k <= 64, look-up chain) is queued without a single read-back: the
    counts the host needs between the calls (requests emitted, deferred entries, requests kept) are last step's -- functions of
    the table and of the exchanged maps -- and the device compares them with this step's (and the per-destination totals of
    route_device with the recorded ones: the caller splits its exchange by those); a difference, an overflow or an order
-   violation is reported through smg_engine_proof as d_dst[3] != 0.  The caller reads the proof words
+   violation is reported through smg_engine_proof as d_dst[3] != 0 (route_device never writes past the capacity it was given: a
+   replayed step whose list outgrew the record drops the surplus and fails this check).  A group of ranks must replay a step
+   TOGETHER or not at all (sharded.py votes in the step's final all_reduce).  The caller reads the proof words
    (its one host wait of the step), tells the engine with replay_done(e, ok) -- ok = 0 drops the record -- and on a failure
    runs the step again, which then takes the plain path.  replay_state: bit 0 = the current step is a replayed one, bit 1 =
    a record exists.  Binding or conditioning a table drops the record.  No counterpart in the reference.                 */

@@ -51,7 +51,9 @@
 #ifndef L_BLIND_P
 #define L_BLIND_P 1                       // 0: read - or - store (A/B builds)
 #endif
-#if L_BLIND_P
+#ifdef L_ABL_NOSETP                       // ablation build (timing only, WRONG results): the look-ups without their flag stores
+#define SET_P(A, j) ((void) 0)
+#elif L_BLIND_P
 #define SET_P(A, j) ((A).code[j] = (uint8_t) CODE_P)
 #else
 #define SET_P(A, j) ((A).code[j] = (uint8_t) ((A).code[j] | CODE_P))

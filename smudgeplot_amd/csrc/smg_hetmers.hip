@@ -39,6 +39,20 @@
 #include "smg_pass1d.hpp"
 #include "smg_lookup.hpp"
 
+// The environment, in three classes (round 6: the product library no longer carries tuning switches):
+//   documented modes    getenv(): SMG_VIRTUAL_SHARDS, SMG_SEQUENTIAL_SHARDS, SMG_SHARD_LIMIT, SMG_HBM_LIMIT, SMG_FORCE_MULTI (smg_hetmers.h);
+//   test hooks          test_hook(): force, on a table of any size, a code path that the engine otherwise picks from the table's
+//                       size, k or counts (the 30-bit exchanged map, the one-bit map of k < 24, kl_probe_x, the unfiltered chain,
+//                       pass 1's own directory, ..) -- tests/test_gpu_parity.py drives every one of them against the oracle;
+//   tuning switches     tune_env(): variants that no table selects (A/B material) -- compiled in with -DSMG_TUNING only
+//                       (tools/build_r06.sh), NULL in the product library.
+static inline const char *test_hook(const char *name) { return getenv(name); }
+#ifdef SMG_TUNING
+static inline const char *tune_env(const char *name) { return getenv(name); }
+#else
+static inline const char *tune_env(const char *) { return NULL; }
+#endif
+
 #define WIN_LIM   32          // window blocks up to this many entries are walked linearly
 #define TPB       256
 
@@ -848,7 +862,7 @@ extern "C" int smg_engine_set_prefix_index(smg_engine *e, const int64_t *d_prefi
 { if (!e) return fail(errbuf, errlen, SMG_EINVAL, "null engine%s");
   if (ibyte < 1 || ibyte > 3 || !d_prefix_index) return fail(errbuf, errlen, SMG_EINVAL, "prefix index: ibyte must be 1, 2 or 3%s");
   e->have_ixdir = false;
-  if (ibyte != 3 || e->kmer < 12 || getenv("SMG_NO_INDEX_DIR")) return SMG_OK;     // (a coarser index is of no use as a directory)
+  if (ibyte != 3 || e->kmer < 12 || test_hook("SMG_NO_INDEX_DIR")) return SMG_OK;     // (a coarser index is of no use as a directory)
   HIPCHK(hipSetDevice(e->device));
   int rc = grow(&e->ixdir, &e->ixdir_cap, (int64_t) sizeof(uint32_t) * ((1ll << IXDIR_BITS) + 2), errbuf, errlen);
   if (rc) return rc;
@@ -886,7 +900,7 @@ static int dir_geometry(smg_engine *e, int per, char *errbuf, size_t errlen, boo
   if (e->n > 0) { first = e->end_first; last = e->end_last; }
   if (last < first) return fail(errbuf, errlen, SMG_EFORMAT, "table entries are not strictly increasing%s");
   int bits = 4;
-  { const char *v = getenv("SMG_DIR_PER"); if (v && atoi(v) >= 1) per = atoi(v); }       // tuning override
+  { const char *v = test_hook("SMG_DIR_PER"); if (v && atoi(v) >= 1) per = atoi(v); }       // tuning override
   while (bits < 30 && (1ll << (bits + 1)) <= e->n / per) bits++;
   const uint32_t hf = (uint32_t) (first >> 32), hl = (uint32_t) (last >> 32);
   int dsh = 0;
@@ -1133,13 +1147,13 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
   e->bm_bits = 0; e->bm2 = 0;
   e->filtered = false; e->presorted = 0;
   e->lg.nb = 0;
-  if (filter_ok(e) && !emit_all && !e->no_filter && !getenv("SMG_NO_FILTER"))
+  if (filter_ok(e) && !emit_all && !e->no_filter && !test_hook("SMG_NO_FILTER"))
     { const int nbits = bm_id_bits(e->kmer, e->bm_cap);
       // the look-up chain of smg_lookup.hpp: one-word k-mers, key-only records, a map of >= 12 id bits
-      const bool chain = nbits >= 12 && e->W <= 2 && e->rw == e->W && !getenv("SMG_OLD_LOOKUP");
+      const bool chain = nbits >= 12 && e->W <= 2 && e->rw == e->W && !tune_env("SMG_OLD_LOOKUP");
       // ... with the two-bit map (smg_fast.hpp) when the k-mer has bits below the id to hash (a function of k and the
       // environment alone: every shard of a table decides the same)
-      e->bm2 = (chain && e->kmer >= 24 && !getenv("SMG_ONE_BIT_MAP")) ? 1 : 0;
+      e->bm2 = (chain && e->kmer >= 24 && !test_hook("SMG_ONE_BIT_MAP")) ? 1 : 0;
       const int64_t bytes = (4 * (((1ll << nbits) + 31) >> 5) + 4 * D_BMW + 64) << e->bm2;
       if ((rc = grow(&e->bmap, &e->bmap_cap, bytes, errbuf, errlen))) return rc;
       HIPCHK(hipMemsetAsync(e->bmap, 0, (size_t) bytes, e->stream));
@@ -1151,7 +1165,7 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
       // the signatures cost pass 1 5 GB of stores and four instructions per entry.  SMG_SIG=0/1 overrides.
       if (chain && e->bm2 && nbits >= 32) e->use_sig = false;
     }
-  { const char *v = getenv("SMG_SIG"); if (v && e->W <= 2) e->use_sig = atoi(v) != 0; }
+  { const char *v = test_hook("SMG_SIG"); if (v && e->W <= 2) e->use_sig = atoi(v) != 0; }
   if (e->use_sig && (rc = grow(&e->sig, &e->sig_cap, 2 * pbytes, errbuf, errlen))) return rc;
   if (e->n > 0 && !e->dir_preset)
     HIPCHK(hipMemsetAsync(e->bstart, 0xFF, sizeof(uint32_t) * ((size_t) e->dir.nb + 2), e->stream));
@@ -1193,9 +1207,9 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
           if (he != hipSuccess || nb < 1) nb = 3;
           if (nb > 8) nb = 8;
           if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || cus < 1) cus = 256;
-          { const char *g = getenv("SMG_P1_WGS_PER_CU"); if (g && atoi(g) > 0) nb = atoi(g); }
+          { const char *g = tune_env("SMG_P1_WGS_PER_CU"); if (g && atoi(g) > 0) nb = atoi(g); }
           cached = (unsigned) (nb * cus);
-          if (getenv("SMG_DEBUG")) fprintf(stderr, "  [smg] kf_pass1_d<%d,%d>: %d workgroups per CU x %d CUs\n", e->W, e->rw, nb, cus);
+          if (tune_env("SMG_DEBUG")) fprintf(stderr, "  [smg] kf_pass1_d<%d,%d>: %d workgroups per CU x %d CUs\n", e->W, e->rw, nb, cus);
         }
       grid = cached;
     }
@@ -1254,15 +1268,18 @@ static int fast_pass1(smg_engine *e, int emit_all, int with_meta, int want_fp, c
           if ((rc = grow(&e->p1tick, &e->p1tick_cap, (int64_t) D_NCLS * D_TICKW * 4, errbuf, errlen))) return rc;
           HIPCHK(hipMemsetAsync(e->p1tick, 0, (size_t) D_NCLS * D_TICKW * 4, e->stream));
           e->h_p1cold->tick = e->p1tick;
-          if (getenv("SMG_P1_TIMES"))                                          // tuning: when did every workgroup start and end?
+          if (tune_env("SMG_P1_TIMES"))                                          // tuning: when did every workgroup start and end?
             { if ((rc = grow(&e->p1times, &e->p1times_cap, (int64_t) grid * 24, errbuf, errlen))) return rc;
               HIPCHK(hipMemsetAsync(e->p1times, 0, (size_t) grid * 24, e->stream));
               e->h_p1cold->times = e->p1times;
             }
           HIPCHK(hipMemcpyAsync(e->p1cold, e->h_p1cold, sizeof(P1Cold), hipMemcpyHostToDevice, e->stream));
-#define LAUNCH_R(W_, RW_, ODD_, KF_) do { if (hot.bstart == NULL && hot.sig == NULL && e->bm2 && hot.bmap != NULL && want_fp && !emit_all && e->lg.nb && (RW_) == (W_)) /* the hot form */ \
-            hipLaunchKernelGGL((kf_pass1_d<W_, RW_, ODD_, KF_, 2>), dim3(grid), dim3(D_TPB), 0, e->stream, hot, (const P1Cold *) e->p1cold); \
-          else hipLaunchKernelGGL((kf_pass1_d<W_, RW_, ODD_, KF_, 1>), dim3(grid), dim3(D_TPB), 0, e->stream, hot, (const P1Cold *) e->p1cold); } while (0)
+#define LAUNCH_R(W_, RW_, ODD_, KF_) do { bool hot_form = false; \
+          if constexpr ((RW_) == (W_))            /* (the hot form exists for key-only records: no dead instantiations) */ \
+            if (hot.bstart == NULL && hot.sig == NULL && e->bm2 && hot.bmap != NULL && want_fp && !emit_all && e->lg.nb) \
+              { hot_form = true; \
+                hipLaunchKernelGGL((kf_pass1_d<W_, W_, ODD_, KF_, 2>), dim3(grid), dim3(D_TPB), 0, e->stream, hot, (const P1Cold *) e->p1cold); } \
+          if (!hot_form) hipLaunchKernelGGL((kf_pass1_d<W_, RW_, ODD_, KF_, 1>), dim3(grid), dim3(D_TPB), 0, e->stream, hot, (const P1Cold *) e->p1cold); } while (0)
 #define LAUNCH_R2(RW_, ODD_) { if (kf) LAUNCH_R(1, RW_, ODD_, true); else LAUNCH_R(1, RW_, ODD_, false); }
           const bool kf = gr.pshift < 32 && gr.kshift < 32;          // 17 <= k <= 32
           if (e->W == 2 && e->rw == 2) { if (odd) LAUNCH_R(2, 2, true, false); else LAUNCH_R(2, 2, false, false); }
@@ -1396,19 +1413,19 @@ static int apply_sorted(smg_engine *e, const u64 *keys_in, int64_t nsort, int ho
   // (a short list -- what one rank of eight receives -- is looked up as it comes: the sort is eight launches, ~90 us, to put
   //  a few hundred thousand look-ups in order, which take 70 us either way)
   int64_t sort_min = 1 << 21;
-  { const char *v = getenv("SMG_APPLY_SORT_MIN"); if (v && atoll(v) >= SORT_MIN) sort_min = atoll(v); }
+  { const char *v = tune_env("SMG_APPLY_SORT_MIN"); if (v && atoll(v) >= SORT_MIN) sort_min = atoll(v); }
   if (nsort >= sort_min)
     { if ((rc = grow(&e->req2, &e->req2_cap, nsort * (int64_t) sizeof(u64), errbuf, errlen))) return rc;
       size_t tmp = 0;
       unsigned lobit = 40;                   // tuning knob: sort on bits [lobit, 64) of the k-mer
-      { const char *lb = getenv("SMG_SORT_LOBIT"); if (lb) lobit = (unsigned) atoi(lb); if (lobit > 56) lobit = 56; }
+      { const char *lb = tune_env("SMG_SORT_LOBIT"); if (lb) lobit = (unsigned) atoi(lb); if (lobit > 56) lobit = 56; }
       HIPCHK(rocprim::radix_sort_keys<smg_sort_config>(nullptr, tmp, (u64 *) keys_in, e->req2, (size_t) nsort,
                                                        lobit, 64u, e->stream));
       if ((rc = grow((char **) &e->sort_tmp, &e->sort_tmp_cap, (int64_t) tmp + 16, errbuf, errlen))) return rc;
       HIPCHK(rocprim::radix_sort_keys<smg_sort_config>(e->sort_tmp, tmp, (u64 *) keys_in, e->req2, (size_t) nsort,
                                                        lobit, 64u, e->stream));
       src = e->req2;
-      if (getenv("SMG_VERIFY_SORT"))
+      if (test_hook("SMG_VERIFY_SORT"))
         { u64 *d_chk = NULL, h[4];
           HIPCHK(hipMalloc(&d_chk, 32));
           HIPCHK(hipMemsetAsync(d_chk, 0, 32, e->stream));
@@ -1464,7 +1481,7 @@ static int apply_indexed(smg_engine *e, const u64 *rec, int64_t n, int check_cou
 // first 30 bits are LDS reads (smg_lookup.hpp) and a finer map only costs its memset; SMG_BM_BITS overrides (8..32).
 // An id never runs past the k-mer (2k bits) nor past its leading 32 bits.
 static int bm_id_bits(int kmer, int cap)
-{ { const char *v = getenv("SMG_BM_BITS"); if (v && atoi(v) >= 8 && atoi(v) <= 32) cap = atoi(v); }
+{ { const char *v = test_hook("SMG_BM_BITS"); if (v && atoi(v) >= 8 && atoi(v) <= 32) cap = atoi(v); }
   int nbits = cap > 30 ? 2 * kmer : 2 * (kmer / 2);
   if (nbits > cap) nbits = cap;
   return nbits;
@@ -1493,14 +1510,17 @@ static int filter_presort(smg_engine *e, char *errbuf, size_t errlen)
         hipLaunchKernelGGL(kl_part<2>, dim3(e->nown), dim3(PT_TPB), 0, e->stream, e->req, e->chunk_fill, e->nown,
                            (const unsigned *) e->whist, e->max_chunks, e->lg.nb, e->req2);
       HIPCHK(hipGetLastError());
+      if (tune_env("SMG_DEBUG"))               // (kl_part's time moves with where its lists lie: profiles/r06_kl_part_addresses.txt)
+        fprintf(stderr, "  [smg] kl_part<%d>: req %p (%lld MB) -> req2 %p (%lld MB), whist %p, %u owners, %u chunks\n", e->rw, (void *) e->req,
+                (long long) (e->req_cap >> 20), (void *) e->req2, (long long) (e->req2_cap >> 20), (void *) e->whist, e->nown, e->n_chunks);
       e->presorted = 3;
       return SMG_OK;
     }
   e->presorted = 2;
   const int64_t nslots = (int64_t) e->n_chunks * F_CH;
   int64_t sort_min = 1 << 22;               // below this the probes are too few to matter
-  { const char *v = getenv("SMG_FILTER_SORT_MIN"); if (v) sort_min = atoll(v); if (sort_min < SORT_MIN) sort_min = SORT_MIN; }
-  if (!(e->rw == 1 && nslots >= sort_min && e->kmer < 32) || getenv("SMG_FILTER_UNSORTED")) return SMG_OK;
+  { const char *v = test_hook("SMG_FILTER_SORT_MIN"); if (v) sort_min = atoll(v); if (sort_min < SORT_MIN) sort_min = SORT_MIN; }
+  if (!(e->rw == 1 && nslots >= sort_min && e->kmer < 32) || tune_env("SMG_FILTER_UNSORTED")) return SMG_OK;
   hipLaunchKernelGGL(kf_fill_holes, dim3(e->n_chunks), dim3(F_TPB), 0, e->stream, e->req, e->chunk_fill);
   if ((rc = grow(&e->req2, &e->req2_cap, nslots * (int64_t) sizeof(u64), errbuf, errlen))) return rc;
   size_t tmp = 0;
@@ -1527,7 +1547,7 @@ static int lookup_probe(smg_engine *e, const uint32_t *map, bool list, unsigned 
   // sixteen waves of a kl_probe workgroup wait for each other at every bucket, and it takes 4.5 ms against 2.9.  The
   // share of deferred entries that pass 1 reported tells the two kinds of table apart (0.13 % / 0.39 % in the two
   // bench workloads); SMG_PROBE_X=0/1 overrides.
-  { const char *px = getenv("SMG_PROBE_X");
+  { const char *px = test_hook("SMG_PROBE_X");
     // ... and so does the share of entries that sent a request: 17.5 % on the diploid tables, a third on the polyploid ones, where
     // one request in seven survives the filter (2.5e7 look-ups at 6.4e8 entries) and kl_probe_x is 7-8 % ahead as well
     const bool auto_x = (e->st.nbig > 0 && e->st.nbig * 400 > e->n) || e->st.nemitted * 100 > e->n * 28;
@@ -1539,9 +1559,9 @@ static int lookup_probe(smg_engine *e, const uint32_t *map, bool list, unsigned 
         // buckets in flight per XCD keep more of a bucket's k-mer lines in reach: -0.25 ms on the hexaploid table), 4096 where the
         // kernel is mostly streaming (a table with repeats: 1 request in 50 survives, and a ticket's fixed cost shows: +0.5 ms at 2048)
         unsigned xw = PX_WGS, part = e->st.nemitted * 100 > e->n * 28 ? PX_PART : 2 * PX_PART;   // (tuning: SMG_PX_WGS workgroups per CU, SMG_PX_PART requests per ticket)
-        { const char *v = getenv("SMG_PX_WGS"); if (v && atoi(v) > 0 && atoi(v) <= 8) xw = (unsigned) atoi(v);
-          v = getenv("SMG_PX_PART"); if (v && atoi(v) >= 512) part = (unsigned) atoi(v) & ~511u;
-          if (getenv("SMG_PX_ONE_XCC")) part |= 0x80000000u;                    // (tests: every workgroup claims XCD 0)
+        { const char *v = tune_env("SMG_PX_WGS"); if (v && atoi(v) > 0 && atoi(v) <= 8) xw = (unsigned) atoi(v);
+          v = tune_env("SMG_PX_PART"); if (v && atoi(v) >= 512) part = (unsigned) atoi(v) & ~511u;
+          if (test_hook("SMG_PX_ONE_XCC")) part |= 0x80000000u;                    // (tests: every workgroup claims XCD 0)
         }
         const unsigned xg = grid * xw;
 #define PROBEX(TWO_, RW_) hipLaunchKernelGGL((kl_probe_x<TWO_, RW_>), dim3(xg), dim3(PX_TPB), 0, e->stream, a, (const u64 *) e->req2, \
@@ -1577,7 +1597,7 @@ static int fast_filter(smg_engine *e, const uint32_t *map, char *errbuf, size_t 
   unsigned grid = 512;
   { int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) == hipSuccess && cus > 0) grid = 2u * (unsigned) cus;
-    const char *v = getenv("SMG_FILTER_GRID"); if (v && atoi(v) > 0) grid = (unsigned) atoi(v);
+    const char *v = tune_env("SMG_FILTER_GRID"); if (v && atoi(v) > 0) grid = (unsigned) atoi(v);
   }
   if (grid > e->n_chunks) grid = e->n_chunks;
   unsigned maxout = e->n_chunks + grid + 16;
@@ -1679,7 +1699,7 @@ static int compact_chunks(smg_engine *e, int64_t nreq, char *errbuf, size_t errl
 static int fast_apply(smg_engine *e, const u64 *flat, int64_t nflat, int check_count, int64_t *missing,
                       char *errbuf, size_t errlen)
 { int rc = SMG_OK;
-  if (!flat && e->lg.nb && e->bm_bits && !e->filtered && !getenv("SMG_LOOKUP_SPLIT"))
+  if (!flat && e->lg.nb && e->bm_bits && !e->filtered && !tune_env("SMG_LOOKUP_SPLIT"))
     { // own requests, own map: partition, then filter and look-ups in one kernel (no survivor list, no sort)
       if (e->n_chunks == 0 || e->st.nrequests == 0) { if (missing) *missing = 0; return SMG_OK; }
       if (!e->presorted && (rc = filter_presort(e, errbuf, errlen))) return rc;

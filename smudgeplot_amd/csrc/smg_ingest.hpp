@@ -125,7 +125,7 @@ static int ingest_records(const smg_table_source *src, int pbyte, int64_t lo, in
   int rc = SMG_OK, made = 0, evs = 0;
   hipEvent_t t0 = NULL, t1 = NULL;
   g.ncs = 1;
-  { const char *v = getenv("SMG_COPY_STREAMS"); if (v && atoi(v) >= 1 && atoi(v) <= 4) g.ncs = atoi(v); }      // (tuning)
+  { const char *v = tune_env("SMG_COPY_STREAMS"); if (v && atoi(v) >= 1 && atoi(v) <= 4) g.ncs = atoi(v); }      // (tuning)
   for (int i = 0; i < g.ncs && rc == SMG_OK; i++)
     if (hipStreamCreateWithFlags(&g.cstream[i], hipStreamNonBlocking) != hipSuccess)
       rc = fail(errbuf, errlen, SMG_ENODEV, "cannot create the copy stream%s");

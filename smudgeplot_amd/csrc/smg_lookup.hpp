@@ -42,6 +42,9 @@ static inline LookupGeo lookup_geo(int fb)
 { LookupGeo g;
   g.fb = fb; g.cb = fb - 2;
   g.nb = g.cb - L_SLICE_LG;
+#ifdef L_NB_FORCE                          // tuning build: another number of request buckets (kl_probe_x only: kl_probe's LDS slice assumes cb - nb <= 20)
+  g.nb = L_NB_FORCE;
+#endif
   if (g.nb < 1) g.nb = 1;
   if (g.nb > L_NB_MAX) g.nb = L_NB_MAX;
   return g;
@@ -56,6 +59,12 @@ template <int W> SMG_DEV void lookup_one(const FastArgs &A, const Key<W> &y, Fas
 {
 #ifdef L_ABL_NOLOOKUP                      // ablation build (timing only, WRONG results): what the probe kernels cost without their look-ups
   return;
+#endif
+#ifdef L_ABL_EXTRAROW                      // ablation build (timing only): one more random k-mer line per look-up -- what a survivor of
+  { const u64 h = (y.w[0] * 0x9E3779B97F4A7C15ull) >> 20;          // an 8-byte "requester's entry number" record would have to fetch
+    const Key<W> z = load_key<W>(A.keys, (int64_t) (h % (u64) A.n));
+    if (z.w[0] == 0x0123456789ABCDEFull) ctl->missing = 2;
+  }
 #endif
   const int64_t i = sig_find<W>(A, y, false);          // (no signatures bound: find_key_near, smg_device.hpp)
   if (i < 0) { if (ctl->missing == 0) ctl->missing = 1; return; }

@@ -40,6 +40,9 @@ struct RcclApi
 static bool rccl_load(RcclApi *a, char *errbuf, size_t errlen)
 { memset(a, 0, sizeof(*a));
   const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so" };
+  // an RCCL that the process has loaded already (a Python caller's torch brings its own) is the one to use: two copies of the
+  // library in one process take each other's state down at exit ("double free or corruption" after an otherwise clean run)
+  for (unsigned i = 0; i < 2 && !a->lib; i++) a->lib = dlopen(names[i], RTLD_NOW | RTLD_NOLOAD);
   for (unsigned i = 0; i < sizeof(names) / sizeof(names[0]) && !a->lib; i++) a->lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
   if (!a->lib) { fail(errbuf, errlen, SMG_ENODEV, "cannot load RCCL (librccl.so) for the multi-GPU run%s"); return false; }
 #define SYM(field, name) *(void **) (&a->field) = dlsym(a->lib, name); if (!a->field) { fail(errbuf, errlen, SMG_ENODEV, "RCCL symbol missing: %s", name); return false; }

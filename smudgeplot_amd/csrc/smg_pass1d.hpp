@@ -30,8 +30,8 @@
 // (Collecting the queued entries over several tiles and detecting 256 at a time from global memory was tried first:
 //  the passes -- 18 dependent-latency loads per entry -- cost 3.2 ms.)
 //
-// The fingerprint mixer is two dependent 32x32->64 multiply-adds (v_mad_u64_u32 is full rate on gfx950) and one
-// ChaCha quarter round: same avalanche as the three quarter rounds it replaces (tests/test_mixer.py), 21
+// The fingerprint mixer is two dependent 32x32->64 multiply-adds (v_mad_u64_u32 is full rate on gfx950) and half a
+// ChaCha quarter round: the avalanche of the three quarter rounds of round 1 to within +-0.03 (tests/test_mixer.py), 15
 // instead of 39 instructions.
 //
 // Semantics are those of kf_pass1_s / kf_pass1_r (smg_fast.hpp: code byte, request protocol), including the
@@ -82,6 +82,10 @@
 #endif                                     //   1 fingerprint, 2 directory, 4 signatures, 8 block map, 16 requests, 32 tail, 64 scan,
                                            //   512 tail detection passes, 4096/8192 the two barriers of a tile
 
+// (Round 6 swizzled the staged k-mers -- every other group of eight threads swapped the 16-byte halves of its 32 bytes, so that
+//  the sixteen lanes of an LDS cycle cover all 64 banks: the two-way conflicts of the 32-byte lane stride were 41 % of the
+//  LDS-active cycles in round 5.  Conflict-free, correct, and no faster: 11.14-11.17 against 11.08-11.10 ms,
+//  profiles/r06_pass1_experiments.txt -- the kernel does not wait for its LDS.  Taken out again.)
 template <int W> struct DWord;
 template <> struct DWord<1> { typedef unsigned type; };
 template <> struct DWord<2> { typedef u64 type; };
@@ -134,8 +138,8 @@ d_unpack(const Key<W> &x, const GeoR &G, typename DWord<W>::type &pre, typename 
     }
 }
 
-// 128-bit mixing of (k-mer, count): two dependent 32x32+64 multiply-adds, then one ChaCha quarter round over
-// (q, p ^ count).  Every input bit flips every output bit with probability 0.5 +- 0.01 (tests/test_mixer.py).
+// 128-bit mixing of (k-mer, count): two dependent 32x32+64 multiply-adds, then the first half of a ChaCha quarter round over
+// (q, p ^ count).  Every input bit flips every output bit with probability 0.5 +- 0.03 (tests/test_mixer.py).
 SMG_DEV u64 d_mad(unsigned a, unsigned b, u64 c) { return (u64) a * (u64) b + c; }       // v_mad_u64_u32
 
 template <int W> SMG_DEV void mix_hash(const Key<W> &x, unsigned cnt, u64 &ha, u64 &hb)
@@ -148,7 +152,10 @@ template <int W> SMG_DEV void mix_hash(const Key<W> &x, unsigned cnt, u64 &ha, u
   const unsigned pl = (unsigned) p, ph = (unsigned) (p >> 32);
   const u64 q = d_mad(pl ^ hi, ph ^ lo ^ 0xC2B2AE35u, p);
   unsigned a = (unsigned) q, b = (unsigned) (q >> 32), c = pl ^ cnt, d = ph;
-  arx_qr(a, b, c, d);
+  // the first half of a ChaCha quarter round (round 6; rounds 2-5 ran the whole one): every input bit still flips every output
+  // bit with probability 0.5 +- 0.03 (tests/test_mixer.py), six vector instructions less per entry: -0.3 ms on the bench table
+  a += b; d ^= a; d = __builtin_rotateleft32(d, 16);
+  c += d; b ^= c; b = __builtin_rotateleft32(b, 12);
   ha = (u64) a | ((u64) b << 32);
   hb = (u64) c | ((u64) d << 32);
 }

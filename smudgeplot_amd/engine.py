@@ -362,7 +362,8 @@ class Engine:
         return int(missing.value)
 
     def proof_into(self, dst_ptr: int):
-        """device uint64[3] at dst_ptr <- (missing complements, fingerprint residue words), in stream order"""
+        """device uint64[4] at dst_ptr <- (missing complements, fingerprint residue word 0, word 1, 1 if a replayed step did not
+        find the counts it was queued with), in stream order.  FOUR words since round 5: a caller's buffer must hold them."""
         _check(self.lib.smg_engine_proof(self.h, dst_ptr, self._buf, 512), self._buf)
 
     def proof_tail(self, tail_ptr: int, nslots: int, slot: int):

@@ -1173,16 +1173,16 @@ def _brute_cached(k, m, seed, packed, cnt):
     return _BRUTE[(k, m, seed)]
 
 
-@pytest.mark.parametrize("env", [{"SMG_ONE_BIT_MAP": "1"}, {"SMG_OLD_LOOKUP": "1"}, {"SMG_LOOKUP_SPLIT": "1"}, {"SMG_BM_BITS": "30"},
+@pytest.mark.parametrize("env", [{"SMG_ONE_BIT_MAP": "1"}, {"SMG_BM_BITS": "30"},
                                  {"SMG_SIG": "1"}, {"SMG_SIG": "0", "SMG_BM_BITS": "30"},
                                  {"SMG_BM_BITS": "24", "SMG_ONE_BIT_MAP": "1"}, {"SMG_DIR_PER": "8"}, {"SMG_DIR_PER": "200"},
                                  {"SMG_NO_FILTER": "1"}, {"SMG_PROBE_X": "1"}, {"SMG_PROBE_X": "1", "SMG_ONE_BIT_MAP": "1"},
-                                 {"SMG_PROBE_X": "1", "SMG_PX_PART": "512", "SMG_PX_WGS": "8"}, {"SMG_PROBE_X": "0"},
-                                 {"SMG_PROBE_X": "1", "SMG_PX_ONE_XCC": "1"}, {"SMG_NO_INDEX_DIR": "1"}])
+                                 {"SMG_PROBE_X": "0"}, {"SMG_PROBE_X": "1", "SMG_PX_ONE_XCC": "1"}, {"SMG_NO_INDEX_DIR": "1"}])
 @pytest.mark.parametrize("k,m,seed", [(31, 60000, 21), (27, 40000, 22), (24, 30000, 23)])
 def test_every_variant_of_the_lookup_chain_gives_the_same_plot(k, m, seed, env, monkeypatch):
-    """the A/B switches of the look-up chain: two-bit / one-bit map, round-1 chain, survivor list
-    instead of fused look-ups, map width, directory bucket size, no filter at all -- one answer"""
+    """the test hooks of the look-up chain (smg_hetmers.hip, test_hook): every form the engine picks from a table's size, k or
+    counts -- two-bit / one-bit map, the 30-bit map of an exchanging run, signatures, directory bucket size, pass 1's own
+    directory, no filter at all, either probe kernel -- forced on one small table: one answer"""
     packed, cnt = synth.adversarial_table(k, m, 4, seed, low_complexity=60, dense=1)
     tab = table_from(packed, cnt, k)
     base, st0 = engine.hetmers_run(tab, symcheck="hash")
@@ -1306,7 +1306,7 @@ def test_a_rerun_on_the_same_engine_takes_nothing_for_granted_that_it_does_not_c
     eng = sharded.TorchEngine(dev)
     eng.bind(k, tk, tc)
     want = brute.hetmers_plot(ktab.u64_to_packed(keys, k), cnt, k)
-    for _ in range(3):                                        # the second and third run are the speculative ones
+    for _ in range(3):                                        # an engine is reused: every run reads its own counts
         plot, st = sharded.hetmers_sharded(k, tk, tc, symcheck="hash", eng=eng, prebound=True)
         assert st["path"] == 1 and np.array_equal(plot.cpu().numpy().reshape(1001, 501), want)
     rc = ktab.revcomp_u64(keys, k)

@@ -45,9 +45,12 @@ for spec in sys.argv[2:]:
         e.bind(k, n, keys.data_ptr(), cnt.data_ptr())
         if "NOINDEX" not in envs: e.set_prefix_index(index.data_ptr(), 3, 0)
         res = []
-        for it in range(4):
+        for it in range(int(os.environ.get("AB_RUNS", "4"))):
             st = e.run(plot.data_ptr(), "hash")
             res.append(st)
+        if os.environ.get("AB_PER_RUN"):          # every run on its own line (is a time bimodal from run to run?)
+            for it, x in enumerate(res):
+                print(f"    run {it}: total {x['ms_total']:7.3f} p1 {x['ms_pass1']:6.3f} lookup {x['ms_rclookup']:6.3f} part {x['ms_filter']:5.3f} p2 {x['ms_pass2']:5.3f}", flush=True)
         torch.cuda.synchronize()
         r = res[1:]
         m = lambda key: sum(x[key] for x in r) / len(r)
