@@ -73,7 +73,9 @@
 #define D_RC_WIDE 1
 #endif
 #ifndef D_TAILB
-#define D_TAILB  8                         // tail: distances 4 .. D_TAILB + 3 come in batches of four LDS reads
+#define D_TAILB  6                         // tail: the next D_TAILB partners of a queued entry (distances 4 .. D_TAILB + 3) are read in one batch, the
+                                           //   (rare) rest one by one.  8 until round 6: 4 / 5 / 6 are 0.2-0.25 ms faster on the bench table (most queued
+                                           //   blocks end within two or three entries), 2 and 12 slower (profiles/r06_pass1_experiments.txt)
 #endif
 #define D_RD     3                         // distances tested register-to-register; the deferred tail starts at D_RD + 1 (a fourth
                                            //   distance in registers: ten vector registers spill, 16.4 instead of 14.7 ms)
@@ -658,45 +660,50 @@ d_tile(const P1Hot &A, const DShared &S, int64_t g0, int64_t g0_next, int t, u64
 // hm: bit d - (D_RD + 1) set for a pair with the entry d slots on; big: the entry 31 slots on still shares the prefix (block
 // beyond the window: both are redone by bisection, as every entry of such a block is in one of these two roles).
 // Partners come from the staged copy (global memory past its end: the last few slots of a tile).
+// The COUNTS are not looked at (round 6): a one-away partner whose count sum exceeds 1000 marks the two entries as well, and
+// kf_bigfix, which redoes a marked entry exactly, finds that it owns no such pair -- a superset costs a few entries of a table
+// with counts above 500 an exact redo, and every queued entry of every table seven LDS reads and a dozen instructions less.
 template <int W, bool ODD, bool KF> SMG_DEV void
 d_detect(const P1Hot &A, const u64 *ent, const uint16_t *lcn, int64_t g0, int sa, unsigned &hm, bool &big)
 { typedef typename DWord<W>::type WT;
   const GeoR &G = A.G;
   const int64_t n = A.n;
   hm = 0; big = false;
+  // (slots of the tile that lie inside the table, as a 32-bit number: one compare per partner instead of a 64-bit add and compare)
+  const int nrel = n - g0 < (int64_t) (1 << 30) ? (int) (n - g0) : (1 << 30);
   WT pa, sfa;
   d_unpack<W, KF>(lds_key<W>(ent, sa), G, pa, sfa);
-  const unsigned ca = lcn[sa];
+  (void) lcn;
   constexpr int D0 = D_RD + 1;                      // first distance the register scan did not cover
   int d = D0;
   if (sa + D0 + D_TAILB <= D_SLOTS)                 // distances D0 .. D0 + D_TAILB - 1 in one batch of LDS reads
-    { Key<W> kb[D_TAILB]; unsigned cb[D_TAILB];
+    { Key<W> kb[D_TAILB];
 #pragma unroll
-      for (int j = 0; j < D_TAILB; j++) { kb[j] = lds_key<W>(ent, sa + D0 + j); cb[j] = lcn[sa + D0 + j]; }
+      for (int j = 0; j < D_TAILB; j++) kb[j] = lds_key<W>(ent, sa + D0 + j);
       bool same = true;
 #pragma unroll
       for (int j = 0; j < D_TAILB; j++)
         { WT pb, sfb;
           d_unpack<W, KF>(kb[j], G, pb, sfb);
-          same = same && g0 + sa + D0 + j < n && pb == pa;
+          same = same && sa + D0 + j < nrel && pb == pa;
           const WT dd = sfa ^ sfb;
           const WT tt = ((dd << 1) | dd) & (WT) 0xAAAAAAAAAAAAAAAAull;
-          if (same && d_popc(tt) == 1 && ca + cb[j] <= SMG_SMAX) hm |= 1u << j;
+          if (same && d_popc(tt) == 1) hm |= 1u << j;
         }
       if (!same) return;
       d = D0 + D_TAILB;
     }
   for (; d <= D_WIN + 1; d++)
     { const int sb = sa + d;
-      if (g0 + sb >= n) break;
-      WT pb, sfb; unsigned cb;
-      if (sb < D_SLOTS) { d_unpack<W, KF>(lds_key<W>(ent, sb), G, pb, sfb); cb = lcn[sb]; }
-      else              { d_unpack<W, KF>(load_key<W>(A.keys, g0 + sb), G, pb, sfb); cb = A.cnt[g0 + sb]; }
+      if (sb >= nrel) break;
+      WT pb, sfb;
+      if (sb < D_SLOTS) d_unpack<W, KF>(lds_key<W>(ent, sb), G, pb, sfb);
+      else              d_unpack<W, KF>(load_key<W>(A.keys, g0 + sb), G, pb, sfb);
       if (pb != pa) break;
       if (d > D_WIN) { big = true; break; }
       const WT dd = sfa ^ sfb;
       const WT tt = ((dd << 1) | dd) & (WT) 0xAAAAAAAAAAAAAAAAull;
-      if (d_popc(tt) == 1 && ca + cb <= SMG_SMAX) hm |= 1u << (d - D0);
+      if (d_popc(tt) == 1) hm |= 1u << (d - D0);
     }
 }
 
