@@ -53,6 +53,24 @@ def test_rank_shards_are_the_table_of_one_rank(name, world):
     assert max(c.numel() for c in cs) < 1.25 * c0.numel() / world      # balanced (uniform random genome)
 
 
+@pytest.mark.parametrize("workload,k,G", [("uniform", 51, 30000), ("uniform", 31, 60000), ("hexaploid", 51, 15000)])
+def test_bench_make_table_is_one_table_whatever_the_number_of_ranks(workload, k, G):
+    """bench.make_table itself (not only the generators behind it): the shards that N ranks generate are, in rank order, the
+    table of N = 1 -- also for two-word k-mers of the uniform workload, where rounds 1-5 picked another generator at N = 1
+    than at N > 1 (advisor finding, round 5): one table_hash whatever the launch"""
+    import bench
+    dev = torch.device("cpu")
+    k0, c0, L0, _ = bench.make_table(workload, G, k, dev)
+    k0 = k0.reshape(c0.numel(), -1)
+    for world in (2, 4):
+        ks, cs = [], []
+        for r in range(world):
+            kr, cr, L, _ = bench.make_table(workload, G, k, dev, key_range=sd.key_range_of(r, world))
+            ks.append(kr.reshape(cr.numel(), -1)); cs.append(cr)
+            assert L == L0
+        assert torch.equal(torch.cat(ks), k0) and torch.equal(torch.cat(cs), c0)
+
+
 def test_table_hash_sees_every_change():
     k, c = sd.diploid_table(50000, k=31, device="cpu")
     h = sd.table_hash(k, c)
