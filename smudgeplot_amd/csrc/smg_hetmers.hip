@@ -616,7 +616,6 @@ struct smg_engine
   u64         *p1times; int64_t p1times_cap;    // SMG_P1_TIMES
   unsigned    *p1tick;  int64_t p1tick_cap;     // tile tickets of kf_pass1_d
   unsigned    *xtick;   int64_t xtick_cap;      // (bucket, part) tickets of kl_probe_x, one counter per XCD
-  uint32_t    *cmapg;   int64_t cmapg_cap;      // (tuning builds) the candidate map folded 4:1 by kl_coarse
   uint32_t    *farp;    int64_t farp_cap;       // beside it: the partner of a listed entry whose code is CODE_FAR (kf_bigfix -> kf_pass2_far)
   int          rw;                           // 64-bit words per request record
   uint32_t    *chunk_fill; int64_t chunk_cap; // bytes
@@ -723,7 +722,7 @@ extern "C" void smg_engine_destroy(smg_engine *e)
   hipSetDevice(e->device);
   hipStreamSynchronize(e->stream);
   hipFree(e->own_keys); hipFree(e->own_cnt); hipFree(e->deg); hipFree(e->sig); hipFree(e->bstart); hipFree(e->ixdir);
-  hipFree(e->req); hipFree(e->req2); hipFree(e->sort_tmp); hipFree(e->dense); hipFree(e->chunk_off); hipFree(e->skey[0]); hipFree(e->skey[1]); hipFree(e->sidx[0]); hipFree(e->sidx[1]); hipFree(e->dbits); hipFree(e->biglist); hipFree(e->farp); hipFree(e->p1times); hipFree(e->p1tick); hipFree(e->xtick); hipFree(e->cmapg); hipFree(e->chunk_fill); hipFree(e->bmap); hipFree(e->reqf); hipFree(e->chunk_fillf); hipFree(e->route_cnt); hipFree(e->route_off);
+  hipFree(e->req); hipFree(e->req2); hipFree(e->sort_tmp); hipFree(e->dense); hipFree(e->chunk_off); hipFree(e->skey[0]); hipFree(e->skey[1]); hipFree(e->sidx[0]); hipFree(e->sidx[1]); hipFree(e->dbits); hipFree(e->biglist); hipFree(e->farp); hipFree(e->p1times); hipFree(e->p1tick); hipFree(e->xtick); hipFree(e->chunk_fill); hipFree(e->bmap); hipFree(e->reqf); hipFree(e->chunk_fillf); hipFree(e->route_cnt); hipFree(e->route_off);
   hipFree(e->partials); hipFree(e->ctrl); hipFree(e->d_split); hipFree(e->p1cold); hipFree(e->ghist); hipFree(e->boff);
   hipFree(e->whist); hipFree(e->rp_totals);
   hipHostFree(e->h_ctrl); hipHostFree(e->h_partials); hipHostFree(e->h_p1cold);
@@ -1574,29 +1573,9 @@ static int lookup_probe(smg_engine *e, const uint32_t *map, bool list, unsigned 
         return SMG_OK;
       }
   }
-  // (tuning builds: SMG_PB_SHARE workgroups of an XCD share a bucket, SMG_PB_COARSE folds the map once in a kernel of its own)
-  unsigned nshare = 0;
-  const uint32_t *coarse = NULL;
-  { const char *v = tune_env("SMG_PB_SHARE"); if (v && !list && e->lg.nb >= 3) nshare = (unsigned) atoi(v);
-    v = tune_env("SMG_PB_COARSE");
-    if (v && atoi(v) && e->lg.cb - e->lg.nb >= 7)
-      { int rc2;
-        const size_t ncoarse = (size_t) 1 << (e->lg.cb - 5);
-        if ((rc2 = grow(&e->cmapg, &e->cmapg_cap, (int64_t) ncoarse * 4, errbuf, errlen))) return rc2;
-        if (two) hipLaunchKernelGGL(kl_coarse<true>, dim3(4096), dim3(256), 0, e->stream, map, ncoarse, e->cmapg);
-        else     hipLaunchKernelGGL(kl_coarse<false>, dim3(4096), dim3(256), 0, e->stream, map, ncoarse, e->cmapg);
-        coarse = e->cmapg;
-      }
-  }
-  if (nshare)
-    { int rc2;
-      const int64_t words = (int64_t) PX_NXCD * PX_TICKW + L_BK;
-      if ((rc2 = grow(&e->xtick, &e->xtick_cap, words * 4, errbuf, errlen))) return rc2;
-      HIPCHK(hipMemsetAsync(e->xtick, 0, (size_t) words * 4, e->stream));
-    }
-  else if (grid > nbk) grid = nbk;
+  if (grid > nbk) grid = nbk;
 #define PROBE(LIST_, TWO_, RW_, OUT_, FILL_, MAX_) hipLaunchKernelGGL((kl_probe<LIST_, TWO_, RW_>), dim3(grid), dim3(PB_TPB), 0, e->stream, a, \
-                       (const u64 *) e->req2, (const u64 *) e->boff, map, e->lg, e->ghist + L_BK, OUT_, FILL_, MAX_, &e->ctrl->fast, nshare, e->xtick, coarse)
+                       (const u64 *) e->req2, (const u64 *) e->boff, map, e->lg, e->ghist + L_BK, OUT_, FILL_, MAX_, &e->ctrl->fast)
 #define PROBE_RW(LIST_, TWO_, OUT_, FILL_, MAX_) { if (e->rw == 1) PROBE(LIST_, TWO_, 1, OUT_, FILL_, MAX_); else PROBE(LIST_, TWO_, 2, OUT_, FILL_, MAX_); }
   if (list) { if (two) PROBE_RW(true, true, e->reqf, e->chunk_fillf, maxout) else PROBE_RW(true, false, e->reqf, e->chunk_fillf, maxout) }
   else      { if (two) PROBE_RW(false, true, (u64 *) NULL, (uint32_t *) NULL, 0u) else PROBE_RW(false, false, (u64 *) NULL, (uint32_t *) NULL, 0u) }

@@ -292,30 +292,6 @@ SMG_DEV unsigned pb_fold(unsigned f)
   return (c | (c >> 12)) & 0xFFu;
 }
 
-// PB_SHARE (round 6, tuning builds only -- see profiles/r06_lookup_experiments.txt).  With a bucket per workgroup the 256 buckets
-// in flight probe 256 MB of map at random: every request that passes the coarse LDS test costs a 128-byte line for its 8-byte map
-// word.  With nshare > 0, nshare workgroups OF ONE XCD work on the same bucket at the same time, a part of its requests each, so
-// an XCD has 32 / nshare buckets of map slices in flight -- its L2 at nshare = 8.  Buckets b = x (mod 8) belong to XCD x
-// (HW_REG_XCC_ID, as in kl_probe_x); its workgroups walk them in groups and CLAIM shares with one atomic per bucket: every share
-// of every bucket is claimed exactly once whatever the dispatcher and the partition mode do.
-#define PX_NXCD  8                        // XCDs of the device (a device that shows fewer XCC ids still does every bucket)
-#define PX_TICKW 32                       // words between two per-XCD counters
-
-// the whole map folded 4:1, once: coarse word w = the fold of the id words 4 w .. 4 w + 3 (what kl_probe keeps of a bucket in LDS)
-template <bool TWO> __global__ void __launch_bounds__(256)
-kl_coarse(const uint32_t *__restrict__ fmap, size_t ncoarse, uint32_t *__restrict__ coarse)
-{ for (size_t cw = (size_t) blockIdx.x * 256 + threadIdx.x; cw < ncoarse; cw += (size_t) gridDim.x * 256)
-    { if (TWO)
-        { const uint4 f0 = *reinterpret_cast<const uint4 *>(fmap + 8 * cw), f1 = *reinterpret_cast<const uint4 *>(fmap + 8 * cw + 4);
-          coarse[cw] = pb_fold(f0.x) | (pb_fold(f0.z) << 8) | (pb_fold(f1.x) << 16) | (pb_fold(f1.z) << 24);
-        }
-      else
-        { const uint4 f = *reinterpret_cast<const uint4 *>(fmap + 4 * cw);
-          coarse[cw] = pb_fold(f.x) | (pb_fold(f.y) << 8) | (pb_fold(f.z) << 16) | (pb_fold(f.w) << 24);
-        }
-    }
-}
-
 // LIST = false: look the survivors up and set their P flags.  LIST = true: append them to the chunk list `out`
 // (every wave fills chunks of its own).
 // RW = words per record: the filter reads the first one; the survivors' queue holds the k-mer itself (RW = 1) or the
@@ -323,12 +299,10 @@ kl_coarse(const uint32_t *__restrict__ fmap, size_t ncoarse, uint32_t *__restric
 template <bool LIST, bool TWO, int RW> __global__ void __launch_bounds__(PB_TPB)
 kl_probe(FastArgs A, const u64 *__restrict__ recs, const u64 *__restrict__ boff, const uint32_t *__restrict__ fmap,
          LookupGeo g, unsigned *__restrict__ bnext, u64 *__restrict__ out, uint32_t *__restrict__ out_fill,
-         unsigned max_out, FastCtl *__restrict__ ctl, unsigned nshare /* 0: a bucket per workgroup; else see PB_SHARE */,
-         unsigned *__restrict__ xwork /* nshare > 0: ranks per XCD [PX_NXCD * PX_TICKW], shares claimed per bucket [L_BK] behind them */,
-         const uint32_t *__restrict__ coarse /* the map folded 4:1 by kl_coarse, or NULL: fold the bucket's slice here */)
+         unsigned max_out, FastCtl *__restrict__ ctl)
 { __shared__ unsigned cmap[PB_SLICEW];
   __shared__ u64      wq[PB_WAVES][PB_WQ];
-  __shared__ unsigned s_b, s_sh;
+  __shared__ unsigned s_b;
   const int t = threadIdx.x, lane = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
   const int nbk = 1 << g.nb;
@@ -370,69 +344,15 @@ kl_probe(FastArgs A, const u64 *__restrict__ recs, const u64 *__restrict__ boff,
     qn -= take; kept += take;
   };
 
-  // Which bucket next, and which part of it.  nshare == 0 (round 2): a whole bucket per workgroup, from one counter.
-  // nshare > 0 (round 6, PB_SHARE): wave 0 walks the buckets of the workgroup's XCD (then the others') and claims a share.
-  unsigned xcls = 0, xj0 = 0, xstep = 0, xfruitless = 0;     // walk state (wave 0): class, first position, steps taken, buckets passed since the last claim
-  const unsigned per_cls = (unsigned) nbk / PX_NXCD;         // buckets b = j * PX_NXCD + class, j < per_cls   (nb >= 3)
-  unsigned *claim = xwork + PX_NXCD * PX_TICKW;
-  if (nshare && wv == 0)
-    { unsigned xcc, rank = 0;
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-      xcls = xcc & (PX_NXCD - 1);
-      if (lane == 0) rank = atomicAdd(&xwork[xcls * PX_TICKW], 1u);        // this workgroup's rank among those of its XCD
-      rank = (unsigned) __builtin_amdgcn_readfirstlane((int) rank);
-      // the workgroups of an XCD walk its buckets in groups of nshare: group rank / nshare starts a (1 / groups)-th of the way in
-      unsigned groups = (gridDim.x / PX_NXCD + nshare - 1) / nshare;
-      if (groups < 1) groups = 1;
-      xj0 = (unsigned) (((u64) ((rank / nshare) % groups) * per_cls) / groups);
-    }
   for (;;)
-    { unsigned b = 0, share = 0;
-      __syncthreads();                                      // (everybody is done with the bucket before: cmap, s_b)
-      if (!nshare)
-        { if (t == 0) s_b = atomicAdd(bnext, 1u); }
-      else if (wv == 0)
-        { // the next bucket on the walk that still has a share to give: 64 candidates per look, one claiming atomic
-          unsigned fb = 0xFFFFFFFFu, fs = 0;
-          while (xfruitless < (unsigned) nbk + 64u)        // (a whole round over every class without a claim: all shares are taken)
-            { const unsigned left = per_cls - xstep, look = left < 64u ? left : 64u;
-              const unsigned bb = ((xj0 + xstep + (unsigned) lane) % per_cls) * PX_NXCD + xcls;
-              const bool open = (unsigned) lane < look && boff[bb] != boff[bb + 1] && __builtin_nontemporal_load(&claim[bb]) < nshare;
-              const u64 m = __ballot(open);
-              unsigned adv = look;
-              if (m)
-                { const unsigned first = (unsigned) __ffsll((long long) m) - 1u;
-                  const unsigned bsel = (unsigned) __shfl((int) bb, (int) first, 64);
-                  unsigned sh = 0;
-                  if (lane == 0) sh = atomicAdd(&claim[bsel], 1u);
-                  sh = (unsigned) __builtin_amdgcn_readfirstlane((int) sh);
-                  adv = first + 1u;                          // on to the bucket behind it either way (its other shares are its group's)
-                  if (sh < nshare) { fb = bsel; fs = sh; xfruitless = 0; }
-                }
-              xstep += adv;
-              if (fb == 0xFFFFFFFFu) xfruitless += adv;
-              if (xstep >= per_cls) { xcls = (xcls + 1u) & (PX_NXCD - 1); xstep = 0; xj0 = 0; }      // the next class (the tail is shared)
-              if (fb != 0xFFFFFFFFu) break;
-            }
-          if (lane == 0) { s_b = fb; s_sh = fs; }
-        }
+    { __syncthreads();
+      if (t == 0) s_b = atomicAdd(bnext, 1u);
       __syncthreads();
-      b = s_b; share = nshare ? s_sh : 0u;
+      const unsigned b = s_b;
       if (b >= (unsigned) nbk) break;
-      u64 r0 = boff[b], r1 = boff[b + 1];
+      const u64 r0 = boff[b], r1 = boff[b + 1];
       if (r0 == r1) continue;
-      if (nshare)                                           // this workgroup's share of the bucket's requests (whole 64-record rows)
-        { const u64 rows = (r1 - r0 + 63) >> 6, ra = r0 + ((rows * share / nshare) << 6), rz = r0 + ((rows * (share + 1) / nshare) << 6);
-          r0 = ra; r1 = rz < r1 ? rz : r1;
-          if (r0 >= r1) continue;
-        }
       // the bucket's part of the map, folded 4:1 into LDS  (fb >= 12: at least 2^9 coarse bits per bucket)
-      if (coarse)                                 // folded once for all by kl_coarse: the bucket's 128 KB (or less) as they are
-        { const uint4 *cs = reinterpret_cast<const uint4 *>(coarse + ((size_t) b << (slice_lg - 5)));
-          if (ncw >= 4) { for (unsigned c4 = t; c4 < ncw / 4; c4 += PB_TPB) reinterpret_cast<uint4 *>(cmap)[c4] = cs[c4]; }
-          else for (unsigned cw = t; cw < ncw; cw += PB_TPB) cmap[cw] = coarse[((size_t) b << (slice_lg - 5)) + cw];
-        }
-      else
       { const uint32_t *fw = fmap + (((size_t) b << (g.fb - g.nb - 5)) << (TWO ? 1 : 0));
         for (unsigned cw = t; cw < ncw; cw += PB_TPB)
           { if (TWO)                                  // 64-bit map words: the first bits are the even 32-bit words
@@ -452,9 +372,7 @@ kl_probe(FastArgs A, const u64 *__restrict__ recs, const u64 *__restrict__ boff,
           for (int j = 0; j < PB_PER; j++)
             { const u64 i = i0 + (u64) j * 64 + lane;
               keep[j] = i < r1;
-              // (one-word records are touched once: non-temporal, they must not push the XCD's map slices out of its L2;
-              //  two-word ones are read again by the survivors' drain)
-              y[j] = keep[j] ? (RW == 1 ? __builtin_nontemporal_load(recs + i) : recs[i * RW]) : 0ull;
+              y[j] = keep[j] ? recs[i * RW] : 0ull;
             }
 #pragma unroll
           for (int j = 0; j < PB_PER; j++)
@@ -507,6 +425,8 @@ kl_probe(FastArgs A, const u64 *__restrict__ recs, const u64 *__restrict__ boff,
 #define PX_PART  2048                     // requests per ticket on a table with many survivors (~0.6 buckets in flight per XCD; lookup_probe doubles it elsewhere)
 #define PX_WGS   4
 #define PX_PER   8                        // requests per lane and step
+#define PX_NXCD  8
+#define PX_TICKW 32                       // words between two XCD counters
 
 template <bool TWO, int RW> __global__ void __launch_bounds__(PX_TPB)
 kl_probe_x(FastArgs A, const u64 *__restrict__ recs, const u64 *__restrict__ boff, const uint32_t *__restrict__ fmap,
