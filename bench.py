@@ -140,6 +140,14 @@ def make_shard(workload: str, G: int, k: int, dev, rank: int, world: int, with_i
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 
+def golden_key(workload: str, G: int, k: int) -> str:
+    """name of a bench table in tests/golden/bench_tables.json: the workload at its default size and k, or
+    <workload>_k<k>_<genome>Mbp for the other lines that are kept under profiles/ (k = 30, k = 51 diploid)"""
+    if int(G) == default_genome(workload) and int(k) == default_k(workload):
+        return workload
+    return "%s_k%d_%dMbp" % (workload, int(k), int(G) // 10 ** 6)
+
+
 def parity_against_golden(workload: str, G: int, k: int, n_total: int, hk: int, hc: int, plot) -> dict:
     """Compare the plot of the last timed step with what the REFERENCE binary (PloidyPlot.c, compiled from the reference's
     own sources) wrote for this very table: tests/golden/bench_<workload>.smu, made on the GPU box by
@@ -154,9 +162,9 @@ def parity_against_golden(workload: str, G: int, k: int, n_total: int, hk: int, 
         out["reason"] = "tests/golden/bench_tables.json is missing"
         return out
     with open(tj) as f:
-        g = json.load(f).get(workload)
+        g = json.load(f).get(golden_key(workload, G, k))
     if not g or int(g["genome"]) != int(G) or int(g["k"]) != int(k):
-        out["reason"] = "no golden for this workload at this size (the goldens are the default sizes)"
+        out["reason"] = "no golden for this workload at this size and k (tests/golden/bench_tables.json lists the ones there are)"
         return out
     smu = engine.smu_text(plot.cpu().numpy().reshape(engine.PLOT_ROWS, engine.PLOT_COLS))
     out["smu_sha256"] = hashlib.sha256(smu.encode()).hexdigest()

@@ -233,7 +233,8 @@ int smg_engine_run(smg_engine *e, int symcheck, int64_t *d_plot, smg_stats *stat
 
 /* (smg_hetmers_run / _run_source on a table that does not fit the device run it OUT OF CORE, prefix shards one after the other
    with the table read twice: there symcheck = SMG_SYM_NONE is taken as SMG_SYM_HASH -- the shards cannot help each other on a
-   table that is not closed, which is refused with SMG_ENOTSYM and the advice to condition it first.)                    */
+   table that is not closed, which is refused with SMG_ENOTSYM and the advice to condition it first.  A table that opts->condition
+   asks to be trimmed / symmetrised is conditioned out of core as well: its closed prefix shards are parked in host memory.)  */
 
 /* ---- sharded (one process per GPU) phase calls ------------------------------------------
    The table is split by k-mer PREFIX: rank r owns the entries in [splitter[r-1], splitter[r]).

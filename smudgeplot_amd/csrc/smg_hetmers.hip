@@ -2793,15 +2793,19 @@ static int host_run(const smg_table_source *tv, const smg_opts *opts, int64_t *p
             if (limit <= 0 && hipSetDevice(device) == hipSuccess && hipMemGetInfo(&fr, &tot) == hipSuccess) limit = 0.9 * (double) fr;
             // what a run in core takes per entry: k-mers 8 W, count 2, code byte 1, deferred-entry map and lists 0.6, the request
             // list (a quarter of the entries + slack) and its partitioned copy ~2.6 W -- and the candidate map (1 GiB at most)
-            const double all = (double) tv->nels * (10.6 * W + 5.5) + 1.1e9;
-            // (conditioning only exists in core: such a run is tried there, and says so itself if it cannot be held)
-            if (limit > 0 && all > limit && !(opts && opts->condition))
+            // (a raw table: the size of the CLOSED table counts -- at most twice the entries -- and conditioning a shard takes
+            //  more than running it: its records (2 (W + 1) words per entry of the piece), the sort's copies and scratch)
+            const bool raw = opts && opts->condition, want_symm = opts && (opts->condition & SMG_COND_SYMM);
+            const double ne = (double) tv->nels * (want_symm ? 2.0 : 1.0);
+            const double per_run = 10.6 * W + 5.5, per_cond = raw ? (want_symm ? 24.0 * W + 30.0 : 8.0 * W + 12.0) : 0.0;
+            const double all = ne * (per_run > per_cond ? per_run : per_cond) + 1.1e9;
+            if (limit > 0 && all > limit)
               { // what a shard leaves behind: its code bytes and its requests -- every entry's (W + 1 words) under the exact
                 // proof, those of the owners of a pair at p > k-1-p otherwise (17 % of a diploid table, 36 % of a polyploid one)
                 const bool exact = symcheck == SMG_SYM_EXACT;
-                const double keep = (double) tv->nels * (1.0 + (exact ? 8.0 * (W + 1) : 0.36 * 8.0 * W));
+                const double keep = ne * (1.0 + (exact ? 8.0 * (W + 1) : 0.36 * 8.0 * W));
                 for (int q = 2; q <= SMG_MAXGPU && !seq; q++)
-                  if (keep + (double) tv->nels / q * (10.6 * W + 5.5) <= limit && tv->nels / q < 0xFFFFFFF0ll - 16) seq = q;     // (no map out of core)
+                  if (keep + ne / q * per_run <= limit && ne / q * per_cond <= limit && ne / q < 0xFFFFFFF0ll - 16) seq = q;     // (no map out of core)
                 if (!seq)
                   return fail(errbuf, errlen, SMG_ENOMEM, "the table does not fit the device even shard by shard (16 shards, a code byte and "
                               "the requests of every entry resident): use SMUDGEPLOT_GPUS%s");

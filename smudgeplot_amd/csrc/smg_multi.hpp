@@ -43,7 +43,9 @@ static bool rccl_load(RcclApi *a, char *errbuf, size_t errlen)
   // an RCCL that the process has loaded already (a Python caller's torch brings its own) is the one to use: two copies of the
   // library in one process take each other's state down at exit ("double free or corruption" after an otherwise clean run)
   for (unsigned i = 0; i < 2 && !a->lib; i++) a->lib = dlopen(names[i], RTLD_NOW | RTLD_NOLOAD);
-  for (unsigned i = 0; i < sizeof(names) / sizeof(names[0]) && !a->lib; i++) a->lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+  // (RTLD_LOCAL: this copy's symbols are reached through dlsym alone -- with RTLD_GLOBAL a torch that loads ITS librccl later
+  //  binds part of it to this one)
+  for (unsigned i = 0; i < sizeof(names) / sizeof(names[0]) && !a->lib; i++) a->lib = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
   if (!a->lib) { fail(errbuf, errlen, SMG_ENODEV, "cannot load RCCL (librccl.so) for the multi-GPU run%s"); return false; }
 #define SYM(field, name) *(void **) (&a->field) = dlsym(a->lib, name); if (!a->field) { fail(errbuf, errlen, SMG_ENODEV, "RCCL symbol missing: %s", name); return false; }
   SYM(CommInitAll, "ncclCommInitAll") SYM(CommDestroy, "ncclCommDestroy") SYM(GroupStart, "ncclGroupStart")
@@ -455,18 +457,129 @@ static void multi_cuts(const smg_table_source *tv, int n, int64_t *cut)
 // Symmetry proof as everywhere: XOR of the shards' fingerprints, no look-up may miss.  A table that fails it, a table that
 // still has to be conditioned and k > 85 are refused with a precise message (condition the table with smg_condition first).
 // The extract leg runs per shard in round 2 (the two members of a pair share a shard).
+// A RAW table out of core (round 6): Logex 'A[e-]' + Symmex (PloidyPlot.c:1381-1414) shard by shard.  The conditioned table
+// never exists on the device as a whole -- and not on disk either (the reference writes .trim / .symx tables into the working
+// directory): its prefix shards are left in HOST memory (8 W + 2 bytes per entry), from where the two rounds of the run
+// below take them instead of reading and decoding part files.
+//   sweep 1  every piece of the input: read + decode, trim, histogram of the entries AND their complements per leading 12 bits
+//            -> splitters that cut the CLOSED table into n shards of equal size (the rule of the in-core protocol, host_run_multi);
+//   sweep 2  every piece again: trim, one record per entry and per complement grouped by destination shard (symm_route),
+//            copied out to the destination's list on the host (2 (W + 1) words per kept entry, for the length of this sweep);
+//   then     every destination: its records back to the device, sort + dedupe (symm_finish), the shard's k-mers and counts
+//            out to the host.
+// Trim only: one sweep, the pieces are the shards.
+struct HostShard { std::vector<u64> keys; std::vector<uint16_t> cnt; int64_t n = 0; };
+
+static int host_condition_sequential(const smg_table_source *tv, const smg_opts *opts, int n, smg_engine *e, const int64_t *d_index,
+                                     std::vector<HostShard> &out, std::vector<u64> &splitters, int verbose, char *errbuf, size_t errlen)
+{ const int W = (tv->kmer + 31) / 32, kbyte = (tv->kmer + 3) >> 2, pbyte = kbyte + 2 - tv->ibyte, rw = W + 1;
+  const bool trim = (opts->condition & SMG_COND_TRIM) != 0, symm = (opts->condition & SMG_COND_SYMM) != 0;
+  std::vector<int64_t> cut((size_t) n + 1);
+  multi_cuts(tv, n, cut.data());
+  int rc = SMG_OK;
+  out.assign((size_t) n, HostShard());
+  splitters.assign((size_t) (n > 1 ? n - 1 : 1) * W, 0);
+  auto load = [&](int s) -> int            // piece s of the input in the engine, trimmed
+  { const int64_t lo = cut[s], hi = cut[s + 1];
+    int r = decode_begin(e, tv->kmer, tv->ibyte, hi - lo, errbuf, errlen);
+    if (r) return r;
+    DecodeHook hk; hk.e = e; hk.d_index = d_index; hk.ibyte = tv->ibyte; hk.ibase = lo;
+    if ((r = ingest_records(tv, pbyte, lo, hi, NULL, opts->device, tv->host_threads, NULL, errbuf, errlen, decode_hook, &hk))) return r;
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(errbuf, errlen, SMG_ENODEV, "decode failed%s");
+    if (trim) { int64_t nn = 0; if ((r = smg_engine_condition(e, opts->ethresh, 1, 0, &nn, errbuf, errlen))) return r; }
+    return SMG_OK;
+  };
+  auto take = [&](int d) -> int            // the engine's table -> shard d on the host
+  { HostShard &h = out[(size_t) d];
+    h.n = e->n;
+    h.keys.resize((size_t) (e->n > 0 ? e->n : 0) * W); h.cnt.resize((size_t) (e->n > 0 ? e->n : 0));
+    if (e->n > 0 && (hipMemcpy(h.keys.data(), e->keys, sizeof(u64) * (size_t) e->n * W, hipMemcpyDeviceToHost) != hipSuccess
+                     || hipMemcpy(h.cnt.data(), e->cnt, sizeof(uint16_t) * (size_t) e->n, hipMemcpyDeviceToHost) != hipSuccess))
+      return fail(errbuf, errlen, SMG_ENODEV, "device to host copy failed%s");
+    return SMG_OK;
+  };
+  if (!symm)
+    { for (int s = 0; s < n && rc == SMG_OK; s++) { if ((rc = load(s)) == SMG_OK) rc = take(s); }
+      // (a splitter = the first k-mer a shard can hold: the prefix bucket its piece starts with, as for a conditioned table)
+      const int64_t ixlen = 1ll << (8 * tv->ibyte);
+      for (int sh = 1; sh < n; sh++)
+        { int64_t lo = 0, hi = ixlen;
+          while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (tv->prefix_index[m] > cut[sh]) hi = m; else lo = m + 1; }
+          splitters[(size_t) (sh - 1) * W] = lo >= ixlen ? ~0ull : (u64) lo << (64 - 8 * tv->ibyte);
+          if (lo >= ixlen) for (int w = 1; w < W; w++) splitters[(size_t) (sh - 1) * W + w] = ~0ull;
+        }
+      return rc;
+    }
+  const int bits = 2 * (tv->kmer / 2) < 12 ? (2 * (tv->kmer / 2) < 2 ? 2 : 2 * (tv->kmer / 2)) : 12, nbin = 1 << bits;
+  std::vector<int64_t> hist((size_t) 2 * nbin, 0), one((size_t) 2 * nbin, 0);
+  for (int s = 0; s < n && rc == SMG_OK; s++)                                  // sweep 1
+    { if ((rc = load(s))) break;
+      if ((rc = smg_engine_symm_hist(e, bits, one.data(), errbuf, errlen))) break;
+      for (int b = 0; b < 2 * nbin; b++) hist[(size_t) b] += one[(size_t) b];
+    }
+  if (rc) return rc;
+  { int64_t total = 0, acc = 0; int next = 1;
+    for (int b = 0; b < 2 * nbin; b++) total += hist[(size_t) b];
+    for (int b = 0; b < nbin && next < n; b++)
+      { while (next < n && acc >= total / n * next) { splitters[(size_t) (next - 1) * W] = (u64) b << (64 - bits); next++; }
+        acc += hist[(size_t) b] + hist[(size_t) nbin + b];
+      }
+    for (; next < n; next++) for (int w = 0; w < W; w++) splitters[(size_t) (next - 1) * W + w] = ~0ull;     // (nothing left for them)
+    if (total / n >= 0xFFFFFFF0ll - 16)
+      return fail(errbuf, errlen, SMG_EINVAL, "out of core: a shard of the closed table would hold more than 2^32 entries (more shards are needed)%s");
+  }
+  std::vector<std::vector<u64> > rec((size_t) n);
+  std::vector<int64_t> counts((size_t) n);
+  for (int s = 0; s < n && rc == SMG_OK; s++)                                  // sweep 2
+    { if ((rc = load(s))) break;
+      const int64_t n2 = 2 * e->n;
+      uint64_t *send = NULL;
+      if (hipMalloc(&send, sizeof(uint64_t) * (size_t) (n2 > 0 ? n2 : 1) * rw) != hipSuccess)
+        return fail(errbuf, errlen, SMG_ENOMEM, "out of device memory while symmetrising%s");
+      rc = smg_engine_symm_route(e, (const uint64_t *) splitters.data(), n, send, n2, counts.data(), errbuf, errlen);
+      int64_t off = 0;
+      for (int d = 0; d < n && rc == SMG_OK; d++)
+        { const size_t at = rec[(size_t) d].size(), words = (size_t) counts[(size_t) d] * rw;
+          rec[(size_t) d].resize(at + words);
+          if (words && hipMemcpy(rec[(size_t) d].data() + at, send + (size_t) off * rw, sizeof(uint64_t) * words, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(errbuf, errlen, SMG_ENODEV, "device to host copy failed%s");
+          off += counts[(size_t) d];
+        }
+      hipFree(send);
+    }
+  for (int d = 0; d < n && rc == SMG_OK; d++)                                  // every destination: sort + dedupe, out to the host
+    { const int64_t nrecv = (int64_t) (rec[(size_t) d].size() / (size_t) rw);
+      uint64_t *recv = NULL;
+      if (hipMalloc(&recv, sizeof(uint64_t) * (size_t) (nrecv > 0 ? nrecv : 1) * rw) != hipSuccess)
+        return fail(errbuf, errlen, SMG_ENOMEM, "out of device memory while symmetrising%s");
+      if (nrecv && hipMemcpy(recv, rec[(size_t) d].data(), sizeof(uint64_t) * (size_t) nrecv * rw, hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(errbuf, errlen, SMG_ENODEV, "host to device copy failed%s");
+      std::vector<u64>().swap(rec[(size_t) d]);
+      int64_t nn = 0;
+      if (rc == SMG_OK) rc = smg_engine_symm_finish(e, recv, nrecv, &nn, errbuf, errlen);
+      hipFree(recv);
+      if (rc == SMG_OK) rc = take(d);
+    }
+  if (rc == SMG_OK && verbose)
+    { int64_t tot = 0; for (int d = 0; d < n; d++) tot += out[(size_t) d].n;
+      fprintf(stderr, "  [smg] conditioned out of core: %lld -> %lld k-mers in %d prefix shards kept in host memory (%s%s)\n", (long long) tv->nels,
+              (long long) tot, n, trim ? "trimmed, " : "", "closed under reverse complement");
+    }
+  return rc;
+}
+
 static int host_run_sequential(const smg_table_source *tv, const smg_opts *opts, int nshards, int64_t *plot, smg_stats *stats,
                                char *errbuf, size_t errlen, const uint16_t *labels = NULL, uint64_t **records = NULL,
                                int64_t *nrec_out = NULL, int *rec_words = NULL)
 { const int W = (tv->kmer + 31) / 32, kbyte = (tv->kmer + 3) >> 2, pbyte = kbyte + 2 - tv->ibyte;
   if (tv->kmer > FAST_MAX_K)
     return fail(errbuf, errlen, SMG_EINVAL, "a table of k > 85 that does not fit the device is not supported (its degrees need all shards at once)%s");
-  if (opts->condition)
-    return fail(errbuf, errlen, SMG_EINVAL, "a raw table that does not fit the device: condition it first (smg_condition), then run hetmers%s");
   if (nshards < 2) nshards = 2;
   if (nshards > SMG_MAXGPU) nshards = SMG_MAXGPU;            // (the router groups by at most 16 destinations)
   const int symcheck = opts->symcheck == SMG_SYM_NONE ? SMG_SYM_HASH : opts->symcheck;
   const int n = nshards;
+  const bool raw = opts->condition != 0;   // the shards come out of host_condition_sequential (host memory), not out of the part files
+  std::vector<HostShard> hshard;
   std::vector<int64_t> cut((size_t) n + 1), counts((size_t) n * n, 0), nreq((size_t) n, 0);
   std::vector<uint8_t *> codes((size_t) n, (uint8_t *) NULL);
   std::vector<uint64_t *> send((size_t) n, (uint64_t *) NULL);
@@ -475,6 +588,7 @@ static int host_run_sequential(const smg_table_source *tv, const smg_opts *opts,
   for (int sh = 0; sh < n; sh++)          // (a forced shard count -- SMG_SEQUENTIAL_SHARDS -- may leave a shard too large to index)
     if (cut[sh + 1] - cut[sh] >= 0xFFFFFFF0ll - 16)
       return fail(errbuf, errlen, SMG_EINVAL, "out of core: a shard of more than 2^32 entries (more shards are needed)%s");
+  if (!raw)
   { // a splitter = the prefix bucket a shard starts with (cuts are bucket boundaries): everything in front is smaller
     const int64_t ixlen = 1ll << (8 * tv->ibyte);
     for (int sh = 1; sh < n; sh++)
@@ -507,14 +621,22 @@ static int host_run_sequential(const smg_table_source *tv, const smg_opts *opts,
   h_plot = (int64_t *) malloc(sizeof(int64_t) * SMG_PLOT_CELLS);
   if (!h_plot) SBAIL(SMG_ENOMEM, "out of host memory")
   memset(plot, 0, sizeof(int64_t) * SMG_PLOT_CELLS);
+  if (raw && (rc = host_condition_sequential(tv, opts, n, e, d_index, hshard, splitters, opts->verbose, errbuf, errlen))) goto done;
   for (int round = 1; round <= 2 && rc == SMG_OK; round++)
     for (int sh = 0; sh < n && rc == SMG_OK; sh++)
-      { const int64_t lo = cut[sh], hi = cut[sh + 1], ns = hi - lo;
+      { const int64_t lo = cut[sh], hi = cut[sh + 1], ns = raw ? hshard[(size_t) sh].n : hi - lo;
         if ((rc = decode_begin(e, tv->kmer, tv->ibyte, ns, errbuf, errlen))) break;
-        { DecodeHook hk; hk.e = e; hk.d_index = d_index; hk.ibyte = tv->ibyte; hk.ibase = lo;
-          if ((rc = ingest_records(tv, pbyte, lo, hi, NULL, opts->device, tv->host_threads, NULL, errbuf, errlen, decode_hook, &hk))) break;
-        }
-        if ((rc = smg_engine_set_prefix_index(e, d_index, tv->ibyte, lo, errbuf, errlen))) break;
+        if (raw)                           // a conditioned shard from host memory (it has no prefix index: pass 1 / k_directory build a directory)
+          { const HostShard &h = hshard[(size_t) sh];
+            if (ns > 0 && (hipMemcpy(e->own_keys, h.keys.data(), sizeof(u64) * (size_t) ns * W, hipMemcpyHostToDevice) != hipSuccess
+                           || hipMemcpy(e->own_cnt, h.cnt.data(), sizeof(uint16_t) * (size_t) ns, hipMemcpyHostToDevice) != hipSuccess))
+              SBAIL(SMG_ENODEV, "host to device copy failed")
+          }
+        else
+          { DecodeHook hk; hk.e = e; hk.d_index = d_index; hk.ibyte = tv->ibyte; hk.ibase = lo;
+            if ((rc = ingest_records(tv, pbyte, lo, hi, NULL, opts->device, tv->host_threads, NULL, errbuf, errlen, decode_hook, &hk))) break;
+            if ((rc = smg_engine_set_prefix_index(e, d_index, tv->ibyte, lo, errbuf, errlen))) break;
+          }
         if (hipStreamSynchronize(e->stream) != hipSuccess) SBAIL(SMG_ENODEV, "decode failed")
         if (round == 1)
           { e->bm_want = 32;

@@ -88,12 +88,13 @@ def test_parity_block_against_a_golden(tmp_path, monkeypatch):
     smu = engine.smu_text(plot.numpy().reshape(engine.PLOT_ROWS, engine.PLOT_COLS))
     assert smu == "12\t18\t8\n25\t26\t2\n"
     (tmp_path / "bench_uniform.smu").write_text(smu)
-    tab = {"uniform": {"genome": 1000, "k": 31, "entries": 99, "table_hash": sd.table_hash_text(99, 5, 6), "smu_file": "bench_uniform.smu",
+    key = bench.golden_key("uniform", 1000, 31)            # (not the default size: <workload>_k<k>_<genome>Mbp)
+    tab = {key: {"workload": "uniform", "genome": 1000, "k": 31, "entries": 99, "table_hash": sd.table_hash_text(99, 5, 6), "smu_file": "bench_uniform.smu",
                        "smu_sha256": hashlib.sha256(smu.encode()).hexdigest()}}
     (tmp_path / "bench_tables.json").write_text(json.dumps(tab))
     monkeypatch.setattr(bench, "GOLDEN_DIR", str(tmp_path))
     p = bench.parity_against_golden("uniform", 1000, 31, 99, 5, 6, plot)
-    assert p["ok"] is True and p["smu_sha256"] == tab["uniform"]["smu_sha256"]
+    assert p["ok"] is True and p["smu_sha256"] == tab[key]["smu_sha256"]
     plot[51 * engine.PLOT_COLS + 25] = 3
     assert bench.parity_against_golden("uniform", 1000, 31, 99, 5, 6, plot)["ok"] is False
     plot[51 * engine.PLOT_COLS + 25] = 2
@@ -109,7 +110,7 @@ def test_committed_bench_goldens_are_consistent():
     import bench
     tab = json.load(open(tj))
     for wl, g in tab.items():
-        assert g["genome"] == bench.default_genome(wl) and g["k"] == bench.default_k(wl)
+        assert bench.golden_key(g["workload"], g["genome"], g["k"]) == wl       # (the default size and k of a workload, or <w>_k<k>_<G>Mbp)
         smu = open(os.path.join(ROOT, "tests", "golden", g["smu_file"])).read()
         assert hashlib.sha256(smu.encode()).hexdigest() == g["smu_sha256"]
         assert g["engine_identical"] is True

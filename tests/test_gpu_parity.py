@@ -1343,8 +1343,8 @@ def test_out_of_core_shards_one_after_the_other(name, nshards, mode, monkeypatch
 
 def test_out_of_core_mode_is_chosen_from_the_free_memory_and_says_what_it_cannot_do(monkeypatch, tmp_path):
     """SMG_HBM_LIMIT (bytes) stands in for the free device memory: the executable picks the number of shards itself and says
-    so; a raw table, k > 85 and a table that is not closed get a precise refusal instead of a wrong answer (the extract leg runs
-    out of core since round 5: tests/test_extract.py)"""
+    so; k > 85 and a table that is not closed get a precise refusal instead of a wrong answer (the extract leg runs out of core
+    since round 5: tests/test_extract.py; a RAW table since round 6: test_raw_table_out_of_core below)"""
     g = load_golden("k31_i3_p4")
     n = len(g["counts"])
     ktab.write_ktab(str(tmp_path / "t"), g["k"], g["packed"], g["counts"], ibyte=g["ibyte"], nparts=g["nparts"])
@@ -1364,8 +1364,48 @@ def test_out_of_core_mode_is_chosen_from_the_free_memory_and_says_what_it_cannot
     keep = np.ones(len(cnt), bool); keep[len(cnt) // 2] = False
     with pytest.raises(engine.EngineError, match="not closed under reverse complement"):
         engine.hetmers_run(table_from(packed[keep], cnt[keep], 31), symcheck="hash")
-    with pytest.raises(engine.EngineError, match="condition it first"):
-        engine.hetmers_run(table_from(packed, cnt, 31), symcheck="hash", condition=engine.COND_TRIM if hasattr(engine, "COND_TRIM") else 1, ethresh=6)
+
+
+@pytest.mark.parametrize("shards", [2, 3, 5])
+@pytest.mark.parametrize("name", ["k31_i1", "k31_i3_p4", "k21_i2_p2", "k51_i1_p3", "k32_i1_p2", "k65_i1", "k17_i1"])
+def test_raw_table_out_of_core(name, shards, monkeypatch):
+    """PloidyPlot.c:931-1038 + 1381-1414: the reference conditions and streams a table of any size.  A RAW table (canonical
+    k-mers, some below the threshold) that does not fit the device: trimmed and closed under reverse complement shard by shard
+    (host_condition_sequential: two sweeps over the part files, the conditioned shards kept in host memory), then run out of
+    core from there -- the plot must be the oracle's on the numpy-conditioned table, whatever the number of shards."""
+    k, L, (rp, rcnt), (cp, cc) = _golden_raw(name)
+    want = brute.hetmers_plot(cp, cc, k)
+    assert want.sum() > 0
+    monkeypatch.setenv("SMG_SEQUENTIAL_SHARDS", str(shards))
+    for mode in ("hash", "exact"):
+        plot, st = engine.hetmers_run(table_from(rp, rcnt, k), symcheck=mode, condition=engine.COND_TRIM | engine.COND_SYMM, ethresh=L)
+        assert st["path"] == 1 and st["nels"] == len(cc), (name, shards, mode)
+        assert np.array_equal(plot, want), (name, shards, mode)
+    # trim only (a table that is closed but not trimmed), symmetrise only
+    sp, sc = ktab.symmetrize(rp, rcnt, k)
+    keep = sc >= L
+    plot, st = engine.hetmers_run(table_from(sp, sc, k), symcheck="hash", condition=engine.COND_TRIM, ethresh=L)
+    assert np.array_equal(plot, brute.hetmers_plot(sp[keep], sc[keep], k)) and st["nels"] == int(keep.sum())
+    keep = rcnt >= L
+    plot, st = engine.hetmers_run(table_from(rp[keep], rcnt[keep], k), symcheck="hash", condition=engine.COND_SYMM, ethresh=L)
+    assert np.array_equal(plot, want) and st["nels"] == len(cc)
+
+
+def test_raw_table_out_of_core_through_the_executable_picks_its_shards_from_the_memory(tmp_path):
+    """the drop-in on a raw table with SMG_HBM_LIMIT standing in for a small device: it says that it conditions out of core, and the
+    .smu is the reference binary's on the numpy-conditioned table"""
+    from conftest import REF_BIN
+    k, L, (rp, rcnt), (cp, cc) = _golden_raw("k31_i3_p4")
+    ktab.write_ktab(str(tmp_path / "raw"), k, rp, rcnt, ibyte=3, nparts=3)
+    ktab.write_ktab(str(tmp_path / "cond"), k, cp, cc, ibyte=3, nparts=2)
+    n2 = 2 * len(rcnt)
+    env = dict(os.environ, SMG_HBM_LIMIT=str(int(n2 * 3.4 + n2 / 3 * 54 + 1000)))      # a third of the closed table at a time
+    r = subprocess.run([HETMERS_BIN, f"-e{L}", "-T4", "-v", "-ogpu", "raw"], cwd=tmp_path, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "prefix shards one after the other" in r.stderr and "conditioned out of core" in r.stderr
+    q = subprocess.run([REF_BIN, f"-e{L}", "-T4", "-oref", "cond"], cwd=tmp_path, capture_output=True, text=True)
+    assert q.returncode == 0, q.stderr
+    assert (tmp_path / "gpu.smu").read_text() == (tmp_path / "ref.smu").read_text() != ""
 
 
 # ---- the bench tables at FULL size against the reference binary's output (tests/golden/bench_*.smu) ------------------------
@@ -1381,7 +1421,7 @@ def _bench_golden(workload):
     return g
 
 
-@pytest.mark.parametrize("workload", ["uniform", "octoploid", "hexaploid", "repeats"])
+@pytest.mark.parametrize("workload", ["uniform", "octoploid", "hexaploid", "repeats", "uniform_k30_1000Mbp", "uniform_k51_500Mbp"])
 def test_full_size_bench_table_vs_reference_golden(workload, tmp_path):
     """BASELINE.md section 3's gate where the driver can see it: the table `bench.py --workload <w>` times (BASELINE
     configs[2]: 2 535 258 108 entries at k = 31; the octoploid / hexaploid k = 51 stand-ins of configs[3] / [4]; the repeats
@@ -1395,7 +1435,8 @@ def test_full_size_bench_table_vs_reference_golden(workload, tmp_path):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     from smudgeplot_amd import sharded, synth_device
-    g = _bench_golden(workload)
+    g = _bench_golden(workload)              # (the key of the golden: a workload, or <workload>_k<k>_<genome>Mbp for the k = 30 / 51 lines)
+    workload = g["workload"]
     dev = torch.device("cuda:0")
     if torch.cuda.mem_get_info(dev)[1] < 250e9:
         pytest.skip("needs a 288 GB device")
@@ -1412,7 +1453,7 @@ def test_full_size_bench_table_vs_reference_golden(workload, tmp_path):
         assert st["path"] == 1
         assert engine.smu_text(plot.cpu().numpy().reshape(1001, 501)) == g["smu"]
     del eng, plot, index
-    if workload != "uniform":
+    if workload != "uniform" or k != 31:
         return
     synth_device.write_table_from_device(str(tmp_path / "t"), keys, cnt, k, nparts=4)
     del keys, cnt

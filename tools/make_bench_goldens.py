@@ -2,7 +2,8 @@
 """Golden .smu files of the bench tables, made by the REFERENCE binary (oracle/_ref/hetmers_ref = PloidyPlot.c compiled from
 the reference's own sources) on the GPU box:
 
-   tools/make_bench_goldens.py [outdir] [workload ...]        default: gpurun_out/goldens, all four bench workloads
+   tools/make_bench_goldens.py [outdir] [workload[@genome][:k] ...]        default: gpurun_out/goldens, all four bench workloads
+                                                                            (e.g. uniform:30, uniform@5e8:51 -- the k = 30 / k = 51 lines)
 
 For every workload of bench.py at its default size: the bench's generator puts the table into HBM, its checksum is taken
 (synth_device.table_hash), the engine runs on the resident table, the table is written as a FastK table from the device and
@@ -26,14 +27,20 @@ ref = os.path.join(ROOT, "oracle", "_ref", "hetmers_ref")
 cores = min(64, os.cpu_count() or 1)
 tmp = os.environ.get("E2E_TMP") or tempfile.gettempdir()
 jobs, meta = [], {}
-for wl in workloads:
-    G, k = bench.default_genome(wl), bench.default_k(wl)
+for spec in workloads:
+    wl, G, k = spec, None, None
+    if ":" in wl: wl, k = wl.split(":"); k = int(k)
+    if "@" in wl: wl, G = wl.split("@"); G = int(float(G))
+    k = k or bench.default_k(wl)
+    G = G or bench.default_genome(wl, k)
+    name = wl
+    wl_name = bench.golden_key(wl, G, k)
     t0 = time.time()
     keys, cnt, L, desc = bench.make_table(wl, G, k, dev)
     torch.cuda.synchronize()
     n = cnt.numel()
     hk, hc = synth_device.table_hash(keys, cnt)
-    m = {"workload": wl, "genome": G, "k": k, "L": L, "entries": int(n), "description": desc,
+    m = {"workload": wl, "key": wl_name, "genome": G, "k": k, "L": L, "entries": int(n), "description": desc,
          "table_hash": synth_device.table_hash_text(n, hk, hc), "generate_s": round(time.time() - t0, 1)}
     eng = sharded.TorchEngine(dev)
     plot, st = sharded.hetmers_sharded(k, keys.reshape(-1), cnt, symcheck="hash", eng=eng)
@@ -41,16 +48,16 @@ for wl in workloads:
     m["engine_smu"] = engine.smu_text(plot.cpu().numpy().reshape(1001, 501))
     m["engine_path"] = int(st.get("path", 0))
     del eng, plot
-    d = tempfile.mkdtemp(prefix="smg_gold_" + wl, dir=tmp)
+    d = tempfile.mkdtemp(prefix="smg_gold_" + wl_name, dir=tmp)
     t0 = time.time()
     m["table_bytes"] = synth_device.write_table_from_device(os.path.join(d, "t"), keys, cnt, k, nparts=4)
     m["write_s"] = round(time.time() - t0, 1)
     del keys, cnt
     torch.cuda.empty_cache()
     p = subprocess.Popen([ref, f"-e{L}", f"-T{cores}", "-oref", "t.ktab"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    jobs.append((wl, d, p, time.time()))
-    meta[wl] = m
-    print(f"[goldens] {wl}: {n} entries, table {m['table_hash']}, reference started", file=sys.stderr, flush=True)
+    jobs.append((wl_name, d, p, time.time()))
+    meta[wl_name] = m
+    print(f"[goldens] {wl_name}: {n} entries, table {m['table_hash']}, reference started", file=sys.stderr, flush=True)
 
 table = {}
 for wl, d, p, t0 in jobs:
@@ -72,6 +79,9 @@ for wl, d, p, t0 in jobs:
     table[wl] = m
     shutil.rmtree(d, ignore_errors=True)
     print(f"[goldens] {wl}: {m['smu_bytes']} bytes, engine identical: {m['engine_identical']}", file=sys.stderr, flush=True)
-with open(os.path.join(outdir, "bench_tables.json"), "w") as f:
+old = os.path.join(outdir, "bench_tables.json")
+if os.path.exists(old):                      # (goldens made earlier stay: this call adds or replaces its own)
+    table = dict(json.load(open(old)), **table)
+with open(old, "w") as f:
     json.dump(table, f, indent=1)
 print(json.dumps({w: {kk: v for kk, v in m.items() if kk in ("entries", "table_hash", "smu_sha256", "engine_identical", "error")} for w, m in table.items()}, indent=1))
