@@ -1421,7 +1421,7 @@ def _bench_golden(workload):
     return g
 
 
-@pytest.mark.parametrize("workload", ["uniform", "octoploid", "hexaploid", "repeats", "uniform_k30_1000Mbp", "uniform_k51_500Mbp"])
+@pytest.mark.parametrize("workload", ["uniform", "octoploid", "hexaploid", "repeats", "uniform_k30_1000Mbp", "uniform_k51_500Mbp", "uniform_k51_1000Mbp"])
 def test_full_size_bench_table_vs_reference_golden(workload, tmp_path):
     """BASELINE.md section 3's gate where the driver can see it: the table `bench.py --workload <w>` times (BASELINE
     configs[2]: 2 535 258 108 entries at k = 31; the octoploid / hexaploid k = 51 stand-ins of configs[3] / [4]; the repeats
@@ -1445,8 +1445,10 @@ def test_full_size_bench_table_vs_reference_golden(workload, tmp_path):
     n = cnt.numel()
     assert n == g["entries"]
     assert synth_device.table_hash_text(n, *synth_device.table_hash(keys, cnt)) == g["table_hash"]
-    eng = sharded.TorchEngine(dev)
     index = torch.cumsum(torch.bincount(((keys if keys.dim() == 1 else keys[:, 0]) >> 40) & 0xFFFFFF, minlength=1 << 24), 0)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()        # (the generator's scratch goes back to the driver: the engine allocates outside torch's pool, as in bench.py)
+    eng = sharded.TorchEngine(dev)
     eng.bind(k, keys.reshape(-1), cnt, index=index)
     for _ in range(2):          # (the second run takes the queued, read-nothing-back form of smg_engine_run)
         plot, st = sharded.hetmers_sharded(k, keys.reshape(-1), cnt, symcheck="hash", eng=eng, prebound=True)
