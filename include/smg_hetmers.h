@@ -180,8 +180,8 @@ int smg_engine_decode(smg_engine *e, int kmer, int ibyte, int64_t nels,
    d_counts= nels uint16.
    While a table is bound its K-MERS must not change (the engine keeps what it has learnt about them between runs: the
    first and the last k-mer, the directory made of the table's prefix index); its COUNTS may -- every run reads them
-   again, and a run that was queued from the counts of the run before (smg_engine_run on the same table, replayed
-   phase steps) notices the difference and is repeated the plain way.  Bind again after changing k-mers.            */
+   again, and a step that was queued from the counts of the step before (replayed phase steps, below) notices the
+   difference and is repeated the plain way.  Bind again after changing k-mers.                                     */
 int smg_engine_bind(smg_engine *e, int kmer, int64_t nels, const uint64_t *d_keys,
                     const uint16_t *d_counts, char *errbuf, size_t errlen);
 

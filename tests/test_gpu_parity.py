@@ -1321,7 +1321,7 @@ def test_a_rerun_on_the_same_engine_takes_nothing_for_granted_that_it_does_not_c
     tc.copy_(torch.from_numpy(cnt3.view(np.int16).copy()))
     plot, st = sharded.hetmers_sharded(k, tk, tc, symcheck="hash", eng=eng, prebound=True)
     assert st["path"] == 2 and np.array_equal(plot.cpu().numpy().reshape(1001, 501), brute.hetmers_plot(ktab.u64_to_packed(keys, k), cnt3, k))
-    tc.copy_(torch.from_numpy(cnt.view(np.int16).copy()))    # back to the first table: the plain path, then speculative again
+    tc.copy_(torch.from_numpy(cnt.view(np.int16).copy()))    # back to the first table
     for _ in range(2):
         plot, st = sharded.hetmers_sharded(k, tk, tc, symcheck="hash", eng=eng, prebound=True)
         assert st["path"] == 1 and np.array_equal(plot.cpu().numpy().reshape(1001, 501), want)
@@ -1450,7 +1450,7 @@ def test_full_size_bench_table_vs_reference_golden(workload, tmp_path):
     torch.cuda.empty_cache()        # (the generator's scratch goes back to the driver: the engine allocates outside torch's pool, as in bench.py)
     eng = sharded.TorchEngine(dev)
     eng.bind(k, keys.reshape(-1), cnt, index=index)
-    for _ in range(2):          # (the second run takes the queued, read-nothing-back form of smg_engine_run)
+    for _ in range(2):          # (an engine is reused by every bench step: the second run must give the same)
         plot, st = sharded.hetmers_sharded(k, keys.reshape(-1), cnt, symcheck="hash", eng=eng, prebound=True)
         assert st["path"] == 1
         assert engine.smu_text(plot.cpu().numpy().reshape(1001, 501)) == g["smu"]
