@@ -1825,6 +1825,22 @@ static int fast_resume(smg_engine *e, const uint8_t *d_codes, int with_meta, cha
   return SMG_OK;
 }
 
+// the same for k > 85 (round 6): the byte a shard left behind is its array of counted degrees (S_all of every entry, uint8 with the
+// reference's wrap); the look-ups of the received requests add S_hi of the complements on top (k_apply) and pass 2 reads the sums
+static int counted_prepare(smg_engine *e, char *errbuf, size_t errlen);
+static int counted_resume(smg_engine *e, const uint8_t *d_degs, char *errbuf, size_t errlen)
+{ HIPCHK(hipSetDevice(e->device));
+  int rc = counted_prepare(e, errbuf, errlen);               // control words, geometry, zeroed degrees, directory
+  if (rc) return rc;
+  if (e->n > 0) HIPCHK(hipMemcpyAsync(e->deg, d_degs, (size_t) e->n, hipMemcpyDeviceToDevice, e->stream));
+  e->rw = e->W + 1;
+  e->lookup_pending = false; e->n_chunks = 0; e->bm_bits = 0; e->filtered = false; e->presorted = 0;
+  e->st.nrequests = 0; e->st.ms_rclookup = 0; e->st.path = 1;
+  memset(e->fp, 0, sizeof(e->fp));
+  e->prepared = true;
+  return SMG_OK;
+}
+
 // ---- public phase API (sharded runs) ------------------------------------------------------------
 // k <= 85: the fast path.  k > 85: the counted path in the same steps (counted_phase_* below) -- pass 1 leaves ONE flat
 // list of (rc(x), count | S_hi << 16) records, presented to the router as full chunks; no block map, nothing is filtered.
@@ -2786,7 +2802,7 @@ static int host_run(const smg_table_source *tv, const smg_opts *opts, int64_t *p
       { const int W = (tv->kmer + 31) / 32;
         int seq = 0;
         { const char *sv = getenv("SMG_SEQUENTIAL_SHARDS"); if (sv && atoi(sv) > 1) seq = atoi(sv); }
-        if (!seq && tv->kmer <= FAST_MAX_K)
+        if (!seq)
           { size_t fr = 0, tot = 0;
             double limit = 0;
             { const char *hl = getenv("SMG_HBM_LIMIT"); if (hl && atof(hl) > 0) limit = atof(hl); }
@@ -2803,7 +2819,7 @@ static int host_run(const smg_table_source *tv, const smg_opts *opts, int64_t *p
               { // what a shard leaves behind: its code bytes and its requests -- every entry's (W + 1 words) under the exact
                 // proof, those of the owners of a pair at p > k-1-p otherwise (17 % of a diploid table, 36 % of a polyploid one)
                 const bool exact = symcheck == SMG_SYM_EXACT;
-                const double keep = ne * (1.0 + (exact ? 8.0 * (W + 1) : 0.36 * 8.0 * W));
+                const double keep = ne * (1.0 + (exact ? 8.0 * (W + 1) : 0.36 * 8.0 * (tv->kmer > FAST_MAX_K ? W + 1 : W)));     // (k > 85: records carry a count word)
                 for (int q = 2; q <= SMG_MAXGPU && !seq; q++)
                   if (keep + ne / q * per_run <= limit && ne / q * per_cond <= limit && ne / q < 0xFFFFFFF0ll - 16) seq = q;     // (no map out of core)
                 if (!seq)

@@ -454,8 +454,9 @@ static void multi_cuts(const smg_table_source *tv, int n, int64_t *cut)
 //            not been read yet), requests grouped by destination, code bytes and requests kept, k-mers dropped;
 //   round 2, shard by shard: read + decode again (the reference reads its table ~2 (BLEVEL + 1) times), code bytes back, look-ups
 //            of all requests that name this shard, pass 2 into the one histogram.
-// Symmetry proof as everywhere: XOR of the shards' fingerprints, no look-up may miss.  A table that fails it, a table that
-// still has to be conditioned and k > 85 are refused with a precise message (condition the table with smg_condition first).
+// Symmetry proof as everywhere: XOR of the shards' fingerprints, no look-up may miss.  A table that fails it is refused with a
+// precise message (condition the table with smg_condition first).  Round 6: a table that still has to be conditioned is -- shard by
+// shard, host_condition_sequential below -- and k > 85 takes the same two rounds with the counted kernels (counted_resume).
 // The extract leg runs per shard in round 2 (the two members of a pair share a shard).
 // A RAW table out of core (round 6): Logex 'A[e-]' + Symmex (PloidyPlot.c:1381-1414) shard by shard.  The conditioned table
 // never exists on the device as a whole -- and not on disk either (the reference writes .trim / .symx tables into the working
@@ -572,8 +573,7 @@ static int host_run_sequential(const smg_table_source *tv, const smg_opts *opts,
                                char *errbuf, size_t errlen, const uint16_t *labels = NULL, uint64_t **records = NULL,
                                int64_t *nrec_out = NULL, int *rec_words = NULL)
 { const int W = (tv->kmer + 31) / 32, kbyte = (tv->kmer + 3) >> 2, pbyte = kbyte + 2 - tv->ibyte;
-  if (tv->kmer > FAST_MAX_K)
-    return fail(errbuf, errlen, SMG_EINVAL, "a table of k > 85 that does not fit the device is not supported (its degrees need all shards at once)%s");
+  const bool counted = tv->kmer > FAST_MAX_K;    // k > 85: the counted kernels in the same steps (what stays between the rounds is the degree byte)
   if (nshards < 2) nshards = 2;
   if (nshards > SMG_MAXGPU) nshards = SMG_MAXGPU;            // (the router groups by at most 16 destinations)
   const int symcheck = opts->symcheck == SMG_SYM_NONE ? SMG_SYM_HASH : opts->symcheck;
@@ -600,7 +600,7 @@ static int host_run_sequential(const smg_table_source *tv, const smg_opts *opts,
   }
   smg_engine *e = smg_engine_create(opts->device, NULL, errbuf, errlen);
   if (!e) return SMG_ENODEV;
-  e->no_filter = true;
+  e->no_filter = true;                    // (k <= 85: no candidate map out of core -- the filter would need the maps of the shards not read yet)
   // extract leg (round 5): the two members of a pair share a window block, hence a shard -- every shard lists the pairs behind
   // the labelled pixels while it is resident for its second round; the lists are only handed out if the whole table proves closed
   std::vector<uint64_t> xrec;
@@ -652,7 +652,7 @@ static int host_run_sequential(const smg_table_source *tv, const smg_opts *opts,
             ms_p1 += e->st.ms_pass1; nels += ns; nemit += e->st.nemitted;
           }
         else
-          { if ((rc = fast_resume(e, codes[sh], symcheck == SMG_SYM_EXACT, errbuf, errlen))) break;
+          { if ((rc = counted ? counted_resume(e, codes[sh], errbuf, errlen) : fast_resume(e, codes[sh], symcheck == SMG_SYM_EXACT, errbuf, errlen))) break;
             int64_t nrecv = 0;
             for (int t = 0; t < n; t++) nrecv += counts[(size_t) t * n + sh];
             if (hipMalloc(&recv, sizeof(uint64_t) * (size_t) (nrecv > 0 ? nrecv : 1) * rw) != hipSuccess)

@@ -1343,8 +1343,8 @@ def test_out_of_core_shards_one_after_the_other(name, nshards, mode, monkeypatch
 
 def test_out_of_core_mode_is_chosen_from_the_free_memory_and_says_what_it_cannot_do(monkeypatch, tmp_path):
     """SMG_HBM_LIMIT (bytes) stands in for the free device memory: the executable picks the number of shards itself and says
-    so; k > 85 and a table that is not closed get a precise refusal instead of a wrong answer (the extract leg runs out of core
-    since round 5: tests/test_extract.py; a RAW table since round 6: test_raw_table_out_of_core below)"""
+    so; a table that is not closed gets a precise refusal instead of a wrong answer (the extract leg runs out of core since
+    round 5: tests/test_extract.py; a RAW table and k > 85 since round 6: test_raw_table_out_of_core, test_out_of_core_above_k_85)"""
     g = load_golden("k31_i3_p4")
     n = len(g["counts"])
     ktab.write_ktab(str(tmp_path / "t"), g["k"], g["packed"], g["counts"], ibyte=g["ibyte"], nparts=g["nparts"])
@@ -1358,8 +1358,6 @@ def test_out_of_core_mode_is_chosen_from_the_free_memory_and_says_what_it_cannot
                        env=dict(os.environ, SMG_HBM_LIMIT=str(int(n * 3.0))))
     assert r.returncode == 1 and "does not fit the device even shard by shard" in r.stderr
     monkeypatch.setenv("SMG_SEQUENTIAL_SHARDS", "3")
-    with pytest.raises(engine.EngineError, match="k > 85"):
-        engine.hetmers_run(make_table(load_golden("k100_i1")), symcheck="hash")
     packed, cnt = synth.adversarial_table(31, 3000, 4, seed=5, low_complexity=40, dense=1)
     keep = np.ones(len(cnt), bool); keep[len(cnt) // 2] = False
     with pytest.raises(engine.EngineError, match="not closed under reverse complement"):
@@ -1389,6 +1387,28 @@ def test_raw_table_out_of_core(name, shards, monkeypatch):
     keep = rcnt >= L
     plot, st = engine.hetmers_run(table_from(rp[keep], rcnt[keep], k), symcheck="hash", condition=engine.COND_SYMM, ethresh=L)
     assert np.array_equal(plot, want) and st["nels"] == len(cc)
+
+
+@pytest.mark.parametrize("shards", [2, 3, 5])
+@pytest.mark.parametrize("name", ["k100_i1", "k100_wrap"])
+def test_out_of_core_above_k_85(name, shards, monkeypatch):
+    """k > 85 (the counted kernels: real uint8 degrees with the reference's wrap, PloidyPlot.c:163, 535) out of core: what a shard
+    leaves behind between its two rounds is its degree bytes; the goldens are the reference binary's, k100_wrap is the table on
+    which a degree really wraps.  Fresh tables and a raw one against the oracle as well."""
+    if name not in golden_names():
+        pytest.skip("no such golden")
+    g = load_golden(name)
+    monkeypatch.setenv("SMG_SEQUENTIAL_SHARDS", str(shards))
+    for mode in ("hash", "exact"):
+        plot, st = engine.hetmers_run(make_table(g), symcheck=mode)
+        assert st["path"] == 1 and engine.smu_text(plot) == g["smu"], (name, shards, mode)
+    for k, seed in ((96, 3), (128, 4)):
+        packed, cnt = synth.adversarial_table(k, 1500, 4, seed, low_complexity=60, dense=1)
+        plot, st = engine.hetmers_run(table_from(packed, cnt, k), symcheck="hash")
+        assert np.array_equal(plot, brute.hetmers_plot(packed, cnt, k)), (k, shards)
+    (rp, rcnt), (cp, cc) = _raw_table(97, 12, 5)
+    plot, st = engine.hetmers_run(table_from(rp, rcnt, 97), symcheck="hash", condition=engine.COND_TRIM | engine.COND_SYMM, ethresh=5)
+    assert np.array_equal(plot, brute.hetmers_plot(cp, cc, 97)) and st["nels"] == len(cc)
 
 
 def test_raw_table_out_of_core_through_the_executable_picks_its_shards_from_the_memory(tmp_path):
