@@ -136,9 +136,13 @@ def test_extract_fresh_tables_vs_oracle(k, seed):
 
 
 @pytest.mark.gpu
-def test_extract_on_raw_table_conditions_first(tmp_path):
+@pytest.mark.parametrize("seq", [0, 3], ids=["in-core", "out-of-core"])
+def test_extract_on_raw_table_conditions_first(seq, tmp_path, monkeypatch):
     """raw canonical table with erroneous k-mers: conditioned on the device, then extracted; compared with
-    the reference extract binary (or the numpy oracle) on the table conditioned by numpy"""
+    the reference extract binary (or the numpy oracle) on the table conditioned by numpy -- also when the table "does not
+    fit" and is conditioned and run shard by shard (round 6)"""
+    if seq:
+        monkeypatch.setenv("SMG_SEQUENTIAL_SHARDS", str(seq))
     k, L = 31, 6
     packed, cnt = synth.adversarial_table(k, 2500, L, 77, low_complexity=100, dense=1)
     rc = ktab.revcomp_packed(packed, k)
@@ -188,7 +192,7 @@ def test_extract_over_prefix_shards_matches_reference_golden(name, shards, monke
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shards", [2, 5])
-@pytest.mark.parametrize("name", ["k31_i1", "k51_i1_p3", "k65_i1"])
+@pytest.mark.parametrize("name", ["k31_i1", "k51_i1_p3", "k65_i1", "k100_i1", "k100_wrap"])       # (k > 85 out of core: round 6)
 def test_extract_out_of_core_matches_reference_golden(name, shards, monkeypatch):
     """... and over a table that does not fit the device (prefix shards one after the other, the table read twice: smg_multi.hpp,
     host_run_sequential): every shard lists the pairs behind the labelled pixels while it is resident for its second round"""

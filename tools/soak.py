@@ -29,7 +29,7 @@ for case in range(ncases):
     nparts = int(rng.integers(1, 4))
     shards = int(rng.choice([0, 0, 0, 2, 3, 7])) if (k <= 85 and mode != "none") else 0
     raw = bool(rng.random() < 0.25) and shards == 0
-    seq = int(rng.choice([0, 0, 2, 3, 5])) if (k <= 85 and mode != "none" and shards == 0) else 0       # out of core
+    seq = int(rng.choice([0, 0, 2, 3, 5])) if (mode != "none" and shards == 0) else 0       # out of core (round 6: any k, raw tables too)
     try:
         if seq:
             os.environ["SMG_SEQUENTIAL_SHARDS"] = str(seq)
