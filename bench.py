@@ -382,12 +382,19 @@ def main():
                 traffic_src = "stale: profiles/hbm_traffic.json was measured on code object %s, this library carries %s" % (
                     t.get("code_object_sha256_16"), lib_hash())
 
+    e2e_failure = None
     if rank == 0:
         parity = parity_against_golden(args.workload, G, args.k, n_total, hk, hc, plot)
         # the end-to-end comparison and the CPU baseline: rank 0 of the single-GPU run only (the reference takes about a minute)
         cpu = e2e = None
         if not (args.no_cpu or world > 1):
-            e2e, cpu = end_to_end(args.workload, int(args.e2e_genome) if args.e2e_genome else e2e_genome(args.workload, G), args.k, dev)
+            try:
+                e2e, cpu = end_to_end(args.workload, int(args.e2e_genome) if args.e2e_genome else e2e_genome(args.workload, G), args.k, dev)
+            except SystemExit as ex:
+                # (a missing reference binary or a failing program: the line of the timed region is still printed -- with the
+                #  error in place of the block -- and the process then FAILS with the message: loud, but no measurement is lost)
+                e2e_failure = str(ex)
+                e2e = {"error": e2e_failure, "smu_identical": None}
         value = n_total * args.steps / dt
         out = {
             "metric": "k-mers/sec through hetmers (k=%d)" % args.k,
@@ -424,6 +431,8 @@ def main():
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0 and e2e_failure is not None:
+        raise SystemExit(e2e_failure)
     if rank == 0 and e2e is not None and not e2e["smu_identical"]:
         raise SystemExit("bench.py: the drop-in executable's .smu differs from the reference binary's on the end-to-end table")
     if rank == 0 and parity["ok"] is False:

@@ -72,7 +72,11 @@ def test_bench_fails_loudly_without_the_reference_binary(tmp_path):
     finally:
         os.rename(hidden, ref)
     assert r.returncode != 0 and "hetmers_ref is missing" in r.stderr
-    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    # ... loudly, but without losing the measurement: the line of the timed region is printed, the error in place of the block
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["value"] > 0 and j["cpu_baseline"] is None and "hetmers_ref is missing" in j["e2e"]["error"]
 
 
 def test_bench_repeats_workload_reaches_the_rare_paths():
